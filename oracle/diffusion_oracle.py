@@ -1,0 +1,149 @@
+"""CPU restatement of the reference sampler (schedules in numpy fp64, updates in torch fp32).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Parity status: PINNED — checked against
+``/root/reference/diffusion`` run in the build container (``oracle/validate_oracle.py``,
+``oracle/VALIDATION.md``) and against the known answers / golden tables in ``tests/golden/``.
+
+Citations: ``gd:N`` = /root/reference/diffusion/gaussian_diffusion.py, ``rs:N`` = .../respace.py,
+``init:N`` = .../diffusion/__init__.py.
+"""
+import numpy as np
+import torch
+
+
+# ----------------------------------------------------------------------------- schedules
+def space_timesteps(num_timesteps: int, section_counts) -> list:
+    """rs:12-62.  Returns the SORTED retained indices.  ``round`` is Python's (banker's)."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return list(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(s) for s in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(section_counts))
+    start, kept = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        frac = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            kept.append(start + round(cur))
+            cur += frac
+        start += size
+    return sorted(set(kept))
+
+
+def named_betas(name: str, n: int) -> np.ndarray:
+    """gd:98-122 (``linear`` = Ho et al. scaled by 1000/n; ``squaredcos_cap_v2`` via gd:125-141)."""
+    if name == "linear":
+        scale = 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if name == "squaredcos_cap_v2":
+        import math
+        f = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.array([min(1 - f((i + 1) / n) / f(i / n), 0.999) for i in range(n)])
+    raise NotImplementedError(name)
+
+
+class Schedule:
+    """Tables of ``GaussianDiffusion.__init__`` (gd:153-201) for the respaced betas of
+    ``SpacedDiffusion.__init__`` (rs:73-87)."""
+
+    def __init__(self, timestep_respacing="", noise_schedule="linear", diffusion_steps=1000):
+        base_betas = named_betas(noise_schedule, diffusion_steps)
+        if timestep_respacing is None or timestep_respacing == "":
+            timestep_respacing = [diffusion_steps]                              # init:29-30
+        use = set(space_timesteps(diffusion_steps, timestep_respacing))
+        base_ac = np.cumprod(1.0 - base_betas, axis=0)
+        last, new_betas, self.timestep_map = 1.0, [], []
+        for i, ac in enumerate(base_ac):                                         # rs:80-85
+            if i in use:
+                new_betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        betas = np.array(new_betas, dtype=np.float64)
+        self.betas = betas
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = (
+            np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+            if self.num_timesteps > 1 else np.array([]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self.log_betas = np.log(betas)                                           # gd:293
+
+
+def _coef(arr: np.ndarray, i: int) -> torch.Tensor:
+    """gd:869-881: fp64 table entry cast to fp32 (then broadcast by the caller's arithmetic)."""
+    return torch.tensor(arr[i], dtype=torch.float64).float()
+
+
+# ----------------------------------------------------------------------------- per-step math
+def p_mean_variance(s: Schedule, model_out: torch.Tensor, x: torch.Tensor, i: int, clip_denoised=False):
+    """gd:254-336, EPSILON mean + LEARNED_RANGE variance (what create_diffusion builds, init:32-46).
+    ``model_out`` is [B,F,2C,H,W]; ``i`` is the respaced index."""
+    C = x.shape[2]
+    eps, v = torch.split(model_out, C, dim=2)                                    # gd:291
+    min_log = _coef(s.posterior_log_variance_clipped, i)
+    max_log = _coef(s.log_betas, i)
+    frac = (v + 1) / 2
+    log_var = frac * max_log + (1 - frac) * min_log                              # gd:296
+    x0 = _coef(s.sqrt_recip_alphas_cumprod, i) * x - _coef(s.sqrt_recipm1_alphas_cumprod, i) * eps
+    if clip_denoised:
+        x0 = x0.clamp(-1, 1)
+    mean = _coef(s.posterior_mean_coef1, i) * x0 + _coef(s.posterior_mean_coef2, i) * x
+    return {"mean": mean, "log_variance": log_var, "variance": torch.exp(log_var), "pred_xstart": x0}
+
+
+def p_sample(s, model_out, x, i, noise, clip_denoised=False):
+    """gd:380-421 (DDPM ancestral step); no noise at i == 0."""
+    out = p_mean_variance(s, model_out, x, i, clip_denoised)
+    mask = 0.0 if i == 0 else 1.0
+    sample = out["mean"] + mask * torch.exp(0.5 * out["log_variance"]) * noise
+    return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+
+
+def ddim_sample(s, model_out, x, i, noise=None, eta=0.0, clip_denoised=False):
+    """gd:517-564."""
+    out = p_mean_variance(s, model_out, x, i, clip_denoised)
+    x0 = out["pred_xstart"]
+    eps = (_coef(s.sqrt_recip_alphas_cumprod, i) * x - x0) / _coef(s.sqrt_recipm1_alphas_cumprod, i)
+    ab = _coef(s.alphas_cumprod, i)
+    ab_prev = _coef(s.alphas_cumprod_prev, i)
+    sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
+    mean_pred = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+    mask = 0.0 if i == 0 else 1.0
+    if noise is None:
+        noise = torch.zeros_like(x)
+    return {"sample": mean_pred + mask * sigma * noise, "pred_xstart": x0}
+
+
+def sample_loop(s: Schedule, model_fn, x: torch.Tensor, method="ddim", eta=0.0, noises=None,
+                clip_denoised=False, progressive=False):
+    """gd:423-515 / gd:604-684.  ``model_fn(x, t_original:int64[B]) -> [B,F,2C,H,W]``; the loop
+    index ``i`` is mapped through ``timestep_map`` exactly as ``_WrappedModel`` does (rs:125-130).
+    ``noises[k]`` is the noise used at the k-th executed step (k=0 is i=T-1) so both sides of a
+    parity run consume identical draws."""
+    trail = []
+    B = x.shape[0]
+    for k, i in enumerate(range(s.num_timesteps - 1, -1, -1)):
+        t = torch.full((B,), s.timestep_map[i], dtype=torch.int64)
+        out = model_fn(x, t)
+        nz = None if noises is None else noises[k]
+        if method == "ddim":
+            r = ddim_sample(s, out, x, i, nz, eta, clip_denoised)
+        else:
+            r = p_sample(s, out, x, i, nz if nz is not None else torch.zeros_like(x), clip_denoised)
+        x = r["sample"]
+        if progressive:
+            trail.append(r)
+    return (x, trail) if progressive else x

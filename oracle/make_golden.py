@@ -1,0 +1,129 @@
+"""Generate ``tests/golden/*.npz`` by running the REAL reference (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage:  python -m oracle.make_golden
+The fixtures are outputs of /root/reference code (models/latte.py via the timm stand-in,
+diffusion/* unmodified); the oracle restatement and the HIP engine are both tested against them.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle.reference_loader import (load_reference_diffusion, load_reference_latte,
+                                     randomize_zero_init)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=4,
+            num_classes=5, extras=2, learn_sigma=True)
+TINY4 = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=16,
+             num_classes=1000, extras=1, learn_sigma=True)
+
+TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+          "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+          "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+def schedules(rd):
+    kat = {}
+    arrays = {}
+    for spec in ["", "1000", "250", "100", "50", "25", "10", "5", "1", "ddim250", "ddim100", "ddim50",
+                 "ddim10", "10,15,20", "1,1,1", "333"]:
+        d = rd.create_diffusion(spec)
+        tm = np.asarray(d.timestep_map, dtype=np.int64)
+        kat[spec] = {"n": int(d.num_timesteps), "sha256": hashlib.sha256(tm.tobytes()).hexdigest(),
+                     "head": tm[:6].tolist(), "tail": tm[-4:].tolist()}
+        arrays[f"map::{spec}"] = tm
+        if spec in ("250", "10", "50", "ddim250", ""):
+            for name in TABLES:
+                arrays[f"{name}::{spec}"] = np.asarray(getattr(d, name), dtype=np.float64)
+            arrays[f"log_betas::{spec}"] = np.log(d.betas)
+    # other diffusion_steps / schedule names through the same factory (init:10-20)
+    d = rd.create_diffusion("20", noise_schedule="squaredcos_cap_v2", diffusion_steps=400)
+    arrays["map::cos400/20"] = np.asarray(d.timestep_map, dtype=np.int64)
+    arrays["betas::cos400/20"] = d.betas
+    arrays["alphas_cumprod::cos400/20"] = d.alphas_cumprod
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **arrays)
+    with open(os.path.join(OUT, "schedules_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+
+
+def tiny_model(rl, rd, name, kw, use_cfg, seed):
+    torch.manual_seed(seed)
+    model = rl.Latte(**kw).eval()
+    randomize_zero_init(model, seed=seed + 1)
+    # the reference zero-inits every Linear bias; give them signal too so bias paths are tested
+    g = torch.Generator("cpu").manual_seed(seed + 2)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith(".bias") and float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator("cpu").manual_seed(seed + 3)
+    B, Fr, C, S = 2, kw["num_frames"], 4, kw["input_size"]
+    x = torch.randn(B, Fr, C, S, S, generator=g)
+    t = torch.tensor([999, 37], dtype=torch.int64)
+    out = {"cfg_json": np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8)}
+    for k, v in sd.items():
+        out["sd::" + k] = v.numpy()
+    out["x"] = x.numpy()
+    out["t"] = t.numpy()
+    with torch.no_grad():
+        if kw["extras"] == 2:
+            y = torch.tensor([3, 1], dtype=torch.int64)
+            out["y"] = y.numpy()
+            out["forward"] = model(x, t, y=y).numpy()
+            # classifier-free guidance batch as sample.py:88-94 builds it
+            xc = torch.cat([x[:1], x[:1]], 0)
+            yc = torch.tensor([3, kw["num_classes"]], dtype=torch.int64)
+            out["x_cfg"], out["y_cfg"] = xc.numpy(), yc.numpy()
+            out["cfg_scale"] = np.float32(7.0)
+            out["forward_with_cfg"] = model.forward_with_cfg(xc, t, y=yc, cfg_scale=7.0).numpy()
+        else:
+            out["forward"] = model(x, t).numpy()
+
+        # sampling loops (sample.py:100-107): clip_denoised=False, explicit noise=z
+        steps = 5
+        diff = rd.create_diffusion(str(steps))
+        if use_cfg:
+            z = out["x_cfg"]
+            z = torch.from_numpy(z)
+            fn = model.forward_with_cfg
+            mk = dict(y=torch.from_numpy(out["y_cfg"]), cfg_scale=7.0)
+        else:
+            z = x
+            fn = model.forward
+            mk = dict(y=torch.from_numpy(out["y"])) if kw["extras"] == 2 else dict(y=None)
+        out["loop_steps"] = np.int64(steps)
+        for method, gen in (("ddim", diff.ddim_sample_loop_progressive), ("ddpm", diff.p_sample_loop_progressive)):
+            torch.manual_seed(seed + 10)
+            noises = [torch.randn_like(z) for _ in range(steps)]
+            torch.manual_seed(seed + 10)
+            samples, x0s = [], []
+            for r in gen(fn, z.shape, z, clip_denoised=False, model_kwargs=mk, device="cpu"):
+                samples.append(r["sample"].numpy())
+                x0s.append(r["pred_xstart"].numpy())
+            out[f"{method}_noises"] = np.stack([n_.numpy() for n_ in noises])
+            out[f"{method}_samples"] = np.stack(samples)
+            out[f"{method}_pred_xstart"] = np.stack(x0s)
+        # DDIM with eta > 0 exercises the sigma / noise branch (gd:549-563)
+        torch.manual_seed(seed + 10)
+        out["ddim_eta05_final"] = diff.ddim_sample_loop(fn, z.shape, z, clip_denoised=False,
+                                                        model_kwargs=mk, device="cpu", eta=0.5).numpy()
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rl, rd = load_reference_latte(), load_reference_diffusion()
+    schedules(rd)
+    tiny_model(rl, rd, "tiny_classcond", TINY, use_cfg=True, seed=100)
+    tiny_model(rl, rd, "tiny_uncond", TINY4, use_cfg=False, seed=200)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

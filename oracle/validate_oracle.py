@@ -1,0 +1,89 @@
+"""Pin the oracle restatement against the REAL reference (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage: python -m oracle.validate_oracle [--xl]  -> oracle/VALIDATION.md
+"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+from oracle import diffusion_oracle as do
+from oracle import latte_oracle as lo
+from oracle.reference_loader import (load_reference_diffusion, load_reference_latte,
+                                     randomize_zero_init)
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def main():
+    rl, rd = load_reference_latte(), load_reference_diffusion()
+    rows = []
+    # --- schedules: every table bit-identical (np.array_equal on fp64)
+    for spec in ["", "250", "100", "50", "10", "1", "ddim250", "ddim10", "10,15,20"]:
+        d = rd.create_diffusion(spec)
+        s = do.Schedule(spec)
+        ok = list(d.timestep_map) == list(s.timestep_map)
+        for name in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                     "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                     "posterior_mean_coef1", "posterior_mean_coef2"]:
+            ok = ok and np.array_equal(np.asarray(getattr(d, name)), getattr(s, name))
+        rows.append((f"schedule '{spec}' (timestep_map + 9 fp64 tables)", "bit-identical" if ok else "MISMATCH"))
+        assert ok, spec
+    # --- denoiser
+    cases = [("Latte-S/2 F=4 latent 8x8 class-cond", "Latte-S/2", dict(input_size=8, num_frames=4, num_classes=101, extras=2)),
+             ("Latte-S/2 F=4 latent 16x16 uncond", "Latte-S/2", dict(input_size=16, num_frames=4, extras=1)),
+             ("Latte-B/2 F=16 latent 8x8 uncond", "Latte-B/2", dict(input_size=8, num_frames=16, extras=1))]
+    if "--xl" in sys.argv:
+        cases.append(("Latte-XL/2 F=16 latent 32x32 class-cond", "Latte-XL/2",
+                      dict(input_size=32, num_frames=16, num_classes=101, extras=2)))
+    for title, name, kw in cases:
+        torch.manual_seed(0)
+        model = rl.Latte_models[name](**kw).eval()
+        randomize_zero_init(model)
+        sd = model.state_dict()
+        cfg = lo.preset_config(name, **kw)
+        g = torch.Generator("cpu").manual_seed(1)
+        B = 2 if name != "Latte-XL/2" else 1
+        x = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
+        t = torch.tensor([999, 12][:B])
+        y = torch.tensor([7, 101][:B]) if kw["extras"] == 2 else None
+        with torch.no_grad():
+            t0 = time.time(); ref = model(x, t, y=y); t_ref = time.time() - t0
+            t0 = time.time(); ora = lo.latte_forward(sd, cfg, x, t, y); t_or = time.time() - t0
+        rows.append((f"{title}: forward", f"rel-L2 {rel(ora, ref):.2e}, max|d| {float((ora-ref).abs().max()):.2e} (ref {t_ref:.2f}s, oracle {t_or:.2f}s)"))
+        assert rel(ora, ref) < 1e-5
+        if kw["extras"] == 2 and B == 2:
+            with torch.no_grad():
+                xc = torch.cat([x[:1], x[:1]])
+                refc = model.forward_with_cfg(xc, t, y=y, cfg_scale=7.0)
+                orac = lo.latte_forward_with_cfg(sd, cfg, xc, t, y, 7.0)
+            rows.append((f"{title}: forward_with_cfg(7.0)", f"rel-L2 {rel(orac, refc):.2e}"))
+            assert rel(orac, refc) < 1e-5
+        if name == "Latte-S/2" and kw["input_size"] == 8:
+            for method in ("ddim", "ddpm"):
+                steps = 10
+                d = rd.create_diffusion(str(steps)); s = do.Schedule(str(steps))
+                mk = dict(y=y)
+                torch.manual_seed(5); noises = [torch.randn_like(x) for _ in range(steps)]
+                torch.manual_seed(5)
+                with torch.no_grad():
+                    loop = d.ddim_sample_loop if method == "ddim" else d.p_sample_loop
+                    refs = loop(model.forward, x.shape, x, clip_denoised=False, model_kwargs=mk, device="cpu")
+                    oras = do.sample_loop(s, lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt, y), x, method=method, noises=noises)
+                rows.append((f"{title}: {method.upper()}-{steps} loop final latents", f"rel-L2 {rel(oras, refs):.2e}"))
+                assert rel(oras, refs) < 1e-5
+    with open("oracle/VALIDATION.md", "w") as f:
+        f.write("# Oracle vs. the real reference (run in the build container)\n\n"
+                "Produced by `python -m oracle.validate_oracle --xl`; reference = `/root/reference` unmodified "
+                "(timm stand-in), fp32 CPU, torch %s.\n\n| check | result |\n|---|---|\n" % torch.__version__)
+        for a, b in rows:
+            f.write(f"| {a} | {b} |\n")
+    for a, b in rows:
+        print(a, "->", b)
+
+
+if __name__ == "__main__":
+    main()
