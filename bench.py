@@ -1,0 +1,174 @@
+"""bench.py — denoising steps/sec of the Latte-XL/2 16x256x256 sampling loop on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (denoiser forward + sampler update) over the rank's batch of
+latents, inputs resident in HBM.  Workload = BASELINE.json configs[1]: Latte-XL/2, FaceForensics
+(unconditional) config, 16 frames of 32x32 latents, per-GPU batch = the YAML's per_proc_batch_size (2),
+DDIM eta=0 over the "250" respacing, random-init weights (adaLN/final layers re-drawn N(0, 0.02) so
+the network is not the identity), synthetic N(0,1) latents.  Weak scaling: every rank runs its own
+samples, no data-path collective (the reference's sample_ddp.py has none either).
+`value` = aggregate denoising sample-steps/s = n_gpus * batch * K / max-over-ranks time.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_SAMPLE_STEP = {"Latte-XL/2": 3.726e12}  # SURVEY.md §8(d), algorithmic, 16x32x32 latents
+MFMA_PEAK_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: bf16/f16 dense
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=250)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=2, help="samples per GPU (ffs_sample.yaml per_proc_batch_size)")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    p.add_argument("--method", default="ddim", choices=["ddim", "ddpm"])
+    p.add_argument("--gemm-variant", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-forwards", type=int, default=2)
+    return p.parse_args()
+
+
+def build_model(args, device):
+    import latte_amd
+    torch.manual_seed(0)
+    m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=1, learn_sigma=True,
+                                             compute_dtype=args.dtype, max_batch=args.batch)
+    g = torch.Generator("cpu").manual_seed(1)
+    with torch.no_grad():
+        for _, prm in m.named_parameters():
+            if prm.requires_grad and float(prm.detach().abs().max()) == 0.0:
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+    return m.to(device).eval()
+
+
+def run_steps(lib, model, diffusion, x, n_steps, method, batch):
+    """Exactly n_steps denoising steps: chains of up to num_timesteps steps through the fused loop."""
+    from latte_amd._lib import check, ptr, stream_ptr
+    eng = model.engine(batch)
+    T = diffusion.num_timesteps
+    left = n_steps
+    mi = 1 if method == "ddim" else 0
+    while left > 0:
+        seg = min(left, T)
+        check(lib.latte_sample_loop(eng, diffusion._h, mi, 0.0, 0, 1.0, ptr(x), None, batch, T - 1, T - seg, None,
+                                    None, None, stream_ptr()))
+        left -= seg
+
+
+def cpu_baseline(n_forwards):
+    """The oracle (a CPU port of the reference forward, bit-identical to it: oracle/VALIDATION.md) timed
+    on this box's host cores — reported beside the GPU number, never the thing measured."""
+    from oracle import latte_oracle as lo
+    cfg = lo.preset_config("Latte-XL/2", input_size=32, num_frames=16, extras=1)
+    sd = lo.init_state_dict(cfg, seed=0)
+    x = torch.randn(1, 16, 4, 32, 32)
+    t = torch.tensor([500])
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        lo.latte_forward(sd, cfg, x, t)                       # warm-up
+        t0 = time.time()
+        for _ in range(n_forwards):
+            lo.latte_forward(sd, cfg, x, t)
+        dt = (time.time() - t0) / n_forwards
+    return {"value": round(1.0 / dt, 4), "unit": "denoising sample-steps/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n_forwards} timed fp32 forwards of Latte-XL/2 (B=1, 16x32x32 latents) after 1 warm-up; "
+                      "the sampler update is negligible on CPU (<0.1%)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+
+    import latte_amd
+    from latte_amd._lib import load_library
+    lib = load_library()
+    model = build_model(args, device)
+    if args.gemm_variant:
+        model.set_engine_option("gemm_variant", args.gemm_variant, args.batch)
+    diffusion = latte_amd.create_diffusion("250")
+    B = args.batch
+    g = torch.Generator("cpu").manual_seed(1000 + rank)
+    x = torch.randn(B, 16, 4, 32, 32, generator=g).to(device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(lib, model, diffusion, x.clone(), max(args.warmup, 1), args.method, B)
+    xx = x.clone()
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(lib, model, diffusion, xx, args.steps, args.method, B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(xx).all())
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        flops = FLOPS_PER_SAMPLE_STEP["Latte-XL/2"]
+        # roofline of the dominant kernel, timed live with HIP events on the launch stream
+        t = torch.full((B,), 500, device=device, dtype=torch.int64)
+        model.profile_forward(x, t)
+        prof = model.profile_forward(x, t)
+        total_ms = sum(v[0] for v in prof.values())
+        D, Hm, M = 1152, 4608, B * 16 * 256
+        gemm_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * Hm * D,
+                      "gemm_fc2": 2.0 * M * D * Hm}
+        dom = max(gemm_flops, key=lambda k: prof[k][0])
+        avg_ms = prof[dom][0] / max(prof[dom][1], 1)
+        achieved = gemm_flops[dom] / (avg_ms * 1e-3) / 1e12
+        res = {
+            "metric": "denoising steps/sec", "value": round(value, 3), "unit": "sample-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "Latte-XL/2 FaceForensics (uncond) 16x256x256 -> latents 16x4x32x32, "
+                                   f"{args.method.upper()} on the '250' respacing, random-init weights",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} (independent samples)"},
+            "latent_frames_per_sec": round(world * B * 16 / (elapsed / args.steps * 250), 3),
+            "model_mfma_frac": round(value / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            "finite": finite,
+            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel ({dom}: M={M})", "achieved": round(achieved, 1),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4)},
+            "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
+            "forward_ms_eager_events": round(total_ms, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_forwards)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * latte_amd.h — C-ABI of the MI355X-native Latte denoising engine (liblatte_amd.so).
+ *
+ * The reference (Vchitect/Latte) exposes its hot path through Python protocols, not a native
+ * plugin ABI; each entry point below names the reference interface it stands
+ * in for.  Conventions:
+ *   - plain C symbols, plain pointers and sizes, no torch / C++ types;
+ *   - tensors are CALLER-OWNED DEVICE pointers in the reference layouts (contiguous);
+ *     the engine owns only its packed weights and workspace;
+ *   - every compute call takes a hipStream_t (as void*), is stream-ordered, never synchronises;
+ *   - return value 0 = ok, non-zero = error; latte_last_error() gives the thread-local message
+ *     (the reference raises Python exceptions / asserts: latte.py:38, gaussian_diffusion.py:278,290);
+ *   - one engine per (device, host thread); no internal threads.
+ */
+#ifndef LATTE_AMD_H_
+#define LATTE_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LATTE_OK 0
+#define LATTE_ERR_INVALID 1   /* bad argument / unsupported configuration */
+#define LATTE_ERR_HIP 2       /* a HIP runtime call failed                 */
+#define LATTE_ERR_STATE 3     /* e.g. weights missing, batch > max_batch   */
+
+/* compute dtype of the MFMA operands (accumulation, residual stream, LN/softmax statistics and the
+ * sampler update are always fp32) */
+#define LATTE_DTYPE_BF16 0
+#define LATTE_DTYPE_F16 1
+
+const char* latte_last_error(void);
+/* "latte_amd <version> gfx950 ..." build identification */
+const char* latte_version(void);
+
+/* ------------------------------------------------------------------ schedule (host, fp64)
+ * Replaces diffusion/__init__.py:10-47 create_diffusion -> respace.py:12-62 space_timesteps,
+ * respace.py:73-87 SpacedDiffusion.__init__, gaussian_diffusion.py:153-201 table construction.
+ * Integer outputs are bit-exact with the reference; fp64 tables are computed in the same order
+ * of operations. */
+typedef struct latte_schedule latte_schedule_t;
+
+int latte_schedule_create(int diffusion_steps, const char* timestep_respacing /* "", "250", "ddim50", "10,15,20" */,
+                          const char* noise_schedule /* "linear" | "squaredcos_cap_v2" */,
+                          latte_schedule_t** out);
+void latte_schedule_destroy(latte_schedule_t* s);
+int latte_schedule_num_timesteps(const latte_schedule_t* s);
+/* SpacedDiffusion.timestep_map (respace.py:75,86): respaced index -> original timestep */
+int latte_schedule_timestep_map(const latte_schedule_t* s, int64_t* out, int n);
+/* name in {betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
+ * sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped,
+ * posterior_mean_coef1, posterior_mean_coef2, log_betas} */
+int latte_schedule_table(const latte_schedule_t* s, const char* name, double* out, int n);
+
+/* ------------------------------------------------------------------ engine
+ * Replaces models/latte.py:204-255 Latte.__init__ (one of the Latte_models presets, :464-506). */
+typedef struct latte_engine latte_engine_t;
+
+typedef struct latte_model_config {
+  int input_size;    /* latent H = W (image_size / 8)          latte.py:210 */
+  int patch_size;    /* 2 | 4 | 8                                latte.py:211 */
+  int in_channels;   /* 4                                        latte.py:212 */
+  int hidden_size;   /* multiple of 128                          latte.py:213 */
+  int depth;         /* even: spatial/temporal alternate         latte.py:214,345 */
+  int num_heads;     /* head_dim = hidden/heads in {64, 72}      latte.py:215 */
+  int mlp_hidden;    /* int(hidden * mlp_ratio)                  latte.py:169 */
+  int num_frames;    /*                                          latte.py:217 */
+  int num_classes;   /* label table has num_classes+1 rows       latte.py:131 */
+  int learn_sigma;   /* out_channels = 2*in_channels if set      latte.py:226 */
+  int extras;        /* 1 = unconditional, 2 = class-conditional latte.py:221 */
+  int compute_dtype; /* LATTE_DTYPE_* for the MFMA operands */
+} latte_model_config_t;
+
+int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_engine_t** out);
+void latte_engine_destroy(latte_engine_t* e);
+
+/* Engine options: "gemm_variant" (0 auto | 1 = 128x128 | 2 = 256x128 | 3 = 256x256 tiles),
+ * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
+ * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
+int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);
+
+/* Replaces nn.Module.load_state_dict (sample.py:62-64) for ONE tensor named by its reference
+ * state_dict key (SURVEY.md §8(b) lists them: "blocks.3.attn.qkv.weight", "pos_embed", ...).
+ * `data` is fp32, contiguous, reference shape; host pointer if on_device == 0, else device pointer.
+ * The engine converts / packs into its own storage (caller may free `data` on return). */
+int latte_engine_load_tensor(latte_engine_t* e, const char* key, const float* data, int64_t numel,
+                             int on_device, void* stream);
+/* Returns 0 when every tensor the configuration needs has been loaded; otherwise LATTE_ERR_STATE
+ * and latte_last_error() names the first missing key (load_state_dict strict=True behaviour). */
+int latte_engine_check_weights(latte_engine_t* e);
+/* number of reference keys expected / name of the i-th one (for enumeration by the host shim) */
+int latte_engine_num_keys(const latte_engine_t* e);
+const char* latte_engine_key(const latte_engine_t* e, int i);
+
+/* Latte.forward (latte.py:314-377).  x:[B,F,C,H,W] fp32, t: int64[B] ORIGINAL timesteps (device),
+ * y: int64[B] labels (device) or NULL when extras == 1, out:[B,F,Cout,H,W] fp32. */
+int latte_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,
+                  float* out, void* stream);
+/* Latte.forward_with_cfg (latte.py:379-398): x is the doubled batch [2b,...] whose first half is
+ * duplicated internally; guidance on the first 4 channels; out:[2b,F,Cout,H,W]. */
+int latte_forward_with_cfg(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y,
+                           int batch /* = 2b */, float cfg_scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------ sampler update
+ * Replaces gaussian_diffusion.py:254-336 p_mean_variance (EPSILON + LEARNED_RANGE, as built by
+ * create_diffusion) followed by :380-421 p_sample (method 0 = "ddpm") or :517-564 ddim_sample
+ * (method 1 = "ddim").  `index` is the respaced step i.  model_out:[B,F,2C,H,W]; noise may be NULL
+ * when no noise term is needed (ddim eta == 0, or index == 0).  Outputs may alias x. */
+#define LATTE_METHOD_DDPM 0
+#define LATTE_METHOD_DDIM 1
+int latte_sampler_step(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised,
+                       const float* x, const float* model_out, const float* noise,
+                       int batch, int frames, int channels, int hw /* H*W */,
+                       float* sample_out, float* pred_xstart_out /* may be NULL */, void* stream);
+
+/* ------------------------------------------------------------------ fused sampling loop
+ * Replaces gaussian_diffusion.py:423-515 p_sample_loop / :604-684 ddim_sample_loop driving the
+ * model through respace.py:125-130 _WrappedModel (index -> original timestep), i.e. the body of
+ * sample/sample.py:100-107.  Runs steps start_index .. end_index (inclusive, descending; the full
+ * chain is num_timesteps-1 .. 0).  x:[B,F,C,H,W] fp32 updated in place.  cfg_scale > 1 selects
+ * forward_with_cfg semantics (batch is then the doubled batch, sample.py:88-94).
+ * noise: NULL, or [n_steps][B,F,C,H,W] with noise[k] consumed by the k-th executed step (parity
+ * runs feed the reference's draws).  trail_sample / trail_x0: NULL or [n_steps][B,F,C,H,W] receiving
+ * every step's {"sample","pred_xstart"} (the *_progressive generators, :468,:637). */
+int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, float eta,
+                      int clip_denoised, float cfg_scale, float* x, const int64_t* y, int batch,
+                      int start_index, int end_index, const float* noise,
+                      float* trail_sample, float* trail_x0, void* stream);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py)
+ * Runs ONE denoiser forward eagerly with HIP events around every kernel launch on `stream`,
+ * synchronises, and reports per-kernel-class totals.  classes (fixed order):
+ *   0 gemm_qkv 1 gemm_proj 2 gemm_fc1 3 gemm_fc2 4 attn_spatial 5 attn_temporal 6 ln_modulate
+ *   7 embed_cond 8 patch_embed 9 final_layer
+ * ms_out / launches_out: arrays of n (>= 10). */
+#define LATTE_NUM_KERNEL_CLASSES 10
+int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,
+                          float* out, float* ms_out, int* launches_out, int n, void* stream);
+/* Stand-alone timing of the dominant kernel: C[M,N] = A[M,K] * W[N,K]^T (+bias epilogue `epi`,
+ * 0 = bf16 out, 1 = bias+GELU, 2 = gated residual) on synthetic operands already resident in HBM;
+ * `iters` back-to-back launches between two HIP events on `stream`.  variant selects the tile
+ * configuration (0 = engine default for the shape). */
+int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int iters, float* ms_per_launch,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LATTE_AMD_H_ */

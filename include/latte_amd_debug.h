@@ -1,0 +1,36 @@
+/*
+ * latte_amd_debug.h — per-kernel test hooks of liblatte_amd.so (C-ABI, same conventions as
+ * latte_amd.h).  They exist so tests/ can check every HIP kernel against the PyTorch op sequence it
+ * replaces (the reference has no tests at all).  All pointers are device pointers;
+ * "half" buffers hold bf16 or f16 bit patterns according to `dtype` (LATTE_DTYPE_*).
+ */
+#ifndef LATTE_AMD_DEBUG_H_
+#define LATTE_AMD_DEBUG_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M,N] = A[M,K] W[N,K]^T with epilogue epi: 0 half=acc+bias | 1 half=gelu_tanh(acc+bias) |
+ * 2 out_f32[m,n] += gate[(m / rows_per_sample) * gate_stride + n] * (acc+bias) | 3 out_f32 = acc+bias.
+ * A must be allocated with rows padded to a multiple of 256.  (nn.Linear, latte.py:43,45,171) */
+int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
+                     int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
+/* Attention core of latte.py:50-70 on a [rows, 3*D] qkv buffer (see AttnArgs in csrc/common.h). */
+int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U,
+                          int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream);
+/* half y = LN(x) * (1 + scale[sample]) + shift[sample]; optional x += temp_embed[frame] first
+ * (latte.py:28-29,166,179; :357-358). */
+int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,
+                            int rows_per_sample, const float* temp_embed, int T, int F, int dtype, void* stream);
+int latte_debug_convert(const float* in, void* out, int64_t n, int dtype, void* stream);
+int latte_debug_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* Writes, for every lane l (0..63) and element j (0..3), the LDS element INDEX that
+ * ds_read_b64_tr_b16 returned when lane l supplies byte address 8*l (LDS pre-filled with
+ * lds[i] = i as 16-bit values): out[l*4 + j].  Documents the transpose-read lane map on this chip. */
+int latte_debug_tr16_probe(uint16_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+// Internal declarations shared by the engine's translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/latte_amd.h"
+
+// Host-side schedule object behind latte_schedule_t (built in schedule.cpp).
+struct latte_schedule {
+  int num_timesteps = 0;
+  std::vector<int64_t> timestep_map;
+  std::vector<double> betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
+      sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped, posterior_mean_coef1,
+      posterior_mean_coef2, log_betas;
+};
+
+namespace latte {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+#define LATTE_HIP(call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return ::latte::fail(LATTE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// 16-bit storage element (bf16 or f16 bit pattern depending on the engine's compute dtype)
+typedef uint16_t half_t;
+
+// ---- GEMM  C[M,N] = A[M,K] · W[N,K]^T, fused epilogues ----------------------------------------
+enum GemmEpi : int {
+  EPI_BIAS_H16 = 0,       // out(half) = acc + bias
+  EPI_BIAS_GELU_H16 = 1,  // out(half) = gelu_tanh(acc + bias)
+  EPI_GATE_RES_F32 = 2,   // res(fp32)[m,n] += gate[sample(m)][n] * (acc + bias)
+  EPI_BIAS_F32 = 3,       // out(fp32) = acc + bias
+};
+struct GemmArgs {
+  const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
+  const half_t* W;    // [N, K]
+  const float* bias;  // [N]
+  void* out;          // half [Mpad, N] | fp32 [Mpad, N]
+  const float* gate;  // EPI_GATE_RES: gate base, row stride gate_stride (per sample)
+  int M, N, K;        // M = valid rows; grid covers ceil(M / BM) tiles
+  int gate_stride;
+  int rows_per_sample;
+};
+// variant: 0 = pick for the shape; 1 = 128x128 tile; 2 = 256x128; 3 = 256x256 (N % tileN == 0 required)
+int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
+int gemm_tile_m(int variant);
+
+// ---- attention --------------------------------------------------------------------------------
+struct AttnArgs {
+  const half_t* qkv;  // [rows, 3*D]; columns ordered [3][heads][hd]   (latte.py:50)
+  half_t* out;        // [rows, D];   column = head*hd + d              (latte.py:70)
+  int num_seq;        // sequences
+  int L;              // tokens per sequence
+  int heads, hd, D;
+  int U;              // sequences per sample
+  int64_t sample_stride;  // rows per sample (F*T)
+  int64_t seq_stride;     // row offset between consecutive sequences of a sample (T spatial, 1 temporal)
+  int64_t row_stride;     // row offset between consecutive tokens of a sequence (1 spatial, T temporal)
+  float scale;            // hd^-0.5
+};
+int launch_attention(const AttnArgs& a, int dtype, hipStream_t st);
+
+// ---- pointwise / small kernels ------------------------------------------------------------------
+// y(half)[m, :] = LN(x[m, :]) * (1 + scale[s(m), :]) + shift[s(m), :], eps 1e-6, no affine.
+// If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).
+int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
+                       int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T,
+                       int F, int dtype, hipStream_t st);
+enum SmallIn : int { IN_PLAIN = 0, IN_SILU = 1, IN_TFREQ = 2 };
+// out[b, n] = bias[n] + sum_k in(b,k) * W[n, k]  (+ add_table[add_idx[b], n]); fp32 exact.
+int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,
+                        const float* add_table, const int64_t* add_idx, float* out, int B, int N, int K,
+                        int out_stride, hipStream_t st);
+int launch_patch_embed(const float* x, const float* Wt /* [C*p*p][D] */, const float* bias, const float* pos,
+                       float* out, int BF, int C, int H, int p, int D, hipStream_t st);
+int launch_final_layer(const float* x, const float* shift, const float* scale, int mod_stride,
+                       const float* Wt /* [D][P] */, const float* bias, float* out, int M, int D,
+                       int rows_per_sample, int T, int p, int Cout, int H, hipStream_t st);
+int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
+int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
+int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);
+// Philox4x32-10 + Box-Muller standard normals; element i depends only on (seed, offset + i).
+int launch_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+
+struct SamplerCoefs {  // fp32 values of the fp64 tables at the step (gaussian_diffusion.py:869-881)
+  float min_log, max_log, sqrt_recip, sqrt_recipm1, coef1, coef2;
+  float sqrt_ab_prev, dir_coef, sigma;  // ddim: sqrt(ab_prev), sqrt(1-ab_prev-sigma^2), sigma
+  float nonzero;                        // 0 when index == 0
+  float cfg_scale;                      // > 1: model_out is a raw doubled batch, combine here
+  int method, clip;
+};
+int launch_sampler_update(const SamplerCoefs& c, const float* x, const float* model_out, const float* noise,
+                          int batch, int frames, int channels, int hw, int raw_cfg, float* sample_out,
+                          float* x0_out, hipStream_t st);
+
+}  // namespace latte

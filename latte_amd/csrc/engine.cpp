@@ -1,0 +1,546 @@
+// Engine host logic: weight ingestion, workspace, the denoiser forward and the fused sampling loop.
+//
+//   Latte.forward / forward_with_cfg      /root/reference/models/latte.py:314-398
+//   p_sample_loop / ddim_sample_loop      /root/reference/diffusion/gaussian_diffusion.py:423-515,604-684
+//   _WrappedModel (index -> timestep)     /root/reference/diffusion/respace.py:125-130
+//
+// Data layout in HBM (one canonical token order, no transposes between spatial and temporal blocks):
+//   residual stream  xres  fp32 [B*F*T (padded to 256), D]   row = (b*F + f)*T + t
+//   GEMM operands    xn    half [rows, D], qkv half [rows, 3D], h half [rows, mlp]
+//   conditioning     mod   fp32 [B, depth*6D + 2D]  (all adaLN outputs of one forward, computed once per
+//                    SAMPLE; the reference recomputes them on F or T repeated rows, latte.py:333-339)
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace latte {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+enum PackKind { PK_F32, PK_F32_TRANSPOSE, PK_H16 };
+struct TensorSlot {
+  std::string key;
+  int64_t numel;
+  PackKind kind;
+  void* dst;
+  int rows, cols;  // for PK_F32_TRANSPOSE: source [rows][cols]
+  bool loaded = false;
+};
+
+struct BlockW {
+  half_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+  float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+};
+
+struct Prof {
+  std::vector<hipEvent_t> ev;
+  std::vector<int> cls;
+};
+
+}  // namespace latte
+
+using namespace latte;
+
+struct latte_engine {
+  latte_model_config_t cfg;
+  int max_batch = 0;
+  int D = 0, T = 0, F = 0, G = 0, Cin = 0, Cout = 0, H = 0, P = 0, KPE = 0, Hm = 0, hd = 0;
+  int nmod = 0;           // depth*6D + 2D
+  int64_t rows_max = 0, rows_pad = 0;
+  int gemm_variant = 1;
+  std::vector<BlockW> blocks;
+  float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
+        *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr, *ytab = nullptr, *fin_wt = nullptr,
+        *fin_b = nullptr;
+  float *xres = nullptr, *mod = nullptr, *temb0 = nullptr, *cvec = nullptr, *model_out = nullptr, *stage = nullptr,
+        *noise_buf = nullptr;
+  half_t *xn = nullptr, *qkv = nullptr, *hbuf = nullptr;
+  int64_t* tmap_dev = nullptr;
+  int64_t tmap_cap = 0;
+  int64_t stage_numel = 0;
+  std::vector<TensorSlot> slots;
+  std::map<std::string, int> slot_index;
+  std::vector<void*> allocs;
+  uint64_t seed = 0, rng_offset = 0;
+};
+
+namespace {
+
+template <typename Tp>
+int dev_alloc(latte_engine* e, Tp** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  const size_t bytes = count * sizeof(Tp);
+  LATTE_HIP(hipMalloc(&q, bytes ? bytes : 16));
+  if (zero) LATTE_HIP(hipMemset(q, 0, bytes ? bytes : 16));
+  e->allocs.push_back(q);
+  *p = (Tp*)q;
+  return LATTE_OK;
+}
+
+void add_slot(latte_engine* e, const std::string& key, int64_t numel, PackKind kind, void* dst, int rows = 0, int cols = 0) {
+  TensorSlot s;
+  s.key = key;
+  s.numel = numel;
+  s.kind = kind;
+  s.dst = dst;
+  s.rows = rows;
+  s.cols = cols;
+  e->slot_index[key] = (int)e->slots.size();
+  e->slots.push_back(s);
+  if (numel > e->stage_numel) e->stage_numel = numel;
+}
+
+struct Timer {  // optional per-launch HIP events (latte_profile_forward)
+  Prof* p;
+  hipStream_t st;
+  void mark(int cls) {
+    if (!p) return;
+    hipEvent_t ev;
+    (void)hipEventCreate(&ev);
+    (void)hipEventRecord(ev, st);
+    p->ev.push_back(ev);
+    p->cls.push_back(cls);
+  }
+};
+enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATCH, C_FINAL, C_NONE = -1 };
+
+int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t* y, int B, bool cfg_dup, float* out,
+                hipStream_t st, Prof* prof) {
+  const auto& c = e->cfg;
+  if (B <= 0 || B > e->max_batch) return fail(LATTE_ERR_STATE, "forward: batch exceeds max_batch of the engine");
+  if (c.extras == 2 && y == nullptr) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
+  if (cfg_dup && (B % 2)) return fail(LATTE_ERR_INVALID, "forward_with_cfg: batch must be even");
+  const int D = e->D, T = e->T, F = e->F, dt = c.compute_dtype;
+  const int M = B * F * T;
+  const int rps = F * T;
+  Timer tm{prof, st};
+  int rc;
+  tm.mark(C_NONE);
+  // --- conditioning: t_emb = MLP(sincos(t)) (latte.py:119-123); c = t_emb (+ y_emb) (:337,:348); all adaLN at once
+  if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t0_w, e->t0_b, nullptr, nullptr, e->temb0, B, D, 256, D, st))) return rc;
+  if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, c.extras == 2 ? e->ytab : nullptr, y,
+                                e->cvec, B, D, D, D, st))) return rc;
+  if ((rc = launch_small_linear(IN_SILU, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
+                                e->nmod, st))) return rc;
+  tm.mark(C_COND);
+  // --- patch embed + pos_embed (latte.py:330-331)
+  if (cfg_dup) {
+    const int hb = B / 2;
+    if ((rc = launch_patch_embed(x, e->pe_wt, e->pe_b, e->pos, e->xres, hb * F, e->Cin, e->H, c.patch_size, D, st))) return rc;
+    if ((rc = launch_patch_embed(x, e->pe_wt, e->pe_b, e->pos, e->xres + (size_t)hb * rps * D, hb * F, e->Cin, e->H,
+                                 c.patch_size, D, st))) return rc;
+  } else {
+    if ((rc = launch_patch_embed(x, e->pe_wt, e->pe_b, e->pos, e->xres, B * F, e->Cin, e->H, c.patch_size, D, st))) return rc;
+  }
+  tm.mark(C_PATCH);
+
+  for (int i = 0; i < c.depth; ++i) {
+    const bool spatial = (i % 2) == 0;  // latte.py:345-346
+    const BlockW& w = e->blocks[i];
+    const float* mb = e->mod + (size_t)i * 6 * D;  // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    // x + temp_embed once, after the first spatial block (latte.py:357-358)
+    const float* te = (i == 1) ? e->temp : nullptr;
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, e->nmod, M, D, rps, te, T, F, dt, st))) return rc;
+    tm.mark(C_LN);
+    GemmArgs g{};
+    g.M = M; g.rows_per_sample = rps; g.gate_stride = e->nmod;
+    g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
+    if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant, st))) return rc;
+    tm.mark(C_QKV);
+    AttnArgs a{};
+    a.qkv = e->qkv; a.out = e->xn; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
+    a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
+    if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
+    else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
+    if ((rc = launch_attention(a, dt, st))) return rc;
+    tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
+    g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D;
+    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant, st))) return rc;
+    tm.mark(C_PROJ);
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, e->nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    tm.mark(C_LN);
+    g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
+    if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant, st))) return rc;
+    tm.mark(C_FC1);
+    g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm;
+    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant, st))) return rc;
+    tm.mark(C_FC2);
+  }
+  // --- final layer (latte.py:197-201) + unpatchify (:297-310)
+  const float* fm = e->mod + (size_t)c.depth * 6 * D;  // chunk(2): shift, scale
+  if ((rc = launch_final_layer(e->xres, fm, fm + D, e->nmod, e->fin_wt, e->fin_b, out, M, D, rps, T, c.patch_size,
+                               e->Cout, e->H, st))) return rc;
+  tm.mark(C_FINAL);
+  return LATTE_OK;
+}
+
+// fp32 emulation of the reference's per-step tensor arithmetic (gaussian_diffusion.py:869-881: fp64 table ->
+// .float()); compiled with -ffp-contract=off.
+SamplerCoefs make_coefs(const latte_schedule_t* s, int method, int i, float eta, int clip) {
+  SamplerCoefs c{};
+  c.method = method;
+  c.clip = clip;
+  c.min_log = (float)s->posterior_log_variance_clipped[i];
+  c.max_log = (float)s->log_betas[i];
+  c.sqrt_recip = (float)s->sqrt_recip_alphas_cumprod[i];
+  c.sqrt_recipm1 = (float)s->sqrt_recipm1_alphas_cumprod[i];
+  c.coef1 = (float)s->posterior_mean_coef1[i];
+  c.coef2 = (float)s->posterior_mean_coef2[i];
+  const float ab = (float)s->alphas_cumprod[i], abp = (float)s->alphas_cumprod_prev[i];
+  // gd:549-553  sigma = eta * sqrt((1-abp)/(1-ab)) * sqrt(1 - ab/abp)
+  const float sigma = (eta * std::sqrt((1.0f - abp) / (1.0f - ab))) * std::sqrt(1.0f - ab / abp);
+  c.sigma = sigma;
+  c.sqrt_ab_prev = std::sqrt(abp);
+  c.dir_coef = std::sqrt((1.0f - abp) - sigma * sigma);  // gd:558: sqrt(1 - abp - sigma**2)
+  c.nonzero = i == 0 ? 0.0f : 1.0f;
+  c.cfg_scale = 1.0f;
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* latte_last_error(void) { return latte::g_last_error.c_str(); }
+const char* latte_version(void) { return "latte_amd 0.1 (gfx950, HIP MFMA engine)"; }
+
+int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_engine_t** out) {
+  if (!cfg || !out || max_batch <= 0) return fail(LATTE_ERR_INVALID, "engine_create: bad arguments");
+  const auto& c = *cfg;
+  if (c.hidden_size % 128 != 0) return fail(LATTE_ERR_INVALID, "engine_create: hidden_size must be a multiple of 128");
+  if (c.depth <= 0 || c.depth % 2) return fail(LATTE_ERR_INVALID, "engine_create: depth must be even (spatial/temporal pairs)");
+  if (c.num_heads <= 0 || c.hidden_size % c.num_heads) return fail(LATTE_ERR_INVALID, "dim should be divisible by num_heads");
+  const int hd = c.hidden_size / c.num_heads;
+  if (hd != 64 && hd != 72) return fail(LATTE_ERR_INVALID, "engine_create: head_dim must be 64 or 72");
+  if (c.patch_size <= 0 || c.input_size % c.patch_size) return fail(LATTE_ERR_INVALID, "engine_create: input_size % patch_size != 0");
+  if (c.mlp_hidden % 128 != 0) return fail(LATTE_ERR_INVALID, "engine_create: mlp_hidden must be a multiple of 128");
+  if (c.extras != 1 && c.extras != 2) return fail(LATTE_ERR_INVALID, "engine_create: extras must be 1 (uncond) or 2 (class-cond)");
+  if (c.in_channels != 4) return fail(LATTE_ERR_INVALID, "engine_create: in_channels must be 4 (guidance is hard-wired to 4 channels, latte.py:394)");
+  if (c.compute_dtype != LATTE_DTYPE_BF16 && c.compute_dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "engine_create: bad compute dtype");
+
+  auto* e = new latte_engine();
+  e->cfg = c;
+  e->max_batch = max_batch;
+  e->D = c.hidden_size;
+  e->G = c.input_size / c.patch_size;
+  e->T = e->G * e->G;
+  e->F = c.num_frames;
+  e->Cin = c.in_channels;
+  e->Cout = c.learn_sigma ? 2 * c.in_channels : c.in_channels;
+  e->H = c.input_size;
+  e->P = c.patch_size * c.patch_size * e->Cout;
+  e->KPE = c.in_channels * c.patch_size * c.patch_size;
+  e->Hm = c.mlp_hidden;
+  e->hd = hd;
+  e->nmod = c.depth * 6 * e->D + 2 * e->D;
+  e->rows_max = (int64_t)max_batch * e->F * e->T;
+  e->rows_pad = (e->rows_max + 255) / 256 * 256;
+  const int D = e->D;
+  int rc = LATTE_OK;
+#define TRY(x) do { if ((rc = (x))) { latte_engine_destroy(e); return rc; } } while (0)
+  TRY(dev_alloc(e, &e->ada_w, (size_t)e->nmod * D));
+  TRY(dev_alloc(e, &e->ada_b, (size_t)e->nmod));
+  TRY(dev_alloc(e, &e->pos, (size_t)e->T * D));
+  TRY(dev_alloc(e, &e->temp, (size_t)e->F * D));
+  TRY(dev_alloc(e, &e->pe_wt, (size_t)e->KPE * D));
+  TRY(dev_alloc(e, &e->pe_b, (size_t)D));
+  TRY(dev_alloc(e, &e->t0_w, (size_t)D * 256));
+  TRY(dev_alloc(e, &e->t0_b, (size_t)D));
+  TRY(dev_alloc(e, &e->t2_w, (size_t)D * D));
+  TRY(dev_alloc(e, &e->t2_b, (size_t)D));
+  TRY(dev_alloc(e, &e->fin_wt, (size_t)D * e->P));
+  TRY(dev_alloc(e, &e->fin_b, (size_t)e->P));
+  add_slot(e, "pos_embed", (int64_t)e->T * D, PK_F32, e->pos);
+  add_slot(e, "temp_embed", (int64_t)e->F * D, PK_F32, e->temp);
+  add_slot(e, "x_embedder.proj.weight", (int64_t)D * e->KPE, PK_F32_TRANSPOSE, e->pe_wt, D, e->KPE);
+  add_slot(e, "x_embedder.proj.bias", D, PK_F32, e->pe_b);
+  add_slot(e, "t_embedder.mlp.0.weight", (int64_t)D * 256, PK_F32, e->t0_w);
+  add_slot(e, "t_embedder.mlp.0.bias", D, PK_F32, e->t0_b);
+  add_slot(e, "t_embedder.mlp.2.weight", (int64_t)D * D, PK_F32, e->t2_w);
+  add_slot(e, "t_embedder.mlp.2.bias", D, PK_F32, e->t2_b);
+  if (c.extras == 2) {
+    TRY(dev_alloc(e, &e->ytab, (size_t)(c.num_classes + 1) * D));
+    add_slot(e, "y_embedder.embedding_table.weight", (int64_t)(c.num_classes + 1) * D, PK_F32, e->ytab);
+  }
+  e->blocks.resize(c.depth);
+  for (int i = 0; i < c.depth; ++i) {
+    BlockW& w = e->blocks[i];
+    TRY(dev_alloc(e, &w.qkv_w, (size_t)3 * D * D));
+    TRY(dev_alloc(e, &w.proj_w, (size_t)D * D));
+    TRY(dev_alloc(e, &w.fc1_w, (size_t)e->Hm * D));
+    TRY(dev_alloc(e, &w.fc2_w, (size_t)D * e->Hm));
+    TRY(dev_alloc(e, &w.qkv_b, (size_t)3 * D));
+    TRY(dev_alloc(e, &w.proj_b, (size_t)D));
+    TRY(dev_alloc(e, &w.fc1_b, (size_t)e->Hm));
+    TRY(dev_alloc(e, &w.fc2_b, (size_t)D));
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    add_slot(e, p + "attn.qkv.weight", (int64_t)3 * D * D, PK_H16, w.qkv_w);
+    add_slot(e, p + "attn.qkv.bias", 3 * D, PK_F32, w.qkv_b);
+    add_slot(e, p + "attn.proj.weight", (int64_t)D * D, PK_H16, w.proj_w);
+    add_slot(e, p + "attn.proj.bias", D, PK_F32, w.proj_b);
+    add_slot(e, p + "mlp.fc1.weight", (int64_t)e->Hm * D, PK_H16, w.fc1_w);
+    add_slot(e, p + "mlp.fc1.bias", e->Hm, PK_F32, w.fc1_b);
+    add_slot(e, p + "mlp.fc2.weight", (int64_t)D * e->Hm, PK_H16, w.fc2_w);
+    add_slot(e, p + "mlp.fc2.bias", D, PK_F32, w.fc2_b);
+    add_slot(e, p + "adaLN_modulation.1.weight", (int64_t)6 * D * D, PK_F32, e->ada_w + (size_t)i * 6 * D * D);
+    add_slot(e, p + "adaLN_modulation.1.bias", 6 * D, PK_F32, e->ada_b + (size_t)i * 6 * D);
+  }
+  add_slot(e, "final_layer.linear.weight", (int64_t)e->P * D, PK_F32_TRANSPOSE, e->fin_wt, e->P, D);
+  add_slot(e, "final_layer.linear.bias", e->P, PK_F32, e->fin_b);
+  add_slot(e, "final_layer.adaLN_modulation.1.weight", (int64_t)2 * D * D, PK_F32, e->ada_w + (size_t)c.depth * 6 * D * D);
+  add_slot(e, "final_layer.adaLN_modulation.1.bias", 2 * D, PK_F32, e->ada_b + (size_t)c.depth * 6 * D);
+
+  TRY(dev_alloc(e, &e->stage, (size_t)e->stage_numel, false));
+  TRY(dev_alloc(e, &e->xres, (size_t)e->rows_pad * D));
+  TRY(dev_alloc(e, &e->xn, (size_t)e->rows_pad * D));
+  TRY(dev_alloc(e, &e->qkv, (size_t)e->rows_pad * 3 * D));
+  TRY(dev_alloc(e, &e->hbuf, (size_t)e->rows_pad * e->Hm));
+  TRY(dev_alloc(e, &e->mod, (size_t)max_batch * e->nmod));
+  TRY(dev_alloc(e, &e->temb0, (size_t)max_batch * D));
+  TRY(dev_alloc(e, &e->cvec, (size_t)max_batch * D));
+  TRY(dev_alloc(e, &e->model_out, (size_t)max_batch * e->F * e->Cout * e->H * e->H));
+  TRY(dev_alloc(e, &e->noise_buf, (size_t)max_batch * e->F * e->Cin * e->H * e->H));
+#undef TRY
+  *out = e;
+  return LATTE_OK;
+}
+
+void latte_engine_destroy(latte_engine_t* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+int latte_engine_num_keys(const latte_engine_t* e) { return e ? (int)e->slots.size() : 0; }
+const char* latte_engine_key(const latte_engine_t* e, int i) {
+  if (!e || i < 0 || i >= (int)e->slots.size()) return nullptr;
+  return e->slots[i].key.c_str();
+}
+
+int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) {
+  if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
+  const std::string k = name;
+  if (k == "gemm_variant") {
+    if (value < 0 || value > 3) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..3");
+    if (value == 3 && ((3 * e->D) % 256 || e->D % 256 || e->Hm % 256))
+      return fail(LATTE_ERR_INVALID, "gemm_variant 3 (256x256 tiles) needs every N to be a multiple of 256");
+    e->gemm_variant = value == 0 ? 1 : (int)value;
+    return LATTE_OK;
+  }
+  if (k == "seed") {
+    e->seed = (uint64_t)value;
+    e->rng_offset = 0;
+    return LATTE_OK;
+  }
+  return fail(LATTE_ERR_INVALID, "set_option: unknown option '" + k + "'");
+}
+
+int latte_engine_load_tensor(latte_engine_t* e, const char* key, const float* data, int64_t numel, int on_device,
+                             void* stream) {
+  if (!e || !key || !data) return fail(LATTE_ERR_INVALID, "load_tensor: null argument");
+  auto it = e->slot_index.find(key);
+  if (it == e->slot_index.end()) return fail(LATTE_ERR_INVALID, std::string("load_tensor: unexpected key '") + key + "'");
+  TensorSlot& s = e->slots[it->second];
+  if (numel != s.numel)
+    return fail(LATTE_ERR_INVALID, std::string("load_tensor: size mismatch for '") + key + "': got " + std::to_string(numel) +
+                                       ", expected " + std::to_string(s.numel));
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = data;
+  if (!on_device) {
+    LATTE_HIP(hipMemcpyAsync(e->stage, data, sizeof(float) * numel, hipMemcpyHostToDevice, st));
+    src = e->stage;
+  }
+  int rc = LATTE_OK;
+  switch (s.kind) {
+    case PK_F32:
+      LATTE_HIP(hipMemcpyAsync(s.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, st));
+      break;
+    case PK_F32_TRANSPOSE:
+      rc = launch_transpose_f32(src, (float*)s.dst, s.rows, s.cols, st);
+      break;
+    case PK_H16:
+      rc = launch_convert_f32_to_h16(src, (half_t*)s.dst, numel, e->cfg.compute_dtype, st);
+      break;
+  }
+  if (rc) return rc;
+  if (!on_device) LATTE_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next call
+  s.loaded = true;
+  return LATTE_OK;
+}
+
+int latte_engine_check_weights(latte_engine_t* e) {
+  if (!e) return fail(LATTE_ERR_INVALID, "check_weights: null engine");
+  for (const auto& s : e->slots)
+    if (!s.loaded) return fail(LATTE_ERR_STATE, "Missing key(s) in state_dict: \"" + s.key + "\"");
+  return LATTE_OK;
+}
+
+int latte_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
+                  void* stream) {
+  if (!e || !x || !t || !out) return fail(LATTE_ERR_INVALID, "forward: null argument");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  return run_forward(e, x, t, y, batch, false, out, (hipStream_t)stream, nullptr);
+}
+
+int latte_forward_with_cfg(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,
+                           float cfg_scale, float* out, void* stream) {
+  if (!e || !x || !t || !out) return fail(LATTE_ERR_INVALID, "forward_with_cfg: null argument");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  if ((rc = run_forward(e, x, t, y, batch, true, out, (hipStream_t)stream, nullptr))) return rc;
+  return launch_cfg_combine(out, batch / 2, e->F, e->Cout, e->H * e->H, cfg_scale, (hipStream_t)stream);
+}
+
+int latte_sampler_step(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised, const float* x,
+                       const float* model_out, const float* noise, int batch, int frames, int channels, int hw,
+                       float* sample_out, float* pred_xstart_out, void* stream) {
+  if (!s || !x || !model_out || !sample_out) return fail(LATTE_ERR_INVALID, "sampler_step: null argument");
+  if (index < 0 || index >= s->num_timesteps) return fail(LATTE_ERR_INVALID, "sampler_step: index out of range");
+  if (method != LATTE_METHOD_DDPM && method != LATTE_METHOD_DDIM) return fail(LATTE_ERR_INVALID, "sampler_step: bad method");
+  if (s->num_timesteps < 2) return fail(LATTE_ERR_INVALID, "sampler_step: learned-range variance needs >= 2 timesteps");
+  SamplerCoefs c = make_coefs(s, method, index, eta, clip_denoised);
+  if (method == LATTE_METHOD_DDPM && index != 0 && noise == nullptr)
+    return fail(LATTE_ERR_INVALID, "sampler_step: DDPM needs noise for index > 0");
+  const bool need_noise = (method == LATTE_METHOD_DDPM) ? (index != 0) : (c.sigma != 0.0f && index != 0);
+  return launch_sampler_update(c, x, model_out, need_noise ? noise : nullptr, batch, frames, channels, hw, 0, sample_out,
+                               pred_xstart_out, (hipStream_t)stream);
+}
+
+int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised,
+                      float cfg_scale, float* x, const int64_t* y, int batch, int start_index, int end_index,
+                      const float* noise, float* trail_sample, float* trail_x0, void* stream) {
+  if (!e || !s || !x) return fail(LATTE_ERR_INVALID, "sample_loop: null argument");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  const int n = s->num_timesteps;
+  if (start_index >= n || end_index < 0 || start_index < end_index) return fail(LATTE_ERR_INVALID, "sample_loop: bad index range");
+  if (n < 2) return fail(LATTE_ERR_INVALID, "sample_loop: learned-range variance needs >= 2 timesteps");
+  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "sample_loop: batch exceeds max_batch");
+  const bool use_cfg = cfg_scale > 1.0f;  // sample.py:51
+  if (use_cfg && (batch % 2)) return fail(LATTE_ERR_INVALID, "sample_loop: guidance needs the doubled batch");
+  hipStream_t st = (hipStream_t)stream;
+  // device copy of respace.py:126-127's map_tensor[ts], one row of `batch` entries per respaced index
+  const int64_t need = (int64_t)n * e->max_batch;
+  if (e->tmap_cap < need) {
+    rc = dev_alloc(e, &e->tmap_dev, (size_t)need, false);
+    if (rc) return rc;
+    e->tmap_cap = need;
+  }
+  {
+    std::vector<int64_t> host((size_t)need);
+    for (int i = 0; i < n; ++i)
+      for (int b = 0; b < e->max_batch; ++b) host[(size_t)i * e->max_batch + b] = s->timestep_map[i];
+    LATTE_HIP(hipMemcpyAsync(e->tmap_dev, host.data(), sizeof(int64_t) * need, hipMemcpyHostToDevice, st));
+    LATTE_HIP(hipStreamSynchronize(st));
+  }
+  const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
+  int k = 0;
+  for (int i = start_index; i >= end_index; --i, ++k) {
+    const int64_t* t = e->tmap_dev + (size_t)i * e->max_batch;
+    if ((rc = run_forward(e, x, t, y, batch, use_cfg, e->model_out, st, nullptr))) return rc;
+    SamplerCoefs c = make_coefs(s, method, i, eta, clip_denoised);
+    c.cfg_scale = cfg_scale;
+    const bool need_noise = (method == LATTE_METHOD_DDPM) ? (i != 0) : (c.sigma != 0.0f && i != 0);
+    const float* nz = nullptr;
+    if (need_noise) {
+      if (noise) {
+        nz = noise + (size_t)k * numel;
+      } else {
+        if ((rc = launch_fill_normal(e->noise_buf, numel, e->seed, e->rng_offset, st))) return rc;
+        e->rng_offset += numel;
+        nz = e->noise_buf;
+      }
+    }
+    float* x0 = trail_x0 ? trail_x0 + (size_t)k * numel : nullptr;
+    if ((rc = launch_sampler_update(c, x, e->model_out, nz, batch, e->F, e->Cin, e->H * e->H, use_cfg ? 1 : 0, x, x0, st))) return rc;
+    if (trail_sample)
+      LATTE_HIP(hipMemcpyAsync(trail_sample + (size_t)k * numel, x, sizeof(float) * numel, hipMemcpyDeviceToDevice, st));
+  }
+  return LATTE_OK;
+}
+
+int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
+                          float* ms_out, int* launches_out, int n, void* stream) {
+  if (!e || !ms_out || !launches_out || n < LATTE_NUM_KERNEL_CLASSES) return fail(LATTE_ERR_INVALID, "profile_forward: bad arguments");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  Prof prof;
+  hipStream_t st = (hipStream_t)stream;
+  rc = run_forward(e, x, t, y, batch, false, out, st, &prof);
+  if (rc) return rc;
+  LATTE_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    ms_out[i] = 0.f;
+    launches_out[i] = 0;
+  }
+  for (size_t i = 1; i < prof.ev.size(); ++i) {
+    float ms = 0.f;
+    LATTE_HIP(hipEventElapsedTime(&ms, prof.ev[i - 1], prof.ev[i]));
+    const int c = prof.cls[i];
+    if (c >= 0 && c < n) {
+      ms_out[c] += ms;
+      launches_out[c] += 1;
+    }
+  }
+  for (auto ev : prof.ev) (void)hipEventDestroy(ev);
+  return LATTE_OK;
+}
+
+int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int iters, float* ms_per_launch, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(LATTE_ERR_INVALID, "bench_gemm: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t Mp = ((int64_t)M + 255) / 256 * 256;
+  half_t *A = nullptr, *W = nullptr;
+  float *bias = nullptr, *gate = nullptr, *tmp = nullptr;
+  void* out = nullptr;
+  const size_t out_bytes = (size_t)Mp * N * 4;
+  LATTE_HIP(hipMalloc((void**)&A, (size_t)Mp * K * 2));
+  LATTE_HIP(hipMalloc((void**)&W, (size_t)N * K * 2));
+  LATTE_HIP(hipMalloc((void**)&bias, (size_t)N * 4));
+  LATTE_HIP(hipMalloc((void**)&gate, (size_t)N * 4));
+  LATTE_HIP(hipMalloc(&out, out_bytes));
+  const size_t big = (size_t)Mp * K > (size_t)N * K ? (size_t)Mp * K : (size_t)N * K;
+  LATTE_HIP(hipMalloc((void**)&tmp, big * 4));
+  LATTE_HIP(hipMemsetAsync(out, 0, out_bytes, st));
+  int rc = LATTE_OK;
+  // uniform-ish random operands (guide §5.4 rule 25: never bench MFMA kernels on zero-filled data)
+  if (!rc) rc = launch_fill_normal(tmp, (size_t)Mp * K, 1234, 0, st);
+  if (!rc) rc = launch_convert_f32_to_h16(tmp, A, (int64_t)Mp * K, dtype, st);
+  if (!rc) rc = launch_fill_normal(tmp, (size_t)N * K, 99, 0, st);
+  if (!rc) rc = launch_convert_f32_to_h16(tmp, W, (int64_t)N * K, dtype, st);
+  if (!rc) rc = launch_fill_normal(bias, (size_t)N, 7, 0, st);
+  if (!rc) rc = launch_fill_normal(gate, (size_t)N, 8, 0, st);
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate; g.M = M; g.N = N; g.K = K;
+  g.gate_stride = 0; g.rows_per_sample = M;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3 && !rc; ++i) rc = launch_gemm(g, epi, dtype, variant, st);
+  if (!rc) {
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm(g, epi, dtype, variant, st);
+    (void)hipEventRecord(e1, st);
+    hipError_t he = hipStreamSynchronize(st);
+    if (he != hipSuccess) rc = fail(LATTE_ERR_HIP, std::string("bench_gemm: ") + hipGetErrorString(he));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_launch = ms / iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(A); (void)hipFree(W); (void)hipFree(bias); (void)hipFree(gate); (void)hipFree(out); (void)hipFree(tmp);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,505 @@
+// HBM-bound and small kernels of the Latte denoiser + the sampler update (gfx950).
+//
+//  ln_modulate   : LayerNorm(eps 1e-6, no affine) + adaLN modulate -> half      latte.py:28-29,166,168,179-180
+//  small_linear  : exact-fp32 row-vector linears (t-embedder MLP, all adaLN)     latte.py:90-94,119-123,172-178,192-198
+//  patch_embed   : Conv2d(k=s=p) as a [C p p]-deep dot + bias + pos_embed        latte.py:233,330-331
+//  final_layer   : LN + modulate + Linear(D, p*p*Cout) + unpatchify              latte.py:197-201,297-310,374-376
+//  cfg_combine   : classifier-free guidance on the first 4 channels              latte.py:394-398
+//  sampler_update: p_mean_variance + p_sample / ddim_sample                      gaussian_diffusion.py:254-336,380-421,517-564
+#include "common.h"
+
+namespace latte {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int DT>
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+  }
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// One wave per token row; lane owns float2 chunks {lane + 64 c}.  Two-pass statistics in registers.
+template <int NCH, int DT, bool ADD_TE>
+__global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restrict__ x_in, float* x_rw,
+                                                          half_t* __restrict__ y, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale, int mod_stride, int M,
+                                                          int rows_per_sample, const float* __restrict__ te, int T,
+                                                          int F) {
+  constexpr int D = NCH * 128;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float2* xr = (const float2*)(x_in + (size_t)row * D);
+  float2 v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+  if constexpr (ADD_TE) {
+    const int f = (row / T) % F;
+    const float2* tr = (const float2*)(te + (size_t)f * D);
+    float2* xw = (float2*)(x_rw + (size_t)row * D);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float2 e = tr[c * 64 + lane];
+      v[c].x += e.x;
+      v[c].y += e.y;
+      xw[c * 64 + lane] = v[c];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s += v[c].x + v[c].y;
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float a = v[c].x - mean, b = v[c].y - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+  const int smp = row / rows_per_sample;
+  const float2* sh = (const float2*)(shift + (size_t)smp * mod_stride);
+  const float2* sc = (const float2*)(scale + (size_t)smp * mod_stride);
+  unsigned int* yr = (unsigned int*)(y + (size_t)row * D);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float2 a = sh[c * 64 + lane], b = sc[c * 64 + lane];
+    const float o0 = (v[c].x - mean) * rstd * (1.0f + b.x) + a.x;
+    const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
+    yr[c * 64 + lane] = pack2<DT>(o0, o1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b, n] = bias[n] + sum_k f(in[b, k]) W[n, k]   (one wave per output feature n, fp32 FMA chain)
+template <int IN_MODE>
+__global__ void __launch_bounds__(256) small_linear_kernel(const float* __restrict__ in, const int64_t* __restrict__ t,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ add_table,
+                                                           const int64_t* __restrict__ add_idx, float* __restrict__ out,
+                                                           int B, int N, int K, int out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float2* wr = (const float2*)(W + (size_t)n * K);
+  const int k2 = K >> 1;  // K % 128 == 0
+  for (int b = 0; b < B; ++b) {
+    float acc = 0.f;
+    if constexpr (IN_MODE == IN_TFREQ) {
+      // latte.py:97-117: freqs = exp(-ln(1e4) * arange(half) / half) in fp32; emb = [cos | sin]
+      const float tv = (float)t[b];
+      const int half = K >> 1;
+      for (int i = lane; i < k2; i += 64) {
+        const float2 w = wr[i];
+        float e[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = 2 * i + u;
+          const int fi = k < half ? k : k - half;
+          const float freq = expf((-9.210340371976184f * (float)fi) / (float)half);
+          const float arg = tv * freq;
+          e[u] = k < half ? cosf(arg) : sinf(arg);
+        }
+        acc = fmaf(e[0], w.x, acc);
+        acc = fmaf(e[1], w.y, acc);
+      }
+    } else {
+      const float2* ir = (const float2*)(in + (size_t)b * K);
+      for (int i = lane; i < k2; i += 64) {
+        const float2 w = wr[i];
+        float2 a = ir[i];
+        if constexpr (IN_MODE == IN_SILU) {
+          a.x = silu(a.x);
+          a.y = silu(a.y);
+        }
+        acc = fmaf(a.x, w.x, acc);
+        acc = fmaf(a.y, w.y, acc);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float r = acc + bias[n];
+      if (add_table != nullptr) r += add_table[(size_t)add_idx[b] * N + n];
+      out[(size_t)b * out_stride + n] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int PE_TOK = 8;
+__global__ void __launch_bounds__(128) patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias, const float* __restrict__ pos,
+                                                          float* __restrict__ out, int ntok, int C, int H, int p, int D) {
+  extern __shared__ float xs[];  // [PE_TOK][K]
+  const int K = C * p * p;
+  const int G = H / p, T = G * G;
+  const int tok0 = blockIdx.x * PE_TOK;
+  for (int i = threadIdx.x; i < PE_TOK * K; i += 128) {
+    const int tk = i / K, k = i % K;
+    const int n = tok0 + tk;
+    float v = 0.f;
+    if (n < ntok) {
+      const int bf = n / T, tt = n % T;
+      const int hp = tt / G, wp = tt % G;
+      const int c = k / (p * p), ii = (k / p) % p, jj = k % p;
+      v = x[(((size_t)bf * C + c) * H + hp * p + ii) * H + wp * p + jj];
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int d = blockIdx.y * 128 + threadIdx.x;
+  float acc[PE_TOK];
+#pragma unroll
+  for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = Wt[(size_t)k * D + d];
+#pragma unroll
+    for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] = fmaf(xs[tk * K + k], w, acc[tk]);
+  }
+  const float bv = bias[d];
+#pragma unroll
+  for (int tk = 0; tk < PE_TOK; ++tk) {
+    const int n = tok0 + tk;
+    if (n < ntok) out[(size_t)n * D + d] = acc[tk] + bv + pos[(size_t)(n % T) * D + d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int FL_ROWS = 8;
+template <int NCH>
+__global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale, int mod_stride,
+                                                          const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int M, int rows_per_sample, int T,
+                                                          int p, int Cout, int H) {
+  constexpr int D = NCH * 128;
+  extern __shared__ float xs[];  // [FL_ROWS][D] normalised + modulated rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * FL_ROWS;
+  for (int rr = wave; rr < FL_ROWS; rr += 4) {
+    const int row = row0 + rr;
+    float2* xo = (float2*)(xs + rr * D);
+    if (row >= M) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xo[c * 64 + lane] = make_float2(0.f, 0.f);
+      continue;
+    }
+    const float2* xr = (const float2*)(x + (size_t)row * D);
+    float2 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      v[c] = xr[c * 64 + lane];
+      s += v[c].x + v[c].y;
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float a = v[c].x - mean, b = v[c].y - mean;
+      q += a * a + b * b;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+    const int smp = row / rows_per_sample;
+    const float2* sh = (const float2*)(shift + (size_t)smp * mod_stride);
+    const float2* sc = (const float2*)(scale + (size_t)smp * mod_stride);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float2 a = sh[c * 64 + lane], b = sc[c * 64 + lane];
+      xo[c * 64 + lane] = make_float2((v[c].x - mean) * rstd * (1.0f + b.x) + a.x,
+                                      (v[c].y - mean) * rstd * (1.0f + b.y) + a.y);
+    }
+  }
+  __syncthreads();
+  const int P = p * p * Cout;
+  const int G = H / p;
+  for (int idx = threadIdx.x; idx < FL_ROWS * P; idx += 256) {
+    const int rr = idx / P, j = idx % P;
+    const int row = row0 + rr;
+    if (row >= M) continue;
+    const float* xr = xs + rr * D;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < D; k += 4) {
+      a0 = fmaf(xr[k + 0], Wt[(size_t)(k + 0) * P + j], a0);
+      a1 = fmaf(xr[k + 1], Wt[(size_t)(k + 1) * P + j], a1);
+      a2 = fmaf(xr[k + 2], Wt[(size_t)(k + 2) * P + j], a2);
+      a3 = fmaf(xr[k + 3], Wt[(size_t)(k + 3) * P + j], a3);
+    }
+    const float r = (a0 + a1) + (a2 + a3) + bias[j];
+    // unpatchify 'nhwpqc->nchpwq' (latte.py:308): j = (pi*p + qi)*Cout + c
+    const int c = j % Cout, qi = (j / Cout) % p, pi = j / (Cout * p);
+    const int bf = row / T, tt = row % T;
+    const int hp = tt / G, wp = tt % G;
+    out[(((size_t)bf * Cout + c) * H + hp * p + pi) * H + wp * p + qi] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void cfg_combine_kernel(float* out, int half_batch, int F, int Cout, int HW, float s) {
+  // eps channels are [0, 4) (hard-coded 4 in the reference, latte.py:394)
+  const size_t per_sample = (size_t)F * 4 * HW;
+  const size_t total = (size_t)half_batch * per_sample;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per_sample, r = i % per_sample;
+    const size_t f = r / (4 * (size_t)HW), q = r % (4 * (size_t)HW);
+    const size_t oc = ((b * F + f) * Cout) * HW + q;
+    const size_t ou = (((b + half_batch) * F + f) * Cout) * HW + q;
+    const float cond = out[oc], unc = out[ou];
+    const float h = unc + s * (cond - unc);
+    out[oc] = h;
+    out[ou] = h;
+  }
+}
+
+__global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ x, const float* __restrict__ mo,
+                                      const float* __restrict__ noise, int batch, int frames, int C, int hw,
+                                      int raw_cfg, float* sample_out, float* x0_out) {
+#pragma clang fp contract(off)
+  // op-for-op the fp32 tensor arithmetic of gaussian_diffusion.py (no FMA contraction)
+  const size_t chw = (size_t)C * hw;
+  const size_t total = (size_t)batch * frames * chw;
+  const int hb = batch >> 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bf = i / chw, r = i % chw;
+    const size_t b = bf / frames, f = bf % frames;
+    const size_t o = ((b * frames + f) * 2 * C) * hw + r;
+    float eps;
+    if (raw_cfg && r < (size_t)4 * hw) {
+      const size_t bc = b % hb;
+      const float cond = mo[((bc * frames + f) * 2 * C) * hw + r];
+      const float unc = mo[(((bc + hb) * frames + f) * 2 * C) * hw + r];
+      eps = unc + c.cfg_scale * (cond - unc);
+    } else {
+      eps = mo[o];
+    }
+    const float v = mo[o + chw];
+    const float xv = x[i];
+    float x0 = c.sqrt_recip * xv - c.sqrt_recipm1 * eps;               // gd:338-343
+    if (c.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    float s;
+    if (c.method == LATTE_METHOD_DDPM) {
+      const float frac = (v + 1.0f) / 2.0f;                            // gd:295
+      const float log_var = frac * c.max_log + (1.0f - frac) * c.min_log;
+      const float mean = c.coef1 * x0 + c.coef2 * xv;                  // gd:232-241
+      const float nz = noise != nullptr ? noise[i] : 0.0f;
+      s = mean + (c.nonzero * expf(0.5f * log_var)) * nz;              // gd:420
+    } else {
+      const float e2 = (c.sqrt_recip * xv - x0) / c.sqrt_recipm1;      // gd:545
+      const float mean_pred = x0 * c.sqrt_ab_prev + c.dir_coef * e2;   // gd:556-559
+      s = mean_pred;
+      if (noise != nullptr) s = mean_pred + (c.nonzero * c.sigma) * noise[i];
+    }
+    sample_out[i] = s;
+    if (x0_out != nullptr) x0_out[i] = x0;
+  }
+}
+
+template <int DT>
+__global__ void convert_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (DT == LATTE_DTYPE_BF16) {
+      const __bf16 h = (__bf16)in[i];
+      out[i] = __builtin_bit_cast(half_t, h);
+    } else {
+      const _Float16 h = (_Float16)in[i];
+      out[i] = __builtin_bit_cast(half_t, h);
+    }
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols, c = i % cols;
+    out[c * rows + r] = in[i];
+  }
+}
+
+// Philox4x32-10 (Salmon et al. 2011): counter = element-quad index, key = seed.
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+  const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0;
+  const unsigned int n1 = (unsigned int)p1;
+  const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+  const unsigned int n3 = (unsigned int)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void fill_normal_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long offset) {
+  const size_t quads = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+    // quad q covers elements [4q, 4q+4) of THIS call; the counter is the global element-quad index
+    const unsigned long long ctr = (offset >> 2) + q;
+    unsigned int c[4] = {(unsigned int)ctr, (unsigned int)(ctr >> 32), (unsigned int)(offset & 3), 0u};
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float r = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * h] = r * cs;
+      z[2 * h + 1] = r * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * q + j < n) out[4 * q + j] = z[j];
+  }
+}
+
+inline int grid_for(size_t n, int block) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g > 4096 ? 4096 : (g == 0 ? 1 : g));
+}
+
+}  // namespace
+
+#define LATTE_NCH_SWITCH(D, MACRO)                                                      \
+  switch ((D) / 128) {                                                                  \
+    case 1: MACRO(1); break;                                                            \
+    case 2: MACRO(2); break;                                                            \
+    case 3: MACRO(3); break;                                                            \
+    case 4: MACRO(4); break;                                                            \
+    case 6: MACRO(6); break;                                                            \
+    case 8: MACRO(8); break;                                                            \
+    case 9: MACRO(9); break;                                                            \
+    default: return fail(LATTE_ERR_INVALID, "hidden_size must be 128*{1,2,3,4,6,8,9}"); \
+  }
+
+int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
+                       int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T, int F,
+                       int dtype, hipStream_t st) {
+  if (D % 128 != 0) return fail(LATTE_ERR_INVALID, "ln_modulate: D % 128 != 0");
+  dim3 grid((M + 3) / 4), block(256);
+#define LN_LAUNCH(NCH)                                                                                         \
+  do {                                                                                                         \
+    if (dtype == LATTE_DTYPE_BF16) {                                                                           \
+      if (temp_embed)                                                                                          \
+        hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, true>), grid, block, 0, st, x_in, x_rw, y, \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
+      else                                                                                                     \
+        hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, false>), grid, block, 0, st, x_in, x_rw, y, \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
+    } else {                                                                                                   \
+      if (temp_embed)                                                                                          \
+        hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, true>), grid, block, 0, st, x_in, x_rw, y, \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
+      else                                                                                                     \
+        hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false>), grid, block, 0, st, x_in, x_rw, y, \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
+    }                                                                                                          \
+  } while (0)
+  LATTE_NCH_SWITCH(D, LN_LAUNCH)
+#undef LN_LAUNCH
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,
+                        const float* add_table, const int64_t* add_idx, float* out, int B, int N, int K,
+                        int out_stride, hipStream_t st) {
+  if (K % 128 != 0) return fail(LATTE_ERR_INVALID, "small_linear: K % 128 != 0");
+  dim3 grid((N + 3) / 4), block(256);
+  switch (in_mode) {
+    case IN_PLAIN:
+      hipLaunchKernelGGL(small_linear_kernel<IN_PLAIN>, grid, block, 0, st, in, t, W, bias, add_table, add_idx, out, B, N, K, out_stride);
+      break;
+    case IN_SILU:
+      hipLaunchKernelGGL(small_linear_kernel<IN_SILU>, grid, block, 0, st, in, t, W, bias, add_table, add_idx, out, B, N, K, out_stride);
+      break;
+    case IN_TFREQ:
+      hipLaunchKernelGGL(small_linear_kernel<IN_TFREQ>, grid, block, 0, st, in, t, W, bias, add_table, add_idx, out, B, N, K, out_stride);
+      break;
+    default:
+      return fail(LATTE_ERR_INVALID, "small_linear: bad input mode");
+  }
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_patch_embed(const float* x, const float* Wt, const float* bias, const float* pos, float* out, int BF,
+                       int C, int H, int p, int D, hipStream_t st) {
+  const int G = H / p, ntok = BF * G * G, K = C * p * p;
+  dim3 grid((ntok + PE_TOK - 1) / PE_TOK, D / 128), block(128);
+  hipLaunchKernelGGL(patch_embed_kernel, grid, block, PE_TOK * K * sizeof(float), st, x, Wt, bias, pos, out, ntok, C, H, p, D);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_final_layer(const float* x, const float* shift, const float* scale, int mod_stride, const float* Wt,
+                       const float* bias, float* out, int M, int D, int rows_per_sample, int T, int p, int Cout,
+                       int H, hipStream_t st) {
+  dim3 grid((M + FL_ROWS - 1) / FL_ROWS), block(256);
+  const size_t lds = (size_t)FL_ROWS * D * sizeof(float);
+#define FL_LAUNCH(NCH)                                                                                       \
+  hipLaunchKernelGGL(final_layer_kernel<NCH>, grid, block, lds, st, x, shift, scale, mod_stride, Wt, bias, out, M, \
+                     rows_per_sample, T, p, Cout, H)
+  LATTE_NCH_SWITCH(D, FL_LAUNCH)
+#undef FL_LAUNCH
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st) {
+  const size_t n = (size_t)half_batch * F * 4 * HW;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, out, half_batch, F, Cout, HW, cfg_scale);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_sampler_update(const SamplerCoefs& c, const float* x, const float* model_out, const float* noise,
+                          int batch, int frames, int channels, int hw, int raw_cfg, float* sample_out, float* x0_out,
+                          hipStream_t st) {
+  const size_t n = (size_t)batch * frames * channels * hw;
+  hipLaunchKernelGGL(sampler_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, c, x, model_out, noise, batch,
+                     frames, channels, hw, raw_cfg, sample_out, x0_out);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st) {
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  else
+    hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, out, n,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((size_t)rows * cols, 256)), dim3(256), 0, st, in, out, rows, cols);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+}  // namespace latte

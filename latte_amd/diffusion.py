@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference sampler interface (``diffusion/__init__.py``, ``respace.py``,
+``gaussian_diffusion.py``) on top of the C-ABI.
+
+* schedules: ``latte_schedule_*`` (host fp64, bit-exact timestep maps);
+* per-step update: ``latte_sampler_step`` (one fused HIP kernel instead of ~25 elementwise ops and
+  8-12 host->device coefficient copies per step, gaussian_diffusion.py:869-881);
+* whole loop: when the model callable is a ``latte_amd.Latte`` method the loop runs inside the
+  engine (``latte_sample_loop``); any other callable following the model-callable protocol is driven
+  step by step with the same update kernel.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LatteError, check, load_library, ptr, stream_ptr
+from .models import Latte
+
+_TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+           "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+           "posterior_mean_coef1", "posterior_mean_coef2", "log_betas"]
+_METHOD = {"ddpm": 0, "ddim": 1}
+
+
+class SpacedDiffusion:
+    """Stand-in for ``respace.SpacedDiffusion`` as built by ``create_diffusion``: EPSILON mean type,
+    LEARNED_RANGE variance (diffusion/__init__.py:32-46)."""
+
+    def __init__(self, timestep_respacing, noise_schedule="linear", diffusion_steps=1000):
+        lib = load_library()
+        h = _lib.c_void()
+        if isinstance(timestep_respacing, (list, tuple)):
+            timestep_respacing = ",".join(str(int(v)) for v in timestep_respacing)
+        spec = "" if timestep_respacing is None else str(timestep_respacing)
+        check(lib.latte_schedule_create(int(diffusion_steps), spec.encode(), noise_schedule.encode(), h))
+        self._h = h
+        self.original_num_steps = int(diffusion_steps)
+        self.num_timesteps = lib.latte_schedule_num_timesteps(h)
+        n = self.num_timesteps
+        tm = np.empty(n, dtype=np.int64)
+        check(lib.latte_schedule_timestep_map(h, tm.ctypes.data_as(ctypes.c_void_p), n))
+        self.timestep_map = tm.tolist()
+        self.use_timesteps = set(self.timestep_map)
+        for name in _TABLES:
+            if name == "posterior_log_variance_clipped" and n < 2:
+                setattr(self, name, np.array([]))
+                continue
+            arr = np.empty(n, dtype=np.float64)
+            check(lib.latte_schedule_table(h, name.encode(), arr.ctypes.data_as(ctypes.c_void_p), n))
+            setattr(self, name, arr)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                load_library().latte_schedule_destroy(self._h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _engine_model(model):
+        """(Latte instance, uses_cfg) when `model` is a bound latte_amd.Latte method, else (None, False)."""
+        owner = getattr(model, "__self__", None)
+        if isinstance(model, Latte):
+            return model, False
+        if isinstance(owner, Latte):
+            fn = getattr(model, "__func__", None)
+            if fn is Latte.forward:
+                return owner, False
+            if fn is Latte.forward_with_cfg:
+                return owner, True
+        return None, False
+
+    def _device(self, model, device):
+        if device is not None:
+            return torch.device(device)
+        owner = getattr(model, "__self__", model)
+        return next(owner.parameters()).device                                     # gd:487-488
+
+    def _step(self, method, model_output, x, index, noise, eta, clip_denoised):
+        _lib.require_gpu()
+        B, F, C = x.shape[:3]
+        if model_output.shape != (B, F, C * 2, *x.shape[3:]):                      # gd:290
+            raise AssertionError(f"model output shape {tuple(model_output.shape)} != {(B, F, C * 2, *x.shape[3:])}")
+        x32 = x.float().contiguous()
+        mo = model_output.float().contiguous()
+        nz = None if noise is None else noise.float().contiguous()
+        sample = torch.empty_like(x32)
+        x0 = torch.empty_like(x32)
+        hw = int(np.prod(x.shape[3:]))
+        with torch.cuda.device(x32.device):
+            check(load_library().latte_sampler_step(self._h, _METHOD[method], int(index), float(eta),
+                                                    int(bool(clip_denoised)), ptr(x32), ptr(mo), ptr(nz), B, F, C, hw,
+                                                    ptr(sample), ptr(x0), stream_ptr()))
+        return {"sample": sample, "pred_xstart": x0}
+
+    def _call_model(self, model, x, index, model_kwargs):
+        # respace.py:125-130: the model sees ORIGINAL timesteps
+        t = torch.full((x.shape[0],), self.timestep_map[index], device=x.device, dtype=torch.int64)
+        out = model(x, t, **model_kwargs)
+        if isinstance(out, tuple):                                                  # gd:284-287
+            out = out[0]
+        return out
+
+    # ------------------------------------------------------------------ single steps (gd:380-421, :517-564)
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
+        self._no_hooks(denoised_fn, cond_fn)
+        index = self._uniform_index(t)
+        out = self._call_model(model, x, index, model_kwargs or {})
+        return self._step("ddpm", out, x, index, torch.randn_like(x.float()), 0.0, clip_denoised)
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        self._no_hooks(denoised_fn, cond_fn)
+        index = self._uniform_index(t)
+        out = self._call_model(model, x, index, model_kwargs or {})
+        return self._step("ddim", out, x, index, torch.randn_like(x.float()), eta, clip_denoised)
+
+    @staticmethod
+    def _no_hooks(denoised_fn, cond_fn):
+        if denoised_fn is not None or cond_fn is not None:
+            raise LatteError("denoised_fn / cond_fn hooks are not part of the accelerated sampling path "
+                             "(sample.py never passes them)")
+
+    @staticmethod
+    def _uniform_index(t):
+        tv = t.tolist()
+        if any(v != tv[0] for v in tv):
+            raise LatteError("the fused sampler step takes one timestep index for the whole batch "
+                             "(the sampling loops always do, gaussian_diffusion.py:503,671)")
+        return int(tv[0])
+
+    # ------------------------------------------------------------------ loops (gd:423-515, :604-684)
+    def _loop(self, method, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
+              eta, progressive):
+        self._no_hooks(denoised_fn, cond_fn)
+        _lib.require_gpu()
+        model_kwargs = dict(model_kwargs or {})
+        device = self._device(model, device)
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        img = img.to(device=device, dtype=torch.float32).contiguous().clone()
+        n = self.num_timesteps
+        needs_noise = method == "ddpm" or eta != 0.0
+        owner, uses_cfg = self._engine_model(model)
+        known = {"y", "use_fp16", "cfg_scale", "text_embedding"}
+        if owner is not None and set(model_kwargs) <= known and model_kwargs.get("text_embedding") is None:
+            # ---- whole chain inside the engine
+            B = img.shape[0]
+            y = model_kwargs.get("y")
+            x32, _, y64 = owner._prep(img, torch.zeros(B, dtype=torch.int64), y)
+            eng = owner.engine(B)
+            cfg_scale = float(model_kwargs.get("cfg_scale", 7.0)) if uses_cfg else 1.0
+            if uses_cfg and cfg_scale <= 1.0:
+                raise LatteError("forward_with_cfg inside the fused loop needs cfg_scale > 1 (sample.py:51)")
+            nz = None
+            if needs_noise:   # same draws, same order as the reference's per-step randn_like (gd:413,555)
+                nz = torch.stack([torch.randn_like(x32) for _ in range(n)])
+            trail_s = trail_0 = None
+            if progressive:
+                trail_s = torch.empty((n,) + tuple(x32.shape), device=device, dtype=torch.float32)
+                trail_0 = torch.empty_like(trail_s)
+            with torch.cuda.device(device):
+                check(load_library().latte_sample_loop(eng, self._h, _METHOD[method], float(eta),
+                                                       int(bool(clip_denoised)), cfg_scale, ptr(x32), ptr(y64), B,
+                                                       n - 1, 0, ptr(nz), ptr(trail_s), ptr(trail_0), stream_ptr()))
+            if progressive:
+                for k in range(n):
+                    yield {"sample": trail_s[k], "pred_xstart": trail_0[k]}
+            else:
+                yield {"sample": x32, "pred_xstart": None}
+            return
+        # ---- generic model callable, step by step
+        indices = list(range(n))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            out = self._call_model(model, img, i, model_kwargs)
+            nz = torch.randn_like(img) if needs_noise else None
+            r = self._step(method, out, img, i, nz, eta, clip_denoised)
+            yield r
+            img = r["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False):
+        yield from self._loop("ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                              progress, 0.0, True)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
+        yield from self._loop("ddim", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                              progress, eta, True)
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False):
+        final = None
+        for final in self._loop("ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                                progress, 0.0, False):
+            pass
+        return final["sample"]
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0):
+        final = None
+        for final in self._loop("ddim", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                                progress, eta, False):
+            pass
+        return final["sample"]
+
+    def training_losses(self, *a, **k):
+        raise LatteError("training_losses is outside the accelerated sampling path (SURVEY.md §8(f) rank 3)")
+
+
+def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
+                     predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000):
+    """``diffusion.create_diffusion`` (diffusion/__init__.py:10-47).  The accelerated path covers the
+    configuration every Latte sampling script uses: epsilon prediction with learned-range variance."""
+    if predict_xstart or not learn_sigma or sigma_small:
+        raise LatteError("latte_amd implements the sampler configuration Latte ships: predict_xstart=False, "
+                         "learn_sigma=True (EPSILON mean, LEARNED_RANGE variance)")
+    if timestep_respacing is None or timestep_respacing == "":
+        timestep_respacing = [diffusion_steps]
+    return SpacedDiffusion(timestep_respacing, noise_schedule=noise_schedule, diffusion_steps=diffusion_steps)

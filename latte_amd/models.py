@@ -1,0 +1,325 @@
+"""Host-side mirror of the reference model interface (``models/latte.py``, ``models/__init__.py``).
+
+``Latte`` keeps the reference constructor signature, parameter names (so reference checkpoints
+``load_state_dict`` unchanged: SURVEY.md §8(b)) and the model-callable protocol
+``model(x, t, **kwargs) -> [B,F,2C,H,W]`` (gaussian_diffusion.py:279-291) — but it never runs a
+PyTorch op on the data path: ``forward`` / ``forward_with_cfg`` hand device pointers to the HIP
+engine through the C-ABI (``include/latte_amd.h``).  No GPU / no library -> it raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import LatteError, ModelConfig, check, load_library, ptr, stream_ptr
+
+
+# ---------------------------------------------------------------------------- fixed embeddings
+def _sincos_1d(embed_dim, pos):
+    """latte.py:438-457 (fp64): [sin(pos * w) | cos(pos * w)], w_i = 10000^(-2i/embed_dim)."""
+    omega = 1.0 / 10000 ** (np.arange(embed_dim // 2, dtype=np.float64) / (embed_dim / 2.0))
+    out = np.einsum("m,d->md", np.asarray(pos, dtype=np.float64).reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size):
+    """latte.py:410-436; meshgrid(w, h) with w first — first half of the dims encodes grid[0]."""
+    axis = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(axis, axis), axis=0)
+    return np.concatenate([_sincos_1d(embed_dim // 2, grid[0]), _sincos_1d(embed_dim // 2, grid[1])], axis=1)
+
+
+def get_1d_sincos_temp_embed(embed_dim, length):
+    """latte.py:406-408."""
+    return _sincos_1d(embed_dim, np.arange(length))
+
+
+# ---------------------------------------------------------------------------- parameter containers
+class _Holder(nn.Module):
+    """Parameter container; never called (the compute lives in the HIP engine)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise LatteError("latte_amd parameter containers are not callable; use Latte.forward")
+
+
+def _linear(out_f, in_f):
+    h = _Holder()
+    h.weight = nn.Parameter(torch.empty(out_f, in_f))
+    h.bias = nn.Parameter(torch.zeros(out_f))
+    return h
+
+
+class Latte(nn.Module):
+    """Drop-in for ``models.latte.Latte`` (latte.py:204-398) backed by the MI355X engine.
+
+    Extra keyword arguments (not in the reference): ``compute_dtype`` ("bf16" | "f16": MFMA operand
+    type; accumulation / residual / statistics are always fp32) and ``max_batch`` (engine workspace).
+    """
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, num_frames=16, class_dropout_prob=0.1, num_classes=1000, learn_sigma=True,
+                 extras=1, attention_mode="math", compute_dtype="bf16", max_batch=2):
+        super().__init__()
+        if hidden_size % num_heads != 0:
+            raise AssertionError("dim should be divisible by num_heads")          # latte.py:38
+        if extras not in (1, 2):
+            raise LatteError("latte_amd supports extras=1 (unconditional) and extras=2 (class-conditional); "
+                             "the text-embedding variant (extras=78) is outside the accelerated path")
+        if attention_mode not in ("math", "flash", "xformers"):
+            raise NotImplementedError(attention_mode)                             # latte.py:73
+        self.learn_sigma = learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.extras = extras
+        self.num_frames = num_frames
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.depth = depth
+        self.num_classes = num_classes if num_classes is not None else 0
+        self.mlp_hidden = int(hidden_size * mlp_ratio)
+        self.compute_dtype = compute_dtype
+        self.max_batch = max_batch
+        D = hidden_size
+        num_patches = (input_size // patch_size) ** 2
+
+        self.x_embedder = _Holder()
+        self.x_embedder.proj = _Holder()
+        self.x_embedder.proj.weight = nn.Parameter(torch.empty(D, in_channels, patch_size, patch_size))
+        self.x_embedder.proj.bias = nn.Parameter(torch.zeros(D))
+        self.t_embedder = _Holder()
+        self.t_embedder.mlp = nn.ModuleList([_linear(D, 256), nn.SiLU(), _linear(D, D)])
+        if extras == 2:
+            use_cfg_embedding = class_dropout_prob > 0                            # latte.py:130-131
+            self.y_embedder = _Holder()
+            self.y_embedder.embedding_table = _Holder()
+            self.y_embedder.embedding_table.weight = nn.Parameter(
+                torch.empty(self.num_classes + int(use_cfg_embedding), D))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, D), requires_grad=False)
+        self.temp_embed = nn.Parameter(torch.zeros(1, num_frames, D), requires_grad=False)
+        blocks = []
+        for _ in range(depth):
+            b = _Holder()
+            b.attn = _Holder()
+            b.attn.qkv = _linear(3 * D, D)
+            b.attn.proj = _linear(D, D)
+            b.mlp = _Holder()
+            b.mlp.fc1 = _linear(self.mlp_hidden, D)
+            b.mlp.fc2 = _linear(D, self.mlp_hidden)
+            b.adaLN_modulation = nn.ModuleList([nn.SiLU(), _linear(6 * D, D)])
+            blocks.append(b)
+        self.blocks = nn.ModuleList(blocks)
+        self.final_layer = _Holder()
+        self.final_layer.linear = _linear(patch_size * patch_size * self.out_channels, D)
+        self.final_layer.adaLN_modulation = nn.ModuleList([nn.SiLU(), _linear(2 * D, D)])
+        self.initialize_weights()
+        self._engine = None
+        self._engine_key = None
+        self._synced = False
+
+    # ------------------------------------------------------------------ init (latte.py:257-295)
+    def initialize_weights(self):
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith(".weight") and p.dim() == 2 and "embedding_table" not in name:
+                    nn.init.xavier_uniform_(p)
+                elif name.endswith(".bias"):
+                    p.zero_()
+            D = self.hidden_size
+            self.pos_embed.copy_(torch.from_numpy(
+                get_2d_sincos_pos_embed(D, self.input_size // self.patch_size)).float().unsqueeze(0))
+            self.temp_embed.copy_(torch.from_numpy(get_1d_sincos_temp_embed(D, self.num_frames)).float().unsqueeze(0))
+            w = self.x_embedder.proj.weight
+            nn.init.xavier_uniform_(w.view(w.shape[0], -1))
+            if self.extras == 2:
+                nn.init.normal_(self.y_embedder.embedding_table.weight, std=0.02)
+            nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+            nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+            for b in self.blocks:                                                  # adaLN-Zero
+                b.adaLN_modulation[-1].weight.zero_()
+                b.adaLN_modulation[-1].bias.zero_()
+            self.final_layer.adaLN_modulation[-1].weight.zero_()
+            self.final_layer.adaLN_modulation[-1].bias.zero_()
+            self.final_layer.linear.weight.zero_()
+            self.final_layer.linear.bias.zero_()
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._synced = False
+        return r
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._synced = False
+        return r
+
+    def mark_weights_dirty(self):
+        """Call after mutating parameters in place so the engine re-packs them."""
+        self._synced = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_engine", None):
+                load_library().latte_engine_destroy(self._engine)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ engine management
+    def engine_config(self):
+        cfg = ModelConfig()
+        cfg.input_size, cfg.patch_size, cfg.in_channels = self.input_size, self.patch_size, self.in_channels
+        cfg.hidden_size, cfg.depth, cfg.num_heads = self.hidden_size, self.depth, self.num_heads
+        cfg.mlp_hidden, cfg.num_frames = self.mlp_hidden, self.num_frames
+        cfg.num_classes = (self.y_embedder.embedding_table.weight.shape[0] - 1) if self.extras == 2 else 0
+        cfg.learn_sigma, cfg.extras = int(self.learn_sigma), self.extras
+        if self.compute_dtype not in _lib.DTYPES:
+            raise LatteError(f"compute_dtype must be one of {sorted(_lib.DTYPES)}")
+        cfg.compute_dtype = _lib.DTYPES[self.compute_dtype]
+        return cfg
+
+    def engine(self, batch):
+        """Engine handle for a batch of ``batch`` samples on the parameters' device (created / re-packed lazily)."""
+        _lib.require_gpu()
+        lib = load_library()
+        dev = self.pos_embed.device
+        if dev.type != "cuda":
+            raise LatteError("latte_amd.Latte runs on an MI355X only: move the module with .to('cuda') "
+                             "(there is no CPU fallback)")
+        want = max(batch, self.max_batch)
+        key = (dev.index, want, self.compute_dtype)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                lib.latte_engine_destroy(self._engine)
+                self._engine = None
+            h = _lib.c_void()
+            cfg = self.engine_config()
+            with torch.cuda.device(dev):
+                check(lib.latte_engine_create(cfg, want, h))
+            self._engine, self._engine_key, self._synced = h, key, False
+            self.max_batch = want
+        if not self._synced:
+            sd = self.state_dict()
+            with torch.cuda.device(dev):
+                for i in range(lib.latte_engine_num_keys(self._engine)):
+                    k = lib.latte_engine_key(self._engine, i).decode()
+                    if k not in sd:
+                        raise LatteError(f'Missing key(s) in state_dict: "{k}"')
+                    t = sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
+                    check(lib.latte_engine_load_tensor(self._engine, k.encode(), ptr(t), t.numel(), 1, stream_ptr()))
+                check(lib.latte_engine_check_weights(self._engine))
+                torch.cuda.current_stream().synchronize()
+            self._synced = True
+        return self._engine
+
+    def set_engine_option(self, name, value, batch=1):
+        check(load_library().latte_engine_set_option(self.engine(batch), name.encode(), int(value)))
+
+    # ------------------------------------------------------------------ the model-callable protocol
+    def _prep(self, x, t, y):
+        if x.dim() != 5:
+            raise LatteError("x must be [B, F, C, H, W]")
+        B, F, C, H, W = x.shape
+        if (F, C, H, W) != (self.num_frames, self.in_channels, self.input_size, self.input_size):
+            raise LatteError(f"input shape {tuple(x.shape)} does not match the model "
+                             f"(F={self.num_frames}, C={self.in_channels}, H=W={self.input_size})")
+        dev = self.pos_embed.device
+        x32 = x.to(device=dev, dtype=torch.float32).contiguous()
+        t64 = t.to(device=dev, dtype=torch.int64).contiguous()
+        if t64.shape != (B,):
+            raise LatteError("t must have shape [B]")
+        y64 = None
+        if self.extras == 2:
+            if y is None:
+                raise LatteError("class-conditional Latte (extras=2) needs labels y")
+            y64 = y.to(device=dev, dtype=torch.int64).contiguous()
+            if y64.shape != (B,):
+                raise LatteError("y must have shape [B]")
+        return x32, t64, y64
+
+    def forward(self, x, t, y=None, text_embedding=None, use_fp16=False):
+        """``Latte.forward`` (latte.py:314-377): x [B,F,C,H,W], t int64[B] -> fp32 [B,F,Cout,H,W]."""
+        x32, t64, y64 = self._prep(x, t, y)
+        B = x32.shape[0]
+        eng = self.engine(B)
+        out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
+                          device=x32.device, dtype=torch.float32)
+        with torch.cuda.device(x32.device):
+            check(load_library().latte_forward(eng, ptr(x32), ptr(t64), ptr(y64), B, ptr(out), stream_ptr()))
+        return out
+
+    def forward_with_cfg(self, x, t, y=None, cfg_scale=7.0, use_fp16=False, text_embedding=None):
+        """``Latte.forward_with_cfg`` (latte.py:379-398)."""
+        x32, t64, y64 = self._prep(x, t, y)
+        B = x32.shape[0]
+        if B % 2:
+            raise LatteError("forward_with_cfg expects the doubled batch [2b, ...] (sample.py:88-94)")
+        eng = self.engine(B)
+        out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
+                          device=x32.device, dtype=torch.float32)
+        with torch.cuda.device(x32.device):
+            check(load_library().latte_forward_with_cfg(eng, ptr(x32), ptr(t64), ptr(y64), B, float(cfg_scale),
+                                                        ptr(out), stream_ptr()))
+        return out
+
+    def profile_forward(self, x, t, y=None):
+        """One eager forward with HIP events around every launch -> {class: (ms, launches)} (bench.py)."""
+        names = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial", "attn_temporal", "ln_modulate",
+                 "embed_cond", "patch_embed", "final_layer"]
+        x32, t64, y64 = self._prep(x, t, y)
+        B = x32.shape[0]
+        eng = self.engine(B)
+        out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
+                          device=x32.device, dtype=torch.float32)
+        ms = (_lib.c_f32 * len(names))()
+        cnt = (_lib.c_int * len(names))()
+        with torch.cuda.device(x32.device):
+            check(load_library().latte_profile_forward(eng, ptr(x32), ptr(t64), ptr(y64), B, ptr(out), ms, cnt,
+                                                       len(names), stream_ptr()))
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names)}
+
+
+# ---------------------------------------------------------------------------- presets (latte.py:464-506)
+def _preset(depth, hidden, patch, heads):
+    def make(**kwargs):
+        return Latte(depth=depth, hidden_size=hidden, patch_size=patch, num_heads=heads, **kwargs)
+    return make
+
+
+Latte_models = {}
+for _fam, (_d, _h, _nh) in {"XL": (28, 1152, 16), "L": (24, 1024, 16), "B": (12, 768, 12), "S": (12, 384, 6)}.items():
+    for _p in (2, 4, 8):
+        Latte_models[f"Latte-{_fam}/{_p}"] = _preset(_d, _h, _p, _nh)
+
+
+def get_models(args):
+    """``models.get_models`` (models/__init__.py:31-51) for the accelerated family."""
+    name = args.model
+    if "LatteIMG" in name or "LatteT2V" in name:
+        raise LatteError(f"{name}: only the class-conditional / unconditional Latte family runs on the "
+                         "MI355X engine in this build (SURVEY.md §8(f) lists LatteT2V as the next row)")
+    if name in Latte_models:
+        extra = {}
+        for k in ("compute_dtype", "max_batch"):
+            v = args.get(k) if hasattr(args, "get") else getattr(args, k, None)
+            if v is not None:
+                extra[k] = v
+        return Latte_models[name](input_size=args.latent_size, num_classes=args.num_classes,
+                                  num_frames=args.num_frames, learn_sigma=args.learn_sigma, extras=args.extras,
+                                  **extra)
+    raise LatteError("{} Model Not Supported!".format(name))
+
+
+def find_model(model_name):
+    """``utils.find_model`` (utils.py:274-287): checkpoint dict -> 'ema' weights if present."""
+    checkpoint = torch.load(model_name, map_location=lambda storage, loc: storage)
+    if "ema" in checkpoint:
+        print("Using Ema!")
+        checkpoint = checkpoint["ema"]
+    else:
+        print("Using model!")
+        checkpoint = checkpoint["model"]
+    return checkpoint

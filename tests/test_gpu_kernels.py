@@ -1,0 +1,136 @@
+"""Every HIP kernel against the PyTorch op sequence it replaces (through the C-ABI test hooks)."""
+import pytest
+import torch
+
+from latte_amd._lib import check, ptr, stream_ptr
+
+pytestmark = pytest.mark.gpu
+TD = {0: torch.bfloat16, 1: torch.float16}
+# half-precision operand rounding: unit roundoff 2^-9 (bf16) / 2^-11 (f16)
+OUT_TOL = {0: 6e-3, 1: 1e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608)])
+def test_gemm_epilogues(lib, dev, dt, variant, shape):
+    M, N, K = shape
+    if variant == 3 and N % 256:
+        pytest.skip("256x256 tile needs N % 256 == 0")
+    g = torch.Generator("cpu").manual_seed(M + N + K)
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, K, generator=g).to(dev).to(TD[dt])
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = A.float()[:M] @ W.float().t() + bias            # same rounded operands, fp32 accumulate
+    rps = 64
+    gate = torch.randn((M + rps - 1) // rps, 2 * N, generator=g).to(dev)
+    for epi in (0, 1, 2, 3):
+        if epi in (0, 1):
+            out = torch.zeros(Mp, N, dtype=TD[dt], device=dev)
+        else:
+            out = torch.randn(Mp, N, generator=g).to(dev)
+        out0 = out.clone()
+        check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 2 * N, rps, epi, dt,
+                                   variant, stream_ptr()))
+        torch.cuda.synchronize()
+        if epi == 0:
+            want, tol = ref, OUT_TOL[dt]
+        elif epi == 1:
+            want, tol = torch.nn.functional.gelu(ref, approximate="tanh"), OUT_TOL[dt]
+        elif epi == 2:
+            gi = torch.arange(M, device=dev) // rps
+            want, tol = out0[:M] + gate[gi, :N] * ref, 2e-5
+        else:
+            want, tol = ref, 2e-5
+        got = out[:M].float()
+        rel = float((got - want).norm() / want.norm())
+        assert rel < tol, (epi, rel)
+        if M < Mp:
+            assert torch.equal(out[M:], out0[M:]), "rows beyond M must not be written"
+
+
+CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),
+         (2, 4, 4, 2, 64)]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mode", ["spatial", "temporal"])
+def test_attention(lib, dev, dt, case, mode):
+    B, F, T, H, hd = case
+    D, rows = H * hd, B * F * T
+    g = torch.Generator("cpu").manual_seed(rows + hd)
+    qh = torch.randn(rows, 3 * D, generator=g).to(dev).to(TD[dt])
+    q5 = qh.float().view(B, F, T, 3, H, hd)
+    if mode == "spatial":
+        q, k, v = [q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3)]
+        a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v
+        want = a.permute(0, 1, 3, 2, 4).reshape(rows, D)
+        args = (B * F, T, H, hd, F, F * T, T, 1)
+    else:
+        q, k, v = [q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3)]
+        a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v
+        want = a.permute(0, 3, 1, 2, 4).reshape(rows, D)
+        args = (B * T, F, H, hd, T, F * T, 1, T)
+    out = torch.zeros(rows, D, dtype=TD[dt], device=dev)
+    check(lib.latte_debug_attention(ptr(qh), ptr(out), *args, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    rel = float((out.float() - want).norm() / want.norm())
+    assert rel < (8e-3 if dt == 0 else 1.5e-3), rel
+
+
+def test_attention_forced_rescale(lib, dev):
+    """Online-softmax rescale branch: one key dominates late in the sequence (guide §5.4 rule 26)."""
+    B, F, T, H, hd, dt = 1, 1, 256, 1, 64, 1
+    g = torch.Generator("cpu").manual_seed(7)
+    qkv = torch.randn(T, 3 * hd, generator=g)
+    qkv[200, hd:2 * hd] = qkv[5, :hd] * 6.0          # key 200 (4th tile) spikes against query 5
+    qh = qkv.to(dev).to(TD[dt])
+    q, k, v = qh.float()[:, :hd], qh.float()[:, hd:2 * hd], qh.float()[:, 2 * hd:]
+    want = torch.softmax((q @ k.t()).double() * hd ** -0.5, dim=-1).float() @ v
+    out = torch.zeros(T, hd, dtype=TD[dt], device=dev)
+    check(lib.latte_debug_attention(ptr(qh), ptr(out), 1, T, 1, hd, 1, T, T, 1, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((out.float() - want).norm() / want.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("D", [128, 384, 768, 1024, 1152])
+@pytest.mark.parametrize("use_te", [False, True])
+def test_ln_modulate(lib, dev, dt, D, use_te):
+    B, F, T = 2, 4, 16
+    M = B * F * T
+    g = torch.Generator("cpu").manual_seed(D)
+    x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(dev)
+    mod = torch.randn(B, 6 * D, generator=g).to(dev)
+    te = torch.randn(F, D, generator=g).to(dev)
+    xin = x.clone()
+    y = torch.zeros(M, D, dtype=TD[dt], device=dev)
+    check(lib.latte_debug_ln_modulate(ptr(xin), ptr(y), ptr(mod), ptr(mod[:, D:]), 6 * D, M, D, F * T,
+                                      ptr(te) if use_te else None, T, F, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    xr = (x.view(B, F, T, D) + te.view(1, F, 1, D)).view(M, D) if use_te else x
+    s = torch.arange(M, device=dev) // (F * T)
+    want = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6) * (1 + mod[s, D:2 * D]) + mod[s, :D]
+    assert float((y.float() - want).norm() / want.norm()) < (3e-3 if dt == 0 else 4e-4)
+    assert torch.allclose(xin, xr, rtol=0, atol=1e-6)
+
+
+def test_fill_normal_moments(lib, dev):
+    n = 1 << 22
+    out = torch.empty(n, device=dev)
+    check(lib.latte_debug_fill_normal(ptr(out), n, 123, 0, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert abs(float(out.mean())) < 3e-3 and abs(float(out.std()) - 1) < 3e-3
+    assert abs(float((out ** 4).mean()) - 3.0) < 0.05
+    out2 = torch.empty(n, device=dev)
+    check(lib.latte_debug_fill_normal(ptr(out2), n, 123, 0, stream_ptr()))
+    assert torch.equal(out, out2)                      # counter-based: reproducible

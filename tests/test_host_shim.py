@@ -1,0 +1,92 @@
+"""Host-side mirror of the reference interface (no GPU): registry, state_dict key set, config
+loading, create_diffusion, and the product path refusing to run without its HIP backend."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import latte_amd
+from _util import load_golden_model
+
+
+def test_registry_has_the_twelve_presets():
+    want = {f"Latte-{f}/{p}" for f in ("XL", "L", "B", "S") for p in (2, 4, 8)}
+    assert set(latte_amd.Latte_models) == want                      # latte.py:501-506
+
+
+def test_state_dict_keys_match_reference_checkpoint():
+    for name in ("tiny_classcond", "tiny_uncond"):
+        kw, sd, _ = load_golden_model(name)
+        m = latte_amd.Latte(**kw)
+        own = m.state_dict()
+        assert set(own) == set(sd)
+        for k in sd:
+            assert tuple(own[k].shape) == tuple(sd[k].shape), k
+        m.load_state_dict(sd, strict=True)
+        # fixed sin-cos tables are rebuilt identically to the checkpoint's (latte.py:266-271)
+        m2 = latte_amd.Latte(**kw)
+        assert torch.equal(m2.pos_embed, sd["pos_embed"]) and torch.equal(m2.temp_embed, sd["temp_embed"])
+
+
+def test_default_init_is_adaln_zero():
+    m = latte_amd.Latte_models["Latte-S/2"](input_size=8, num_frames=4, num_classes=5, extras=2)
+    assert float(m.blocks[0].adaLN_modulation[1].weight.abs().max()) == 0.0
+    assert float(m.final_layer.linear.weight.abs().max()) == 0.0
+    assert m.y_embedder.embedding_table.weight.shape == (6, 384)
+    n = sum(p.numel() for p in latte_amd.Latte_models["Latte-S/2"](input_size=64, num_frames=4).parameters())
+    assert abs(n / 1e6 - 32.9) < 0.2                                   # 32.9 M
+
+
+def test_get_models_reads_reference_config_keys(tmp_path):
+    y = tmp_path / "sample.yaml"
+    y.write_text("ckpt:\nmodel: Latte-S/2\nnum_frames: 4\nimage_size: 64\nlearn_sigma: True\nextras: 2\n"
+                 "num_classes: 101\nuse_fp16: True\nsample_method: 'ddpm'\nnum_sampling_steps: 250\ncfg_scale: 7.0\n"
+                 "per_proc_batch_size: 2\nnum_fvd_samples: 2\n")
+    cfg = latte_amd.load_config(str(y))
+    cfg.ckpt = "x.pt"                                                   # sample.py:137
+    cfg.latent_size = cfg.image_size // 8                               # sample.py:54-55
+    assert cfg.ckpt == "x.pt" and cfg.cfg_scale == 7.0 and cfg.sample_method == "ddpm"
+    m = latte_amd.get_models(cfg)
+    assert m.input_size == 8 and m.extras == 2 and m.num_frames == 4
+    cfg.model = "LatteT2V"
+    with pytest.raises(latte_amd.LatteError):
+        latte_amd.get_models(cfg)
+
+
+def test_create_diffusion_surface():
+    d = latte_amd.create_diffusion("250")
+    assert d.num_timesteps == 250 and d.timestep_map[:3] == [0, 4, 8] and d.timestep_map[-1] == 999
+    assert abs(d.betas[-1] - 0.077519344992350026) < 1e-18
+    assert abs(d.alphas_cumprod[-1] - 4.0358297653756747e-05) < 1e-19
+    d = latte_amd.create_diffusion("")
+    assert d.num_timesteps == 1000
+    with pytest.raises(latte_amd.LatteError):
+        latte_amd.create_diffusion("250", learn_sigma=False)
+    with pytest.raises(latte_amd.LatteError):
+        latte_amd.create_diffusion("ddim600")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    m = latte_amd.Latte_models["Latte-S/2"](input_size=8, num_frames=4)
+    with pytest.raises(latte_amd.LatteError):
+        m(torch.zeros(1, 4, 4, 8, 8), torch.zeros(1, dtype=torch.int64))
+    d = latte_amd.create_diffusion("10")
+    with pytest.raises(latte_amd.LatteError):
+        d.ddim_sample_loop(m.forward, (1, 4, 4, 8, 8), torch.zeros(1, 4, 4, 8, 8), clip_denoised=False,
+                           model_kwargs=dict(y=None), device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = "import sys, latte_amd; bad=[m for m in sys.modules if m.split('.')[0]=='oracle']; assert not bad, bad"
+    subprocess.run([sys.executable, "-c", code], check=True,
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "latte_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

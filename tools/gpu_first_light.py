@@ -1,0 +1,313 @@
+"""First-light / measurement report on a real MI355X (run through gpurun; writes gpurun_out/first_light.log).
+
+Not a test: every section is independent and prints errors + timings so one run answers as many
+questions as possible (GPU minutes are scarce)."""
+import ctypes
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+LOG = open(os.path.join(OUT, "first_light.log"), "a")
+
+
+def log(*a):
+    s = " ".join(str(x) for x in a)
+    print(s, flush=True)
+    LOG.write(s + "\n")
+    LOG.flush()
+
+
+def section(fn):
+    log(f"\n===== {fn.__name__} =====")
+    t0 = time.time()
+    try:
+        fn()
+    except Exception:
+        log("SECTION FAILED:\n" + traceback.format_exc())
+    log(f"[{fn.__name__}: {time.time() - t0:.1f}s]")
+
+
+from latte_amd import _lib  # noqa: E402
+from latte_amd._lib import check, load_library, ptr, stream_ptr  # noqa: E402
+
+lib = load_library()
+dev = torch.device("cuda")
+TD = {0: torch.bfloat16, 1: torch.float16}
+
+
+def to_h16(x, dt):
+    return x.to(TD[dt]).contiguous()
+
+
+def env():
+    log("torch", torch.__version__, "hip", torch.version.hip, "dev", torch.cuda.get_device_name(0))
+    p = torch.cuda.get_device_properties(0)
+    log("CUs", p.multi_processor_count, "mem GB", p.total_memory / 2**30, "cpus", os.cpu_count())
+    log(lib.latte_version().decode())
+
+
+def tr16_probe():
+    out = torch.zeros(256, dtype=torch.int16, device=dev)
+    check(lib.latte_debug_tr16_probe(ptr(out), stream_ptr()))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().astype(np.int64).reshape(64, 4)
+    for l in range(0, 64, 1):
+        if l < 20 or l % 16 == 0:
+            log(f"lane {l:2d}: {o[l].tolist()}")
+    # hypothesis: out[l][j] = lds[ 4*(4*j + (l&15)>>2) + (l&3) + 64*(l>>4) ]
+    ok = True
+    for l in range(64):
+        for j in range(4):
+            i = l & 15
+            want = 64 * (l >> 4) + 4 * (4 * j + (i >> 2)) + (i & 3)
+            ok &= (o[l, j] == want)
+    log("hypothesis out[l][j] = lds[64*(l>>4) + 16*j + 4*((l&15)>>2) + (l&3)]... ->", ok)
+    ok2 = all(o[l, j] == 64 * (l >> 4) + 16 * j + (l & 15) for l in range(64) for j in range(4))
+    log("hypothesis out[l][j] = lds[64*(l>>4) + 16*j + (l&15)] ->", ok2)
+
+
+def gemm_checks():
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for dt in (0, 1):
+        for variant in (1, 2, 3):
+            for (M, N, K) in [(256, 256, 128), (512, 768, 1152), (300, 512, 256)]:
+                if variant == 3 and N % 256:
+                    continue
+                Mp = (M + 255) // 256 * 256
+                A = torch.randn(Mp, K, generator=g).to(dev)
+                W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+                bias = torch.randn(N, generator=g).to(dev)
+                Ah, Wh = to_h16(A, dt), to_h16(W, dt)
+                ref = Ah.float()[:M] @ Wh.float().t() + bias
+                for epi in (0, 1, 2, 3):
+                    rps = 64
+                    nsamp = (M + rps - 1) // rps
+                    gate = torch.randn(nsamp, 2 * N, generator=g).to(dev)
+                    if epi in (0, 1):
+                        out = torch.zeros(Mp, N, dtype=TD[dt], device=dev)
+                    else:
+                        out = torch.randn(Mp, N, generator=g).to(dev)
+                    out0 = out.clone()
+                    check(lib.latte_debug_gemm(ptr(Ah), ptr(Wh), ptr(bias), ptr(out), ptr(gate), M, N, K,
+                                               2 * N, rps, epi, dt, variant, stream_ptr()))
+                    torch.cuda.synchronize()
+                    if epi == 0:
+                        want = ref
+                    elif epi == 1:
+                        want = torch.nn.functional.gelu(ref, approximate="tanh")
+                    elif epi == 2:
+                        gi = torch.arange(M, device=dev) // rps
+                        want = out0[:M] + gate[gi, :N] * ref
+                    else:
+                        want = ref
+                    got = out[:M].float()
+                    err = (got - want).abs().max().item()
+                    rel = ((got - want).norm() / want.norm()).item()
+                    pad_ok = bool((out[M:] == out0[M:]).all()) if M < Mp else True
+                    flag = "" if rel < (6e-3 if epi in (0, 1) else 1e-4) and pad_ok else "  <<<<<< BAD"
+                    log(f"gemm dt={dt} var={variant} M={M} N={N} K={K} epi={epi}: max|d|={err:.3e} rel={rel:.3e} pad_untouched={pad_ok}{flag}")
+
+
+def attention_checks():
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for dt in (0, 1):
+        for (B, F, T, H, hd) in [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64)]:
+            D = H * hd
+            rows = B * F * T
+            qkv = torch.randn(rows, 3 * D, generator=g).to(dev)
+            qh = to_h16(qkv, dt)
+            q5 = qh.float().view(B, F, T, 3, H, hd)
+            for mode in ("spatial", "temporal"):
+                if mode == "spatial":
+                    q, k, v = [q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3)]      # [B,F,H,T,hd]
+                    a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v
+                    want = a.permute(0, 1, 3, 2, 4).reshape(rows, D)
+                    args = (B * F, T, H, hd, F, F * T, T, 1)
+                else:
+                    q, k, v = [q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3)]      # [B,T,H,F,hd]
+                    a = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v
+                    want = a.permute(0, 3, 1, 2, 4).reshape(rows, D)
+                    args = (B * T, F, H, hd, T, F * T, 1, T)
+                out = torch.zeros(rows, D, dtype=TD[dt], device=dev)
+                check(lib.latte_debug_attention(ptr(qh), ptr(out), *args, dt, stream_ptr()))
+                torch.cuda.synchronize()
+                got = out.float()
+                rel = ((got - want).norm() / want.norm()).item()
+                flag = "" if rel < 8e-3 else "  <<<<<< BAD"
+                log(f"attn dt={dt} {mode} B={B} F={F} T={T} H={H} hd={hd}: max|d|={(got - want).abs().max().item():.3e} rel={rel:.3e}{flag}")
+
+
+def ln_checks():
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for dt in (0, 1):
+        for D in (128, 384, 1152):
+            B, F, T = 2, 4, 16
+            M = B * F * T
+            x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(dev)
+            mod = torch.randn(B, 6 * D, generator=g).to(dev)
+            te = torch.randn(F, D, generator=g).to(dev)
+            for use_te in (False, True):
+                xin = x.clone()
+                y = torch.zeros(M, D, dtype=TD[dt], device=dev)
+                check(lib.latte_debug_ln_modulate(ptr(xin), ptr(y), ptr(mod), ptr(mod[:, D:]), 6 * D, M, D, F * T,
+                                                  ptr(te) if use_te else None, T, F, dt, stream_ptr()))
+                torch.cuda.synchronize()
+                xr = x.clone()
+                if use_te:
+                    xr = (xr.view(B, F, T, D) + te.view(1, F, 1, D)).view(M, D)
+                s = torch.arange(M, device=dev) // (F * T)
+                want = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6) * (1 + mod[s, D:2 * D]) + mod[s, :D]
+                rel = ((y.float() - want).norm() / want.norm()).item()
+                xerr = (xin - xr).abs().max().item()
+                log(f"ln dt={dt} D={D} te={use_te}: rel={rel:.3e} x_writeback_err={xerr:.2e}")
+
+
+def normal_check():
+    n = 1 << 22
+    out = torch.empty(n, device=dev)
+    check(lib.latte_debug_fill_normal(ptr(out), n, 123, 0, stream_ptr()))
+    torch.cuda.synchronize()
+    log(f"fill_normal: mean={out.mean().item():.4f} std={out.std().item():.4f} kurt={(out**4).mean().item():.3f} finite={bool(torch.isfinite(out).all())}")
+
+
+def golden_parity():
+    from _util import engine_model, load_golden_model, rel_l2
+    import latte_amd
+    for name in ("tiny_classcond", "tiny_uncond"):
+        kw, sd, r = load_golden_model(name)
+        for cd in ("bf16", "f16"):
+            m = engine_model(kw, sd, cd, max_batch=2)
+            x = torch.from_numpy(r["x"]).to(dev)
+            t = torch.from_numpy(r["t"]).to(dev)
+            y = torch.from_numpy(r["y"]).to(dev) if "y" in r else None
+            out = m(x, t, y=y)
+            log(f"{name} {cd} forward: rel-L2 {rel_l2(out, torch.from_numpy(r['forward'])):.3e}")
+            if "forward_with_cfg" in r:
+                out = m.forward_with_cfg(torch.from_numpy(r["x_cfg"]).to(dev), t, y=torch.from_numpy(r["y_cfg"]).to(dev), cfg_scale=7.0)
+                log(f"{name} {cd} forward_with_cfg: rel-L2 {rel_l2(out, torch.from_numpy(r['forward_with_cfg'])):.3e}")
+            steps = int(r["loop_steps"])
+            d = latte_amd.create_diffusion(str(steps))
+            if "x_cfg" in r:
+                z = torch.from_numpy(r["x_cfg"]).to(dev)
+                fn, mk = m.forward_with_cfg, dict(y=torch.from_numpy(r["y_cfg"]).to(dev), cfg_scale=7.0)
+            else:
+                z = x
+                fn, mk = m.forward, dict(y=y)
+            # feed the reference's noise draws through the C loop directly
+            for method, mi in (("ddim", 1), ("ddpm", 0)):
+                xx = z.clone().contiguous()
+                nz = torch.from_numpy(r[f"{method}_noises"]).to(dev).contiguous()
+                ts = torch.empty((steps,) + tuple(xx.shape), device=dev)
+                t0s = torch.empty_like(ts)
+                eng = m.engine(xx.shape[0])
+                yy = mk.get("y")
+                check(lib.latte_sample_loop(eng, d._h, mi, 0.0, 0, float(mk.get("cfg_scale", 1.0)), ptr(xx), ptr(yy), xx.shape[0],
+                                            steps - 1, 0, ptr(nz), ptr(ts), ptr(t0s), stream_ptr()))
+                torch.cuda.synchronize()
+                ref_s = torch.from_numpy(r[f"{method}_samples"])
+                ref_0 = torch.from_numpy(r[f"{method}_pred_xstart"])
+                per = [f"{rel_l2(ts[k], ref_s[k]):.1e}" for k in range(steps)]
+                log(f"{name} {cd} {method} loop: final rel-L2 {rel_l2(xx, ref_s[-1]):.3e}; per-step sample {per}; x0 last {rel_l2(t0s[-1], ref_0[-1]):.3e}")
+
+
+def oracle_parity():
+    from _util import rel_l2
+    from oracle import latte_oracle as lo
+    from latte_amd.models import Latte_models
+    cases = [("Latte-S/2", dict(input_size=8, num_frames=4, num_classes=101, extras=2), 2),
+             ("Latte-S/2", dict(input_size=32, num_frames=4, extras=1), 1),
+             ("Latte-B/2", dict(input_size=16, num_frames=16, extras=1), 1),
+             ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 1)]
+    for name, kw, B in cases:
+        cfg = lo.preset_config(name, **kw)
+        sd = lo.init_state_dict(cfg, seed=0)
+        g = torch.Generator("cpu").manual_seed(1)
+        x = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
+        t = torch.tensor([999, 12][:B])
+        y = torch.tensor([7, 101][:B]) if kw["extras"] == 2 else None
+        t0 = time.time()
+        with torch.no_grad():
+            ref = lo.latte_forward(sd, cfg, x, t, y)
+        t_or = time.time() - t0
+        for cd in ("bf16", "f16"):
+            m = Latte_models[name](compute_dtype=cd, max_batch=B, **kw)
+            m.load_state_dict(sd)
+            m = m.to(dev)
+            out = m(x.to(dev), t.to(dev), y=None if y is None else y.to(dev))
+            torch.cuda.synchronize()
+            eps_rel = rel_l2(out[:, :, :4], ref[:, :, :4])
+            log(f"{name} {kw} B={B} {cd}: rel-L2 all {rel_l2(out, ref):.3e} eps-only {eps_rel:.3e} (oracle {t_or:.1f}s)")
+            del m
+            torch.cuda.empty_cache()
+
+
+def gemm_bench():
+    ms = _lib.c_f32()
+    for M in (4096, 8192, 32768):
+        for (N, K, epi, nm) in [(3456, 1152, 0, "qkv"), (1152, 1152, 2, "proj"), (4608, 1152, 1, "fc1"), (1152, 4608, 2, "fc2")]:
+            for variant in (1, 2):
+                for dt in (0, 1):
+                    check(lib.latte_bench_gemm(M, N, K, epi, dt, variant, 20, ctypes.byref(ms), stream_ptr()))
+                    tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+                    log(f"gemm_bench M={M} {nm} N={N} K={K} var={variant} dt={dt}: {ms.value*1e3:.1f} us  {tf:.0f} TF/s")
+    # 256x256 tile where N allows
+    for (M, N, K, epi) in [(8192, 4608, 1152, 1), (32768, 4608, 1152, 1), (8192, 4096, 4096, 0)]:
+        for variant in (1, 2, 3):
+            check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
+            tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+            log(f"gemm_bench M={M} N={N} K={K} var={variant} epi={epi}: {ms.value*1e3:.1f} us  {tf:.0f} TF/s")
+
+
+def xl_profile():
+    from oracle import latte_oracle as lo
+    from latte_amd.models import Latte_models
+    import latte_amd
+    kw = dict(input_size=32, num_frames=16, extras=1)
+    for B in (1, 2, 8):
+        m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, **kw)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if float(p_.abs().max()) == 0.0:
+                    p_.normal_(0, 0.02)
+        m = m.to(dev)
+        x = torch.randn(B, 16, 4, 32, 32, device=dev)
+        t = torch.full((B,), 500, device=dev, dtype=torch.int64)
+        for variant in (1, 2):
+            m.set_engine_option("gemm_variant", variant, B)
+            m(x, t)
+            prof = m.profile_forward(x, t)
+            tot = sum(v[0] for v in prof.values())
+            log(f"XL/2 B={B} variant={variant} profile (ms, launches): total {tot:.3f} ms")
+            for k, v in prof.items():
+                log(f"    {k:14s} {v[0]:8.3f} ms  {v[1]:4d}  {100*v[0]/tot:5.1f}%")
+            d = latte_amd.create_diffusion("250")
+            torch.cuda.synchronize()
+            for steps in (10,):
+                xx = x.clone()
+                eng = m.engine(B)
+                check(lib.latte_sample_loop(eng, d._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 249, 249 - 2, None, None, None, stream_ptr()))
+                torch.cuda.synchronize()
+                t0 = time.time()
+                check(lib.latte_sample_loop(eng, d._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 246, 246 - steps + 1, None, None, None, stream_ptr()))
+                torch.cuda.synchronize()
+                dtm = time.time() - t0
+                log(f"XL/2 B={B} variant={variant}: {steps} DDIM steps {dtm*1e3:.1f} ms -> {steps/dtm:.2f} it/s, {B*steps/dtm:.2f} sample-steps/s, "
+                    f"MFMA frac {B*steps/dtm*3.726e12/2.5e15:.3f}; finite={bool(torch.isfinite(xx).all())}")
+        del m
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["env", "tr16_probe", "gemm_checks", "attention_checks", "ln_checks", "normal_check",
+                             "golden_parity", "oracle_parity", "gemm_bench", "xl_profile"]
+    for w in which:
+        section(globals()[w])
