@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[b, n] = bias[n] + sum_k f(in[b, k]) W[n, k]   (one wave per output feature n, fp32 FMA chain)
+// out[b, n] = bias[n] + sum_k f(in[b, k]) W[n, k]   (one wave per output feature n, fp32 FMA chain).
+// The weight row is read ONCE into registers (K <= 1152) and reused for every batch row: the adaLN
+// table is 0.9 GB of fp32 weights per forward, so this kernel is HBM-bound on W alone.
+constexpr int SL_MAXCH = 9;  // float2 chunks per lane: K / 128
 template <int IN_MODE>
 __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restrict__ in, const int64_t* __restrict__ t,
                                                            const float* __restrict__ W, const float* __restrict__ bias,
@@ -96,43 +99,51 @@ __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restri
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const float2* wr = (const float2*)(W + (size_t)n * K);
-  const int k2 = K >> 1;  // K % 128 == 0
+  const int nch = K >> 7;  // K % 128 == 0, nch <= SL_MAXCH (checked by the launcher)
+  float2 w[SL_MAXCH];
+#pragma unroll
+  for (int c = 0; c < SL_MAXCH; ++c) w[c] = c < nch ? wr[c * 64 + lane] : make_float2(0.f, 0.f);
+  const float bn = bias[n];
   for (int b = 0; b < B; ++b) {
     float acc = 0.f;
     if constexpr (IN_MODE == IN_TFREQ) {
       // latte.py:97-117: freqs = exp(-ln(1e4) * arange(half) / half) in fp32; emb = [cos | sin]
       const float tv = (float)t[b];
       const int half = K >> 1;
-      for (int i = lane; i < k2; i += 64) {
-        const float2 w = wr[i];
-        float e[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = 2 * i + u;
-          const int fi = k < half ? k : k - half;
-          const float freq = expf((-9.210340371976184f * (float)fi) / (float)half);
-          const float arg = tv * freq;
-          e[u] = k < half ? cosf(arg) : sinf(arg);
+      for (int c = 0; c < SL_MAXCH; ++c) {
+        if (c < nch) {
+          float e[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int k = 2 * (c * 64 + lane) + u;
+            const int fi = k < half ? k : k - half;
+            const float freq = expf((-9.210340371976184f * (float)fi) / (float)half);
+            const float arg = tv * freq;
+            e[u] = k < half ? cosf(arg) : sinf(arg);
+          }
+          acc = fmaf(e[0], w[c].x, acc);
+          acc = fmaf(e[1], w[c].y, acc);
         }
-        acc = fmaf(e[0], w.x, acc);
-        acc = fmaf(e[1], w.y, acc);
       }
     } else {
       const float2* ir = (const float2*)(in + (size_t)b * K);
-      for (int i = lane; i < k2; i += 64) {
-        const float2 w = wr[i];
-        float2 a = ir[i];
-        if constexpr (IN_MODE == IN_SILU) {
-          a.x = silu(a.x);
-          a.y = silu(a.y);
+#pragma unroll
+      for (int c = 0; c < SL_MAXCH; ++c) {
+        if (c < nch) {
+          float2 a = ir[c * 64 + lane];
+          if constexpr (IN_MODE == IN_SILU) {
+            a.x = silu(a.x);
+            a.y = silu(a.y);
+          }
+          acc = fmaf(a.x, w[c].x, acc);
+          acc = fmaf(a.y, w[c].y, acc);
         }
-        acc = fmaf(a.x, w.x, acc);
-        acc = fmaf(a.y, w.y, acc);
       }
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-      float r = acc + bias[n];
+      float r = acc + bn;
       if (add_table != nullptr) r += add_table[(size_t)add_idx[b] * N + n];
       out[(size_t)b * out_stride + n] = r;
     }
@@ -421,7 +432,7 @@ int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* s
 int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,
                         const float* add_table, const int64_t* add_idx, float* out, int B, int N, int K,
                         int out_stride, hipStream_t st) {
-  if (K % 128 != 0) return fail(LATTE_ERR_INVALID, "small_linear: K % 128 != 0");
+  if (K % 128 != 0 || K > 128 * SL_MAXCH) return fail(LATTE_ERR_INVALID, "small_linear: need K % 128 == 0 and K <= 1152");
   dim3 grid((N + 3) / 4), block(256);
   switch (in_mode) {
     case IN_PLAIN:
