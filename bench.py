@@ -75,7 +75,9 @@ def cpu_baseline(n_forwards):
     sd = lo.init_state_dict(cfg, seed=0)
     x = torch.randn(1, 16, 4, 32, 32)
     t = torch.tensor([500])
-    torch.set_num_threads(os.cpu_count() or 1)
+    # MKL/OpenMP GEMMs stop scaling (and can collapse) far below the 256 hardware threads of the GPU box
+    cores = min(len(os.sched_getaffinity(0)), 32)
+    torch.set_num_threads(cores)
     with torch.no_grad():
         lo.latte_forward(sd, cfg, x, t)                       # warm-up
         t0 = time.time()
@@ -86,6 +88,10 @@ def cpu_baseline(n_forwards):
             "kind": "port",
             "sample": f"{n_forwards} timed fp32 forwards of Latte-XL/2 (B=1, 16x32x32 latents) after 1 warm-up; "
                       "the sampler update is negligible on CPU (<0.1%)"}
+
+
+def note(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -105,7 +111,9 @@ def main():
     import latte_amd
     from latte_amd._lib import load_library
     lib = load_library()
+    note('building model')
     model = build_model(args, device)
+    note('model on device')
     if args.gemm_variant:
         model.set_engine_option("gemm_variant", args.gemm_variant, args.batch)
     diffusion = latte_amd.create_diffusion("250")
@@ -119,6 +127,7 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(lib, model, diffusion, x.clone(), max(args.warmup, 1), args.method, B)
+    note('warm-up done')
     xx = x.clone()
     barrier()
     t0 = time.perf_counter()
@@ -130,6 +139,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(xx).all())
+    note(f'timed region done: {elapsed:.3f}s')
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -163,7 +173,9 @@ def main():
             "forward_ms_eager_events": round(total_ms, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
+            note('cpu baseline (oracle on host cores)')
             res["cpu_baseline"] = cpu_baseline(args.cpu_forwards)
+            note('cpu baseline done')
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

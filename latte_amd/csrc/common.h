@@ -48,9 +48,12 @@ struct GemmArgs {
   int gate_stride;
   int rows_per_sample;
 };
-// variant: 0 = pick for the shape; 1 = 128x128 tile; 2 = 256x128; 3 = 256x256 (N % tileN == 0 required)
+// variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
+// ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256   (N % tileN == 0 required)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
 int gemm_tile_m(int variant);
+int gemm_tile_n(int variant);
+int gemm_auto_variant(int M, int N);
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {

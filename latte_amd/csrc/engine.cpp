@@ -56,7 +56,7 @@ struct latte_engine {
   int D = 0, T = 0, F = 0, G = 0, Cin = 0, Cout = 0, H = 0, P = 0, KPE = 0, Hm = 0, hd = 0;
   int nmod = 0;           // depth*6D + 2D
   int64_t rows_max = 0, rows_pad = 0;
-  int gemm_variant = 1;
+  int gemm_variant = 0;  // 0 = per-shape choice (gemm_auto_variant)
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
         *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr, *ytab = nullptr, *fin_wt = nullptr,
@@ -330,10 +330,11 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 3) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..3");
-    if (value == 3 && ((3 * e->D) % 256 || e->D % 256 || e->Hm % 256))
-      return fail(LATTE_ERR_INVALID, "gemm_variant 3 (256x256 tiles) needs every N to be a multiple of 256");
-    e->gemm_variant = value == 0 ? 1 : (int)value;
+    if (value < 0 || value > 6) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..6");
+    const int bn = gemm_tile_n((int)value);
+    if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
+      return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
+    e->gemm_variant = (int)value;
     return LATTE_OK;
   }
   if (k == "seed") {

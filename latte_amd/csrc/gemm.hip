@@ -50,12 +50,35 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
 // GELU(tanh approximation) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (latte.py:170)
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// One accumulator fragment -> memory.  Lane holds 4 consecutive columns n..n+3 of row m.
+template <int EPI, int DT>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4& a, int m, int n, const float* gate_row) {
+  const float4 b4 = *(const float4*)(g.bias + n);
+  float v0 = a[0] + b4.x, v1 = a[1] + b4.y, v2 = a[2] + b4.z, v3 = a[3] + b4.w;
+  const size_t o = (size_t)m * g.N + n;
+  if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
+    if constexpr (EPI == EPI_BIAS_GELU_H16) {
+      v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+    }
+    u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+    *(u32x2*)((half_t*)g.out + o) = p;
+  } else if constexpr (EPI == EPI_GATE_RES_F32) {
+    const float4 g4 = *(const float4*)(gate_row + n);
+    float4* dst = (float4*)((float*)g.out + o);
+    float4 r = *dst;
+    r.x += g4.x * v0; r.y += g4.y * v1; r.z += g4.z * v2; r.w += g4.w * v3;
+    *dst = r;
+  } else {
+    *(float4*)((float*)g.out + o) = make_float4(v0, v1, v2, v3);
+  }
 }
 
 // XCD-aware bijective remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a
@@ -161,27 +184,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
     const float* gate_row = nullptr;
     if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = ncol + j * 16;
-      const float4 b4 = *(const float4*)(g.bias + n);
-      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-      const size_t o = (size_t)m * g.N + n;
-      if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
-        if constexpr (EPI == EPI_BIAS_GELU_H16) {
-          v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
-        }
-        u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
-        *(u32x2*)((half_t*)g.out + o) = p;
-      } else if constexpr (EPI == EPI_GATE_RES_F32) {
-        const float4 g4 = *(const float4*)(gate_row + n);
-        float4* dst = (float4*)((float*)g.out + o);
-        float4 r = *dst;
-        r.x += g4.x * v0; r.y += g4.y * v1; r.z += g4.z * v2; r.w += g4.w * v3;
-        *dst = r;
-      } else {
-        *(float4*)((float*)g.out + o) = make_float4(v0, v1, v2, v3);
-      }
-    }
+    for (int j = 0; j < FN; ++j) epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, gate_row);
   }
 }
 
@@ -214,23 +217,224 @@ int launch_cfg(const GemmArgs& a, int epi, hipStream_t st) {
   return LATTE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong kernel: 256 x BN tile, 8 waves = 2 groups (output rows 0-127 / 128-255) x 4 waves along
+// N (wave tile 128 x BN/4), BK = 64, two LDS stages.  Per K tile every wave runs two
+// barrier-delimited segments
+//     L(t): 8*2 A + FN*2 B fragment reads (ds_read_b128)          ~550 cycles
+//     C(t): all 16*FN MFMAs of the K tile                          ~16*FN*16 cycles
+// and group 1 executes one extra barrier up front, so it is always one segment behind group 0: each
+// SIMD hosts one wave of each group, and while one is in C the other is in L (guide: 8-phase /
+// ping-pong, T3+T4+T5).  Intervals: 2t = {G0 L(t), G1 C(t-1)}, 2t+1 = {G0 C(t), G1 L(t)}.
+//
+// DMA (global_load_lds) placement: group 0's waves load the B tile and A rows 0-127 of K tile t+1 at
+// the end of L(t) [interval 2t] -- what group 0 itself reads first, in interval 2t+2; group 1's waves
+// load only A rows 128-255 (read by group 1 alone, in 2t+3) at the end of their L(t) [2t+1].  Every
+// wave drains its own DMA (vmcnt(0)) at the end of its C(t), i.e. one barrier before the first reader.
+// WAR: readers retire their ds_reads (lgkmcnt(0)) before the barrier ending their L segment; the DMA
+// that overwrites that stage is issued after it.
+// Measured alternatives (DESIGN.md "GEMM experiments"): four segments per K tile (all DMA in one
+// 16-read segment) -15 %; moving half of the B DMA into group 1's compute segment with counted vmcnt
+// (prefetch distance 2) -5 %; ablations on 8192x4096x4096: no DMA 208 us, no ds_read 241 us, neither
+// 200 us vs 244-251 us for the full kernel -> the schedule runs at ~80 % of its load-free ceiling.
+template <int BN, int EPI, int DT>
+__global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
+  constexpr int BM = 256, NW = 8;
+  constexpr int WTN = BN / 4, FN = WTN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;   // prologue: all 8 waves cooperate
+  constexpr int AH_INSTR = 128 / 8 / 4;                          // a group's 4 waves load its 128 A rows: 4 each
+  constexpr int BG_INSTR = BN / 8 / 4;                           // B row-groups per wave of ONE group: 4 / 6 / 8
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+
+  int tm, tn;
+  tile_coords((g.M + BM - 1) / BM, g.N / BN, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K = g.K;
+
+  // DMA addressing: ONE 32-bit per-lane byte offset (row-in-group, swizzled chunk); tile base, row-group
+  // stride and K offset stay in scalar registers (SGPR base + VGPR offset form: no 64-bit pointer VGPRs).
+  const int lrow = lane >> 3, cpos = lane & 7;
+  // lane part is identical for the 8-wave prologue mapping (row-group = wave + 8 j) and the 4-wave
+  // main-loop mapping (row-group = wn + 4 j): the swizzle only sees ((row >> 1) & 7) and both
+  // 8*wave and 8*wn contribute (wave or wn)*4 -> add that parity term per mapping below.
+  const unsigned lane_row_off = (unsigned)lrow * (unsigned)K * 2u;
+  auto lane_off = [&](int group_row0) -> unsigned {   // group_row0 = first row of the wave's row-group (multiple of 8)
+    const int row = group_row0 + lrow;
+    return lane_row_off + (unsigned)((cpos ^ ((row >> 1) & 7)) * 16);
+  };
+  const unsigned off_pro = lane_off(wave * 8);          // prologue: rows wave*8 + 64 j  (64 j does not move the swizzle)
+  const unsigned off_main = lane_off(wn * 8);           // main loop: rows wn*8 + 32 j
+  const char* a_tile = (const char*)(g.A + (size_t)m0 * K);
+  const char* b_tile = (const char*)(g.W + (size_t)n0 * K);
+  const size_t row_bytes = (size_t)K * 2;
+
+  auto dma_a_half = [&](int kt) {   // own 128 A rows of K tile kt: row-groups wn + 4 j
+    char* sA = smem + (kt & 1) * STAGE + grp * 128 * 128 + wn * 1024;
+    const char* src = a_tile + ((size_t)(grp * 128 + wn * 8)) * row_bytes + (size_t)kt * 128;
+#pragma unroll
+    for (int j = 0; j < AH_INSTR; ++j)
+      glds16((const half_t*)(src + (size_t)(32 * j) * row_bytes + off_main), sA + j * 4 * 1024);
+  };
+  auto dma_b_all = [&](int kt) {   // whole B tile by ONE group's 4 waves: row-groups wn + 4 j
+    char* sB = smem + (kt & 1) * STAGE + A_BYTES + wn * 1024;
+    const char* src = b_tile + ((size_t)(wn * 8)) * row_bytes + (size_t)kt * 128;
+#pragma unroll
+    for (int j = 0; j < BG_INSTR; ++j) glds16((const half_t*)(src + (size_t)(32 * j) * row_bytes + off_main), sB + j * 4 * 1024);
+  };
+
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int chunk0 = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + frow) * 128 + chunk0;
+  const int b_off = A_BYTES + (wn * WTN + frow) * 128 + chunk0;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  {  // prologue: K tile 0 by all waves; G1 also places its share of B(1) (its "C(-1)" slot)
+    char* sA = smem + wave * 1024;
+    char* sB = sA + A_BYTES;
+    const char* srcA = a_tile + (size_t)(wave * 8) * row_bytes;
+    const char* srcB = b_tile + (size_t)(wave * 8) * row_bytes;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) glds16((const half_t*)(srcA + (size_t)(64 * j) * row_bytes + off_pro), sA + j * NW * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) glds16((const half_t*)(srcB + (size_t)(64 * j) * row_bytes + off_pro), sB + j * NW * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sbuf = smem + (kt & 1) * STAGE;
+    u32x4 bf[2][FN], af[2][8];
+    // ---- L(kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+    }
+    if (kt + 1 < nk) {
+      dma_a_half(kt + 1);
+      if (grp == 0) dma_b_all(kt + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage kt fully consumed by this wave
+    __builtin_amdgcn_s_barrier();
+    // ---- C(kt)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA of K tile kt+1 landed
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+
+  const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + grp * 128 + i * 16 + frow;
+    if (m >= g.M) continue;
+    const float* gate_row = nullptr;
+    if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, gate_row);
+  }
+}
+
+template <int BN, int DT>
+int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
+  constexpr int LDS = 2 * (256 + BN) * 128;
+  const int tiles = ((a.M + 255) / 256) * (a.N / BN);
+  dim3 grid(tiles), block(512);
+#define LATTE_GEMM_CASE(E)                                                                           \
+  case E: {                                                                                          \
+    auto kern = gemm_pp_kernel<BN, E, DT>;                                                           \
+    static bool attr_done = false;                                                                   \
+    if (!attr_done) {                                                                                \
+      LATTE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+      attr_done = true;                                                                              \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+    break;                                                                                           \
+  }
+  switch (epi) {
+    LATTE_GEMM_CASE(EPI_BIAS_H16)
+    LATTE_GEMM_CASE(EPI_BIAS_GELU_H16)
+    LATTE_GEMM_CASE(EPI_GATE_RES_F32)
+    LATTE_GEMM_CASE(EPI_BIAS_F32)
+    default:
+      return fail(LATTE_ERR_INVALID, "gemm: unknown epilogue");
+  }
+#undef LATTE_GEMM_CASE
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 template <int DT>
 int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
-  if (variant == 0) variant = 1;
   switch (variant) {
     case 1: return launch_cfg<128, 128, 2, 2, DT>(a, epi, st);
     case 2: return launch_cfg<256, 128, 4, 2, DT>(a, epi, st);
     case 3: return launch_cfg<256, 256, 2, 4, DT>(a, epi, st);
+    case 4: return launch_pp<128, DT>(a, epi, st);
+    case 5: return launch_pp<192, DT>(a, epi, st);
+    case 6: return launch_pp<256, DT>(a, epi, st);
     default: return fail(LATTE_ERR_INVALID, "gemm: unknown tile variant");
   }
 }
 
 }  // namespace
 
-int gemm_tile_m(int variant) { return (variant == 2 || variant == 3) ? 256 : 128; }
+int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
+
+int gemm_tile_n(int variant) {
+  switch (variant) {
+    case 3: case 6: return 256;
+    case 5: return 192;
+    default: return 128;
+  }
+}
+
+// variant 0: pick the tile by a wave-quantisation model.  score = (tiles / (rounds * slots)) * rate where
+// slots = resident workgroups on 256 CUs (ping-pong: 1 per CU; 128x128: 2 per CU) and rate is the kernel's
+// relative throughput at full occupancy (microbenchmarks).
+int gemm_auto_variant(int M, int N) {
+  struct Cand { int variant, bm, bn, slots; float rate; };
+  static const Cand cands[] = {{6, 256, 256, 256, 1.00f}, {5, 256, 192, 256, 0.97f}, {4, 256, 128, 256, 0.82f},
+                               {1, 128, 128, 512, 0.86f}};
+  int best = 1;
+  float best_score = -1.f;
+  for (const Cand& c : cands) {
+    if (N % c.bn) continue;
+    const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+    const long rounds = (tiles + c.slots - 1) / c.slots;
+    const float score = (float)tiles / (float)(rounds * c.slots) * c.rate;
+    if (score > best_score) { best_score = score; best = c.variant; }
+  }
+  return best;
+}
 
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st) {
-  const int bn = (variant == 3) ? 256 : 128;
+  if (variant == 0) variant = gemm_auto_variant(a.M, a.N);
+  const int bn = gemm_tile_n(variant);
   if (a.K % 64 != 0 || a.N % bn != 0 || a.M <= 0)
     return fail(LATTE_ERR_INVALID, "gemm: shape not tileable (need K % 64 == 0, N % tileN == 0)");
   if (dtype == LATTE_DTYPE_BF16) return launch_dt<LATTE_DTYPE_BF16>(a, epi, variant, st);

@@ -17,12 +17,13 @@ def dev():
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("variant", [1, 2, 3])
-@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608), (700, 384, 64)])
 def test_gemm_epilogues(lib, dev, dt, variant, shape):
     M, N, K = shape
-    if variant == 3 and N % 256:
-        pytest.skip("256x256 tile needs N % 256 == 0")
+    tile_n = {0: 64, 1: 128, 2: 128, 3: 256, 4: 128, 5: 192, 6: 256}[variant]
+    if N % tile_n:
+        pytest.skip(f"tile width {tile_n} does not divide N")
     g = torch.Generator("cpu").manual_seed(M + N + K)
     Mp = (M + 255) // 256 * 256
     A = torch.randn(Mp, K, generator=g).to(dev).to(TD[dt])

@@ -254,17 +254,21 @@ def gemm_bench():
     ms = _lib.c_f32()
     for M in (4096, 8192, 32768):
         for (N, K, epi, nm) in [(3456, 1152, 0, "qkv"), (1152, 1152, 2, "proj"), (4608, 1152, 1, "fc1"), (1152, 4608, 2, "fc2")]:
-            for variant in (1, 2):
-                for dt in (0, 1):
-                    check(lib.latte_bench_gemm(M, N, K, epi, dt, variant, 20, ctypes.byref(ms), stream_ptr()))
-                    tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
-                    log(f"gemm_bench M={M} {nm} N={N} K={K} var={variant} dt={dt}: {ms.value*1e3:.1f} us  {tf:.0f} TF/s")
-    # 256x256 tile where N allows
-    for (M, N, K, epi) in [(8192, 4608, 1152, 1), (32768, 4608, 1152, 1), (8192, 4096, 4096, 0)]:
-        for variant in (1, 2, 3):
-            check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
+            row = []
+            for variant in (1, 4, 5, 6):
+                if N % {1: 128, 4: 128, 5: 192, 6: 256}[variant]:
+                    continue
+                check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
+                tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+                row.append(f"v{variant}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
+            log(f"gemm_bench M={M:5d} {nm:4s} N={N} K={K}: " + " | ".join(row))
+    for (M, N, K, epi) in [(8192, 4096, 4096, 0), (4096, 4096, 4096, 0), (8192, 8192, 8192, 0)]:
+        row = []
+        for variant in (1, 6):
+            check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 10, ctypes.byref(ms), stream_ptr()))
             tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
-            log(f"gemm_bench M={M} N={N} K={K} var={variant} epi={epi}: {ms.value*1e3:.1f} us  {tf:.0f} TF/s")
+            row.append(f"v{variant}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
+        log(f"gemm_bench M={M} N={N} K={K}: " + " | ".join(row))
 
 
 def xl_profile():
@@ -272,7 +276,7 @@ def xl_profile():
     from latte_amd.models import Latte_models
     import latte_amd
     kw = dict(input_size=32, num_frames=16, extras=1)
-    for B in (1, 2, 8):
+    for B in (2, 8):
         m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, **kw)
         with torch.no_grad():
             for n_, p_ in m.named_parameters():
@@ -281,7 +285,7 @@ def xl_profile():
         m = m.to(dev)
         x = torch.randn(B, 16, 4, 32, 32, device=dev)
         t = torch.full((B,), 500, device=dev, dtype=torch.int64)
-        for variant in (1, 2):
+        for variant in (1, 0):
             m.set_engine_option("gemm_variant", variant, B)
             m(x, t)
             prof = m.profile_forward(x, t)
