@@ -37,6 +37,7 @@ enum GemmEpi : int {
   EPI_BIAS_GELU_H16 = 1,  // out(half) = gelu_tanh(acc + bias)
   EPI_GATE_RES_F32 = 2,   // res(fp32)[m,n] += gate[sample(m)][n] * (acc + bias)
   EPI_BIAS_F32 = 3,       // out(fp32) = acc + bias
+  EPI_ABLATE_NOSTORE = 4, // measurement only: bias add, nothing written (persistent kernel only)
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -49,7 +50,8 @@ struct GemmArgs {
   int rows_per_sample;
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
-// ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256   (N % tileN == 0 required)
+// ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
+// 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);

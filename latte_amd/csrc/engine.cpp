@@ -330,8 +330,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 6) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..6");
-    const int bn = gemm_tile_n((int)value);
+    if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..9");
+    const int bn = value >= 7 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
     e->gemm_variant = (int)value;

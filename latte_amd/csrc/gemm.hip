@@ -64,7 +64,9 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4& a
   const float4 b4 = *(const float4*)(g.bias + n);
   float v0 = a[0] + b4.x, v1 = a[1] + b4.y, v2 = a[2] + b4.z, v3 = a[3] + b4.w;
   const size_t o = (size_t)m * g.N + n;
-  if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
+  if constexpr (EPI == EPI_ABLATE_NOSTORE) {
+    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+  } else if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
     if constexpr (EPI == EPI_BIAS_GELU_H16) {
       v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
     }
@@ -359,6 +361,303 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent ping-pong kernel: the same 256 x BN segment schedule as gemm_pp_kernel, but ONE workgroup
+// per CU walks a sequence of output tiles and the K loop is continued across tile boundaries:
+//   * the DMA of the next tile's K tile 0 is issued in the last L segment of the current tile, so only
+//     the first tile of a workgroup pays the HBM/L2 latency of an empty pipeline;
+//   * the epilogue's stores are asynchronous and drain under the next tile's main loop instead of all
+//     256 CUs bursting to HBM at the end of a lock-step round;
+//   * at a tile boundary group 1 (one segment behind) runs its epilogue BEFORE the barrier that ends its
+//     last compute segment and group 0 AFTER it, so the two epilogues overlap each other and the matrix
+//     pipe idles for about one epilogue, not two.
+// Register budget (2 waves / SIMD -> 256 VGPRs): 128 accumulators + 96 fragment registers leave ~30 for
+// everything else, so the DMA uses buffer_load ... lds (ONE 32-bit per-lane offset; tile / row-group /
+// K offsets are scalar soffsets against a descriptor of the whole matrix) and the epilogue re-derives
+// its lane-dependent indices from an opaque copy of the lane id (nothing of it stays live in the K loop).
+// Tile sequence of a workgroup: XCD x (= blockIdx & 7) owns a contiguous chunk of the grouped tile
+// order (tile_coords' order); slot s (= blockIdx >> 3) takes positions s, s + G/8, ... of that chunk, so
+// the 32 workgroups of one XCD work on a compact patch of tiles at any time (shared A / W panels in L2).
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int BN, int EPI, int DT>
+__global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
+  constexpr int BM = 256, NW = 8;
+  constexpr int WTN = BN / 4, FN = WTN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  constexpr int AH_INSTR = 128 / 8 / 4;
+  constexpr int BG_INSTR = BN / 8 / 4;
+  constexpr int GROUP_M = 8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int K = g.K;
+  const unsigned row_bytes = (unsigned)K * 2u;
+
+  // ---- this workgroup's tile sequence
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, nwg = tiles_m * tiles_n;   // N % WTN == 0 (launcher)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+
+  // descriptors of the whole (row-padded) activation matrix and of the weight matrix (< 4 GiB: launcher)
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)tiles_m * BM * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)g.N * row_bytes, 0x00020000);
+
+  // per-lane DMA offset: row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7) ^ swizzle(row)
+  const int lrow = lane >> 3, cpos = lane & 7;
+  auto lane_off = [&](int group_row0) -> unsigned {
+    const int row = group_row0 + lrow;
+    return (unsigned)lrow * row_bytes + (unsigned)((cpos ^ ((row >> 1) & 7)) * 16);
+  };
+  const unsigned off_main = lane_off(wn * 8);   // rows wn*8 + 32 j (32 j does not move the swizzle)
+
+  // own 128 A rows of K tile kt of tile-row tm_: row-groups wn + 4 j
+  auto dma_a_half = [&](int tm_, int kt, int stg) {
+    char* sA = smem + stg * STAGE + grp * 128 * 128 + wn * 1024;
+    const unsigned so = (unsigned)(tm_ * BM + grp * 128 + wn * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+    for (int j = 0; j < AH_INSTR; ++j) bload_lds16(rsA, sA + j * 4 * 1024, off_main, so + (unsigned)(32 * j) * row_bytes);
+  };
+  // whole B tile by ONE group's 4 waves
+  auto dma_b_all = [&](int tn_, int kt, int stg) {
+    char* sB = smem + stg * STAGE + A_BYTES + wn * 1024;
+    const unsigned so = (unsigned)(tn_ * BN + wn * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+    for (int j = 0; j < BG_INSTR; ++j) bload_lds16(rsB, sB + j * 4 * 1024, off_main, so + (unsigned)(32 * j) * row_bytes);
+  };
+
+  const int sw = (lane >> 1) & 7;
+  const int chunkb = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + (lane & 15)) * 128 + chunkb;
+  const int b_off = A_BYTES + (wn * WTN + (lane & 15)) * 128 + chunkb;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int pos = slot, tm, tn;
+  decode(chunk0 + pos, tm, tn);
+  const int nk = K / 64;   // >= 2 (launcher)
+  {  // pipeline fill: K tile 0 of the first tile by all 8 waves (row-groups wave + 8 j)
+    const unsigned off_pro = lane_off(wave * 8);
+    char* sA = smem + wave * 1024;
+    char* sB = sA + A_BYTES;
+    const unsigned soA = (unsigned)(tm * BM + wave * 8) * row_bytes;
+    const unsigned soB = (unsigned)(tn * BN + wave * 8) * row_bytes;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) bload_lds16(rsA, sA + j * NW * 1024, off_pro, soA + (unsigned)(64 * j) * row_bytes);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) bload_lds16(rsB, sB + j * NW * 1024, off_pro, soB + (unsigned)(64 * j) * row_bytes);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // K tile 1 (stage 1 is untouched so far): each group its own A rows, group 0 the B tile
+  dma_a_half(tm, 1, 1);
+  if (grp == 0) dma_b_all(tn, 1, 1);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
+
+  // Epilogue of tile (tm_, tn_) for this wave's 128 x WTN sub-tile, then clear the accumulators.
+  // Half-precision outputs of the 256-wide tile go through a wave-private 4 KB LDS patch (the 32 KB the two
+  // stages leave free) so that every global store instruction writes 8 complete 128-byte rows instead of
+  // 16 rows x 32 bytes: the direct form is store-ISSUE bound (measured: 25-30 % of the fc1 / qkv launch).
+  constexpr bool LDS_EPI = (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) && BN == 256;
+  constexpr int NST = LDS_EPI ? 16 : 8 * FN;   // store instructions one wave issues per (full) tile
+  auto epilogue = [&](int tm_, int tn_) {
+    int le = lane;
+    asm volatile("" : "+v"(le));   // opaque: keeps every lane-derived epilogue index out of the K loop's live set
+    const int fr = le & 15;
+    const int ncol0 = tn_ * BN + wn * WTN;          // first column of this wave's sub-tile
+    if (ncol0 >= g.N) {                             // N edge: this wave's columns do not exist (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+    if constexpr (LDS_EPI) {
+      // patch image: [32 rows][128 B]; 16-byte piece p of row r lives at piece p ^ ((r >> 1) & 7)
+      char* patch = smem + 2 * STAGE + wave * 4096;
+      const int gq = le >> 4;
+      float4 b4[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);
+      const int mrow0 = tm_ * BM + grp * 128;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * c + ii;
+          const int row = ii * 16 + fr;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+            if constexpr (EPI == EPI_BIAS_GELU_H16) {
+              v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+            }
+            const u32x2 pk = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+            const int piece = j * 2 + (gq >> 1);
+            *(u32x2*)(patch + row * 128 + ((piece ^ ((row >> 1) & 7)) << 4) + ((gq & 1) << 3)) = pk;
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+          const int row = kq * 8 + (le >> 3), piece = le & 7;
+          const u32x4 v = *(const u32x4*)(patch + row * 128 + ((piece ^ ((row >> 1) & 7)) << 4));
+          const int m = mrow0 + c * 32 + row;
+          if (m < g.M) *(u32x4*)((half_t*)g.out + (size_t)m * g.N + ncol0 + piece * 8) = v;
+        }
+      }
+    } else {
+      const int ncol = ncol0 + (le >> 4) * 4;
+      const int mbase = tm_ * BM + grp * 128 + fr;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = mbase + i * 16;
+        if (m < g.M) {
+          const float* gate_row = nullptr;
+          if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, gate_row);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  // Schedule per K tile u (global counter `it`), stage(u) = u & 1:
+  //   L(u)  : fragment reads of stage(u), lgkmcnt(0), barrier
+  //   C(u)  : MFMAs; wait for DMA(u+1)
+  //   then  : issue DMA(u+2) into stage(u) -- group 1 BEFORE the barrier ending its C(u) (it only writes its
+  //           own A rows, which nobody else reads), group 0 AFTER the barrier ending its C(u) (by then group 1
+  //           has finished L(u), the last reader of stage(u)); at a tile boundary the epilogue follows.
+  // vmcnt retires in issue order and counts stores, so the DMA is issued BEFORE the epilogue's stores and
+  // the wait at the end of the next C segment is vmcnt(NST): everything older than the youngest NST
+  // operations -- i.e. the DMA -- has landed, while the stores keep draining under the next tile's loop.
+  // (A tile with rows >= M issues fewer stores: that boundary waits vmcnt(0).)
+  int it = 0;
+  bool counted = false;   // the DMA waited for in this iteration was followed by exactly NST stores
+  for (;;) {
+    const int npos = pos + per;
+    const bool has_next = npos < cnt;
+    int ntm = tm, ntn = tn;
+    if (has_next) decode(chunk0 + npos, ntm, ntn);
+    const bool full_rows = (tm + 1) * BM <= g.M;
+
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      const char* sbuf = smem + (it & 1) * STAGE;
+      u32x4 bf[2][FN], af[2][8];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      if (counted) {
+        if constexpr (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if constexpr (NST == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      counted = false;
+      // K tile u+2: same tile, or the next tile's K tile kt + 2 - nk
+      const bool last = kt + 1 == nk;
+      const bool in_tile = kt + 2 < nk;
+      const bool do_dma = in_tile || has_next;
+      const int stm = in_tile ? tm : ntm, stn = in_tile ? tn : ntn, skt = in_tile ? kt + 2 : kt + 2 - nk;
+      if (grp == 1) {
+        if (do_dma) dma_a_half(stm, skt, it & 1);
+        if (last) epilogue(tm, tn);
+      }
+      __builtin_amdgcn_s_barrier();
+      if (grp == 0) {
+        if (do_dma) {
+          dma_a_half(stm, skt, it & 1);
+          dma_b_all(stn, skt, it & 1);
+        }
+        if (last) epilogue(tm, tn);
+      }
+      if (last) counted = do_dma && full_rows && (tn * BN + wn * WTN < g.N);
+    }
+    if (!has_next) break;
+    pos = npos; tm = ntm; tn = ntn;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+}
+
+template <int BN, int DT>
+int launch_pp(const GemmArgs& a, int epi, hipStream_t st);
+
+template <int BN, int DT>
+int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
+  constexpr int LDS = 2 * (256 + BN) * 128 + (BN == 256 ? 8 * 4096 : 0);   // + wave-private epilogue patches
+  const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
+  if ((uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 >= (1ull << 32) || (uint64_t)a.N * a.K * 2 >= (1ull << 32) || a.K < 128)
+  {  // 32-bit buffer offsets would overflow / a single K tile: non-persistent kernel (whole tile columns only)
+    if (a.N % BN) return fail(LATTE_ERR_INVALID, "gemm: shape needs the persistent kernel but exceeds its 4 GiB / K >= 128 limits");
+    return launch_pp<BN, DT>(a, epi, st);
+  }
+  const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;   // one workgroup per CU, multiple of the 8 XCDs
+  dim3 grid(nblk), block(512);
+#define LATTE_GEMM_CASE(E)                                                                           \
+  case E: {                                                                                          \
+    auto kern = gemm_pps_kernel<BN, E, DT>;                                                          \
+    static bool attr_done = false;                                                                   \
+    if (!attr_done) {                                                                                \
+      LATTE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+      attr_done = true;                                                                              \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+    break;                                                                                           \
+  }
+  switch (epi) {
+    LATTE_GEMM_CASE(EPI_BIAS_H16)
+    LATTE_GEMM_CASE(EPI_BIAS_GELU_H16)
+    LATTE_GEMM_CASE(EPI_GATE_RES_F32)
+    LATTE_GEMM_CASE(EPI_BIAS_F32)
+    LATTE_GEMM_CASE(EPI_ABLATE_NOSTORE)
+    default:
+      return fail(LATTE_ERR_INVALID, "gemm: unknown epilogue");
+  }
+#undef LATTE_GEMM_CASE
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 template <int BN, int DT>
 int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
   constexpr int LDS = 2 * (256 + BN) * 128;
@@ -397,6 +696,9 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
     case 4: return launch_pp<128, DT>(a, epi, st);
     case 5: return launch_pp<192, DT>(a, epi, st);
     case 6: return launch_pp<256, DT>(a, epi, st);
+    case 7: return launch_pps<128, DT>(a, epi, st);
+    case 8: return launch_pps<192, DT>(a, epi, st);
+    case 9: return launch_pps<256, DT>(a, epi, st);
     default: return fail(LATTE_ERR_INVALID, "gemm: unknown tile variant");
   }
 }
@@ -407,8 +709,8 @@ int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
 
 int gemm_tile_n(int variant) {
   switch (variant) {
-    case 3: case 6: return 256;
-    case 5: return 192;
+    case 3: case 6: case 9: return 256;
+    case 5: case 8: return 192;
     default: return 128;
   }
 }
@@ -418,15 +720,18 @@ int gemm_tile_n(int variant) {
 // relative throughput at full occupancy (microbenchmarks).
 int gemm_auto_variant(int M, int N) {
   struct Cand { int variant, bm, bn, slots; float rate; };
-  static const Cand cands[] = {{6, 256, 256, 256, 1.00f}, {5, 256, 192, 256, 0.97f}, {4, 256, 128, 256, 0.82f},
-                               {1, 128, 128, 512, 0.86f}};
+  static const Cand cands[] = {{9, 256, 256, 256, 1.00f}, {8, 256, 192, 256, 0.97f}, {7, 256, 128, 256, 0.82f},
+                               {1, 128, 128, 512, 0.80f}};
   int best = 1;
   float best_score = -1.f;
   for (const Cand& c : cands) {
-    if (N % c.bn) continue;
-    const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+    // the persistent kernels take a partial last tile column as long as every wave's WTN = bn / 4 columns
+    // are all inside or all outside N
+    if (c.variant >= 7 ? (N % (c.bn / 4)) != 0 : (N % c.bn) != 0) continue;
+    const long tiles_n = (N + c.bn - 1) / c.bn;
+    const long tiles = (long)((M + c.bm - 1) / c.bm) * tiles_n;
     const long rounds = (tiles + c.slots - 1) / c.slots;
-    const float score = (float)tiles / (float)(rounds * c.slots) * c.rate;
+    const float score = (float)tiles / (float)(rounds * c.slots) * c.rate * ((float)N / (float)(tiles_n * c.bn));
     if (score > best_score) { best_score = score; best = c.variant; }
   }
   return best;
@@ -435,7 +740,8 @@ int gemm_auto_variant(int M, int N) {
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st) {
   if (variant == 0) variant = gemm_auto_variant(a.M, a.N);
   const int bn = gemm_tile_n(variant);
-  if (a.K % 64 != 0 || a.N % bn != 0 || a.M <= 0)
+  const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
+  if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)
     return fail(LATTE_ERR_INVALID, "gemm: shape not tileable (need K % 64 == 0, N % tileN == 0)");
   if (dtype == LATTE_DTYPE_BF16) return launch_dt<LATTE_DTYPE_BF16>(a, epi, variant, st);
   if (dtype == LATTE_DTYPE_F16) return launch_dt<LATTE_DTYPE_F16>(a, epi, variant, st);

@@ -255,8 +255,8 @@ def gemm_bench():
     for M in (4096, 8192, 32768):
         for (N, K, epi, nm) in [(3456, 1152, 0, "qkv"), (1152, 1152, 2, "proj"), (4608, 1152, 1, "fc1"), (1152, 4608, 2, "fc2")]:
             row = []
-            for variant in (1, 4, 5, 6):
-                if N % {1: 128, 4: 128, 5: 192, 6: 256}[variant]:
+            for variant in (1, 5, 6, 7, 8, 9):
+                if N % {1: 128, 5: 192, 6: 256, 7: 128, 8: 192, 9: 256}[variant]:
                     continue
                 check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
                 tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
@@ -264,11 +264,25 @@ def gemm_bench():
             log(f"gemm_bench M={M:5d} {nm:4s} N={N} K={K}: " + " | ".join(row))
     for (M, N, K, epi) in [(8192, 4096, 4096, 0), (4096, 4096, 4096, 0), (8192, 8192, 8192, 0)]:
         row = []
-        for variant in (1, 6):
+        for variant in (6, 9):
             check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 10, ctypes.byref(ms), stream_ptr()))
             tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
             row.append(f"v{variant}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
         log(f"gemm_bench M={M} N={N} K={K}: " + " | ".join(row))
+
+
+
+def gemm_epi_ablation():
+    """Same shape, different epilogues on the persistent kernel: 0 bf16 out, 1 GELU bf16, 2 gated fp32 RMW, 3 fp32 out, 4 no store."""
+    ms = _lib.c_f32()
+    for (M, N, K, variant) in [(32768, 4608, 1152, 9), (32768, 4608, 1152, 8), (32768, 3456, 1152, 8), (32768, 1152, 4608, 8),
+                               (32768, 1152, 1152, 8)]:
+        row = []
+        for epi in (0, 1, 2, 3, 4):
+            check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
+            tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+            row.append(f"epi{epi}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
+        log(f"epi_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
 
 
 def xl_profile():
@@ -285,7 +299,7 @@ def xl_profile():
         m = m.to(dev)
         x = torch.randn(B, 16, 4, 32, 32, device=dev)
         t = torch.full((B,), 500, device=dev, dtype=torch.int64)
-        for variant in (1, 0):
+        for variant in (0,):
             m.set_engine_option("gemm_variant", variant, B)
             m(x, t)
             prof = m.profile_forward(x, t)
