@@ -130,6 +130,28 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
                       int start_index, int end_index, const float* noise,
                       float* trail_sample, float* trail_x0, void* stream);
 
+/* ------------------------------------------------------------------ VAE decoder
+ * Replaces diffusers.AutoencoderKL (sample/sample.py:69 from_pretrained, :113-115 vae.decode(z / 0.18215).sample;
+ * sample_ddp.py:90,165-168) for the stabilityai/sd-vae-ft-* architecture: latent_channels 4,
+ * block_out_channels (128, 256, 512, 512), layers_per_block 2, norm_num_groups 32, SiLU.  diffusers is not vendored
+ * in the reference: the restated algorithm and its parity status are in oracle/vae_oracle.py. */
+typedef struct latte_vae latte_vae_t;
+/* latent_size: H = W of the latent (multiple of 16); max_frames: largest N of one decode call */
+int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out);
+void latte_vae_destroy(latte_vae_t* v);
+/* load_state_dict for ONE tensor named by its diffusers key ("decoder.up_blocks.2.resnets.0.conv1.weight",
+ * "post_quant_conv.bias", ...); fp32, reference shape; encoder.* / quant_conv.* keys are not accepted. */
+int latte_vae_num_keys(const latte_vae_t* v);
+const char* latte_vae_key(const latte_vae_t* v, int i);
+int latte_vae_load_tensor(latte_vae_t* v, const char* key, const float* data, int64_t numel, int on_device,
+                          void* stream);
+int latte_vae_check_weights(latte_vae_t* v);
+/* vae.decode(z * z_scale).sample: z [N,4,h,w] fp32 (device, the layout sample.py:112 produces), z_scale = 1/0.18215
+ * folds the caller's division.  out_mode 0: fp32 [N,3,8h,8w] (the reference's `.sample`); out_mode 1: uint8
+ * [N,8h,8w,3] = ((x*0.5+0.5)*255+0.5).clamp(0,255) of sample.py:122 fused into the last convolution. */
+int latte_vae_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out,
+                     void* stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * Runs ONE denoiser forward eagerly with HIP events around every kernel launch on `stream`,
  * synchronises, and reports per-kernel-class totals.  classes (fixed order):

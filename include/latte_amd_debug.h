@@ -30,6 +30,21 @@ int latte_debug_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offse
  * lds[i] = i as 16-bit values): out[l*4 + j].  Documents the transpose-read lane map on this chip. */
 int latte_debug_tr16_probe(uint16_t* out, void* stream);
 
+/* 3x3 convolution, padding 1, NHWC half: out[N,H<<ups,W<<ups,Cout] = conv(nearest_upsample^ups(in[N,H,W,Cin]), w) + bias
+ * (+ res).  w is the PyTorch weight [Cout,Cin,3,3] in fp32 (packed internally).  (F.conv2d / Upsample2D) */
+int latte_debug_conv3x3(const void* in, const float* w, const float* bias, const void* res, void* out, int N, int H, int W,
+                        int Cin, int Cout, int ups, int dtype, void* stream);
+/* GroupNorm(32 groups, eps 1e-6, affine) [+ SiLU] on NHWC half [N, HW, C]. */
+int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
+                          int dtype, void* stream);
+
+/* Runs the VAE decoder (include/latte_amd.h) up to and including stage `stop_after` and returns that stage's NHWC
+ * activation widened to fp32 (trace_dims = N, H, W, C).  Stages: 0 conv_in, 1 mid.resnets.0, 2 mid.attentions.0,
+ * 3 mid.resnets.1, then for up block i: three resnets and (i < 3) the upsampler -> 4..18.  Localises a divergence. */
+struct latte_vae;
+int latte_debug_vae_trace(struct latte_vae* v, const float* z, int n_frames, float z_scale, int stop_after, float* trace_out,
+                          int64_t* trace_numel, int* trace_dims, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

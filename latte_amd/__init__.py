@@ -2,7 +2,7 @@
 
 Public surface = the reference entry points for the sampling hot path:
 ``Latte_models`` / ``get_models`` / ``find_model`` (models/latte.py, models/__init__.py, utils.py),
-``create_diffusion`` (diffusion/__init__.py), ``LattePipeline`` (sample/pipeline_latte.py, name kept;
+``create_diffusion`` (diffusion/__init__.py), ``AutoencoderKL`` (diffusers, decode only), ``LattePipeline`` (sample/pipeline_latte.py, name kept;
 the T2V family is a later row), ``load_config`` (OmegaConf.load stand-in for the YAMLs).
 """
 from ._lib import LatteError, load_library  # noqa: F401
@@ -10,5 +10,6 @@ from .config import Config, load_config  # noqa: F401
 from .diffusion import SpacedDiffusion, create_diffusion  # noqa: F401
 from .models import Latte, Latte_models, find_model, get_models  # noqa: F401
 from .pipeline import LattePipeline  # noqa: F401
+from .vae import AutoencoderKL  # noqa: F401
 
 __version__ = "0.1.0"

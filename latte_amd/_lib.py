@@ -52,13 +52,13 @@ PROTOTYPES = {
                                   c_void, c_void, c_void, c_void]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_bench_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_f32), c_void]),
-    "latte_vae_create": (c_int, [c_int, c_int, ctypes.POINTER(c_void)]),
+    "latte_vae_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void)]),
     "latte_vae_destroy": (None, [c_void]),
     "latte_vae_num_keys": (c_int, [c_void]),
     "latte_vae_key": (c_char, [c_void, c_int]),
     "latte_vae_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
     "latte_vae_check_weights": (c_int, [c_void]),
-    "latte_vae_decode": (c_int, [c_void, c_void, c_int, c_int, c_int, c_f32, c_void, c_void, c_void]),
+    "latte_vae_decode": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void]),
     # test hooks
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),
@@ -69,6 +69,10 @@ PROTOTYPES = {
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),
     "latte_debug_fill_normal": (c_int, [c_void, c_i64, c_u64, c_u64, c_void]),
     "latte_debug_tr16_probe": (c_int, [c_void, c_void]),
+    "latte_debug_conv3x3": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_void]),
+    "latte_debug_vae_trace": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_void, c_void]),
+    "latte_debug_groupnorm": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
 }
 
 _lib = None

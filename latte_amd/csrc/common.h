@@ -38,6 +38,7 @@ enum GemmEpi : int {
   EPI_GATE_RES_F32 = 2,   // res(fp32)[m,n] += gate[sample(m)][n] * (acc + bias)
   EPI_BIAS_F32 = 3,       // out(fp32) = acc + bias
   EPI_ABLATE_NOSTORE = 4, // measurement only: bias add, nothing written (persistent kernel only)
+  EPI_BIAS_RES_H16 = 5,   // out(half) = acc + bias + res(half)[m,n]   (plain kernel only; VAE attention out-proj)
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -45,6 +46,7 @@ struct GemmArgs {
   const float* bias;  // [N]
   void* out;          // half [Mpad, N] | fp32 [Mpad, N]
   const float* gate;  // EPI_GATE_RES: gate base, row stride gate_stride (per sample)
+  const half_t* res;  // EPI_BIAS_RES_H16: residual [Mpad, N] (may alias out)
   int M, N, K;        // M = valid rows; grid covers ceil(M / BM) tiles
   int gate_stride;
   int rows_per_sample;
@@ -90,9 +92,25 @@ int launch_final_layer(const float* x, const float* shift, const float* scale, i
                        int rows_per_sample, int T, int p, int Cout, int H, hipStream_t st);
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
+int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);
 int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);
 // Philox4x32-10 + Box-Muller standard normals; element i depends only on (seed, offset + i).
 int launch_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+
+// ---- VAE decoder kernels (vae.hip) -----------------------------------------------------------------
+int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
+                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st);
+int launch_groupnorm(const half_t* x, half_t* y, const float* gamma, const float* beta, float* partial, float* stats, int N,
+                     int HW, int C, int silu, int dtype, hipStream_t st);
+int groupnorm_max_slabs();
+int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st);
+int launch_conv_in(const float* x, const float* wt, const float* bias, half_t* out, int N, int H, int W, int Cout, int dtype,
+                   hipStream_t st);
+int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* out, int N, int H, int W, int C, int out_mode,
+                    int dtype, hipStream_t st);
+int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st);
+int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st);
+int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t st);
 
 struct SamplerCoefs {  // fp32 values of the fp64 tables at the step (gaussian_diffusion.py:869-881)
   float min_log, max_log, sqrt_recip, sqrt_recipm1, coef1, coef2;

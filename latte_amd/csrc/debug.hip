@@ -25,6 +25,7 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
   GemmArgs g{};
   g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = out; g.gate = gate;
   g.M = M; g.N = N; g.K = K; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample;
+  if (epi == EPI_BIAS_RES_H16) g.res = (const half_t*)gate;   // epi 5: `gate` carries the half residual [Mpad, N]
   return launch_gemm(g, epi, dtype, variant, (hipStream_t)stream);
 }
 
@@ -49,6 +50,34 @@ int latte_debug_convert(const float* in, void* out, int64_t n, int dtype, void* 
 
 int latte_debug_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
   return launch_fill_normal(out, (size_t)n, seed, offset, (hipStream_t)stream);
+}
+
+int latte_debug_conv3x3(const void* in, const float* w, const float* bias, const void* res, void* out, int N, int H, int W,
+                        int Cin, int Cout, int ups, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  half_t *wp = nullptr, *zeros = nullptr;
+  LATTE_HIP(hipMalloc((void**)&wp, (size_t)Cout * Cin * 9 * 2));
+  LATTE_HIP(hipMalloc((void**)&zeros, 64));
+  LATTE_HIP(hipMemsetAsync(zeros, 0, 64, st));
+  int rc = launch_pack_conv_w(w, wp, Cout, Cin, dtype, st);
+  if (!rc) rc = launch_conv3x3((const half_t*)in, wp, bias, (const half_t*)res, (half_t*)out, zeros, N, H, W, Cin, Cout, ups, dtype, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(wp);
+  (void)hipFree(zeros);
+  return rc;
+}
+
+int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
+                          int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float *partial = nullptr, *stats = nullptr;
+  LATTE_HIP(hipMalloc((void**)&partial, (size_t)N * groupnorm_max_slabs() * 64 * 4));
+  LATTE_HIP(hipMalloc((void**)&stats, (size_t)N * 64 * 4));
+  int rc = launch_groupnorm((const half_t*)x, (half_t*)y, gamma, beta, partial, stats, N, HW, C, silu, dtype, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(partial);
+  (void)hipFree(stats);
+  return rc;
 }
 
 int latte_debug_tr16_probe(uint16_t* out, void* stream) {

@@ -16,46 +16,15 @@
 //  * XCD-aware, grouped block->tile mapping so that co-resident tiles of one XCD share A/W panels in
 //    that XCD's private L2.
 #include "common.h"
+#include "mfma_util.h"
 
 namespace latte {
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-
-template <int DT>
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-  if constexpr (DT == LATTE_DTYPE_BF16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-template <int DT>
-__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
-  if constexpr (DT == LATTE_DTYPE_BF16) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned int, v);
-  } else {
-    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-    f16x2 v = {(_Float16)lo, (_Float16)hi};
-    return __builtin_bit_cast(unsigned int, v);
-  }
-}
 
 // GELU(tanh approximation) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (latte.py:170)
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
-}
-
-__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // One accumulator fragment -> memory.  Lane holds 4 consecutive columns n..n+3 of row m.
@@ -66,6 +35,21 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4& a
   const size_t o = (size_t)m * g.N + n;
   if constexpr (EPI == EPI_ABLATE_NOSTORE) {
     asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+  } else if constexpr (EPI == EPI_BIAS_RES_H16) {
+    const u32x2 r2 = *(const u32x2*)(g.res + o);
+    if constexpr (DT == LATTE_DTYPE_BF16) {
+      v0 += __builtin_bit_cast(float, r2[0] << 16); v1 += __builtin_bit_cast(float, r2[0] & 0xffff0000u);
+      v2 += __builtin_bit_cast(float, r2[1] << 16); v3 += __builtin_bit_cast(float, r2[1] & 0xffff0000u);
+    } else {
+      // (scalar copies first: bit-casting the vector elements directly was miscompiled into re-using element 0)
+      const unsigned int lo = r2[0], hi = r2[1];
+      v0 += (float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu));
+      v1 += (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
+      v2 += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu));
+      v3 += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
+    }
+    u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+    *(u32x2*)((half_t*)g.out + o) = p;
   } else if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
     if constexpr (EPI == EPI_BIAS_GELU_H16) {
       v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
@@ -81,23 +65,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4& a
   } else {
     *(float4*)((float*)g.out + o) = make_float4(v0, v1, v2, v3);
   }
-}
-
-// XCD-aware bijective remap (blocks are dispatched round-robin over the 8 XCDs): give every XCD a
-// contiguous chunk of the tile sequence, then walk tiles in groups of GROUP_M tile-rows.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int in_group = wg - group * per_group;
-  tm = first_m + in_group % gsz;
-  tn = in_group / gsz;
 }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int DT>
@@ -211,6 +178,7 @@ int launch_cfg(const GemmArgs& a, int epi, hipStream_t st) {
     LATTE_GEMM_CASE(EPI_BIAS_GELU_H16)
     LATTE_GEMM_CASE(EPI_GATE_RES_F32)
     LATTE_GEMM_CASE(EPI_BIAS_F32)
+    LATTE_GEMM_CASE(EPI_BIAS_RES_H16)
     default:
       return fail(LATTE_ERR_INVALID, "gemm: unknown epilogue");
   }

@@ -332,6 +332,14 @@ __global__ void convert_kernel(const float* __restrict__ in, half_t* __restrict_
   }
 }
 
+template <int DT>
+__global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (DT == LATTE_DTYPE_BF16) out[i] = __builtin_bit_cast(float, (unsigned int)in[i] << 16);
+    else out[i] = (float)__builtin_bit_cast(_Float16, in[i]);
+  }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   const size_t total = (size_t)rows * cols;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -496,6 +504,15 @@ int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype
     hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
   else
     hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st) {
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(widen_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  else
+    hipLaunchKernelGGL(widen_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -1,0 +1,515 @@
+// SD-VAE decoder kernels (gfx950):  AutoencoderKL.decode of diffusers 0.24.0, called by the reference at
+// /root/reference/sample/sample.py:113-115 and sample_ddp.py:165-168 (class not vendored: see oracle/vae_oracle.py).
+//
+// Activations are NHWC half [N, H, W, C] (a pixel's channels are contiguous), so
+//   conv3x3     = implicit GEMM  out[p, co] = sum_{tap, ci} in[p + tap, ci] * Wp[co, tap * Cin + ci]
+//                 on the MFMA tile machinery of gemm.hip: 128 pixels x 128 output channels per workgroup, BK = 64
+//                 (one tap, 64 input channels), both operands K-contiguous, staged by global_load_lds with the
+//                 bank swizzle on the SOURCE address.  The zero padding, and the nearest-2x upsample of
+//                 Upsample2D, live in the per-lane source address (a padded tap reads a zero page; an upsampled
+//                 tap reads pixel (y >> 1, x >> 1)) -- the upsampled tensor is never materialised;
+//   GroupNorm   = partial sums per (image, slab, group) -> finalize -> apply (+ SiLU), fp32 statistics;
+//   conv_in / post_quant_conv / conv_out (4 -> 4, 4 -> 512, 128 -> 3 channels) = small direct kernels;
+//   attention   = 1 head of 512 over H*W tokens: plain GEMMs (gemm.hip) + a row softmax.
+#include "mfma_util.h"
+
+namespace latte {
+namespace {
+
+__device__ __forceinline__ float h2f_bf16(unsigned int lo16) { return __builtin_bit_cast(float, lo16 << 16); }
+template <int DT>
+__device__ __forceinline__ void unpack2(unsigned int u, float& a, float& b) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    a = __builtin_bit_cast(float, u << 16);
+    b = __builtin_bit_cast(float, u & 0xffff0000u);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    const f16x2 h = __builtin_bit_cast(f16x2, u);
+    a = (float)h[0];
+    b = (float)h[1];
+  }
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+struct ConvArgs {
+  const half_t* in;     // [N, Hin, Win, Cin]
+  const half_t* w;      // [Cout, 9 * Cin], k = (ky * 3 + kx) * Cin + ci
+  const float* bias;    // [Cout]
+  const half_t* res;    // nullptr or [N, Hout, Wout, Cout] residual (may alias out)
+  half_t* out;          // [N, Hout, Wout, Cout]
+  const half_t* zeros;  // >= 16 bytes of zeros (padded taps)
+  int N, Hin, Win, Cin, Cout, ups;   // Hout = Hin << ups
+};
+
+// 128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators.
+template <int DT>
+__global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
+  constexpr int BM = 128, BN = 128, NW = 4;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int INSTR = BM / 8 / NW;   // 4 row-group instructions per operand per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Hout = g.Hin << g.ups, Wout = g.Win << g.ups;
+  const int M = g.N * Hout * Wout;
+  const int K = 9 * g.Cin;
+  int tm, tn;
+  tile_coords((M + BM - 1) / BM, g.Cout / BN, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: lane fills bytes [16 * lane, +16) of an 8-row group -> row lrow, chunk position cpos of the image;
+  // it fetches logical chunk cpos ^ swizzle(row)
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const int srow = wave * 8 + lrow;
+  const int schunk = cpos ^ ((srow >> 1) & 7);
+  int py[INSTR], px[INSTR], pbase[INSTR];   // output pixel (y, x) and image base pixel index of row srow + 32 j
+#pragma unroll
+  for (int j = 0; j < INSTR; ++j) {
+    const int m = m0 + srow + 32 * j;
+    if (m < M) {
+      const int img = m / (Hout * Wout), rem = m - img * (Hout * Wout);
+      py[j] = rem / Wout;
+      px[j] = rem - py[j] * Wout;
+      pbase[j] = img * g.Hin * g.Win;
+    } else {
+      py[j] = -4;   // every tap out of range
+      px[j] = 0;
+      pbase[j] = 0;
+    }
+  }
+  const half_t* b_src = g.w + (size_t)(n0 + srow) * K + schunk * 8;
+  const size_t bstride = (size_t)NW * 8 * K;
+  const int cpt = g.Cin >> 6;   // K tiles per tap
+
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * STAGE + wave * 1024;
+    char* sB = sA + A_BYTES;
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int j = 0; j < INSTR; ++j) {
+      const int yy = py[j] + dy, xx = px[j] + dx;
+      const bool ok = yy >= 0 && yy < Hout && xx >= 0 && xx < Wout;
+      const int sy = yy >> g.ups, sx = xx >> g.ups;
+      const half_t* src = ok ? g.in + ((size_t)(pbase[j] + sy * g.Win + sx) * g.Cin + c0 + schunk * 8) : g.zeros;
+      glds16(src, sA + j * NW * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < INSTR; ++j) glds16(b_src + j * bstride + kt * 64, sB + j * NW * 1024);
+  };
+
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int chunk0 = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (wm * 64 + frow) * 128 + chunk0;
+  const int b_off = A_BYTES + (wn * 64 + frow) * 128 + chunk0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* sbuf = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(bf[j], af[i], acc[i][j]);
+    }
+  }
+
+  // lane holds out[pixel m = .. + (lane & 15)][co = .. + (lane >> 4) * 4 + {0..3}]
+  const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol + j * 16;
+      const float4 b4 = *(const float4*)(g.bias + n);
+      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      const size_t o = (size_t)m * g.Cout + n;
+      if (g.res != nullptr) {
+        const u32x2 r2 = *(const u32x2*)(g.res + o);
+        float r0, r1, r2f, r3;
+        unpack2<DT>(r2[0], r0, r1);
+        unpack2<DT>(r2[1], r2f, r3);
+        v0 += r0; v1 += r1; v2 += r2f; v3 += r3;
+      }
+      const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+      *(u32x2*)(g.out + o) = p;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// partial[n][slab][g] = (sum, sumsq) over the slab's pixels and the group's channels.  One thread owns 8 consecutive
+// channels of a pixel (16-byte loads); the per-thread sums are combined in a FIXED order (deterministic).
+template <int DT>
+__global__ void __launch_bounds__(256) gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial, int HW,
+                                                         int C, int slabs) {
+  __shared__ float red[256 * 4];
+  const int n = blockIdx.y, slab = blockIdx.x;
+  const int oct_per_px = C >> 3;               // threads per pixel
+  const int px_per_it = 256 / oct_per_px;      // C in {128, 256, 512} -> 16, 8, 4 pixels per iteration
+  const int oct = threadIdx.x % oct_per_px, pl = threadIdx.x / oct_per_px;
+  const int per = (HW + slabs - 1) / slabs;
+  const int p0 = slab * per, p1 = min(HW, p0 + per);
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;   // channels [8 oct, +4) and [8 oct + 4, +4)
+  for (int p = p0 + pl; p < p1; p += px_per_it) {
+    const u32x4 v = *(const u32x4*)(x + ((size_t)n * HW + p) * C + oct * 8);
+    float a, b;
+    unpack2<DT>(v[0], a, b); s0 += a + b; q0 += a * a + b * b;
+    unpack2<DT>(v[1], a, b); s0 += a + b; q0 += a * a + b * b;
+    unpack2<DT>(v[2], a, b); s1 += a + b; q1 += a * a + b * b;
+    unpack2<DT>(v[3], a, b); s1 += a + b; q1 += a * a + b * b;
+  }
+  red[threadIdx.x * 4 + 0] = s0; red[threadIdx.x * 4 + 1] = q0;
+  red[threadIdx.x * 4 + 2] = s1; red[threadIdx.x * 4 + 3] = q1;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int gi = threadIdx.x, cpg = C >> 5;    // channels per group: 4, 8, 16
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < 256; ++t) {
+      const int o = t % oct_per_px;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if ((o * 8 + h * 4) / cpg == gi) {
+          s += red[t * 4 + 2 * h];
+          q += red[t * 4 + 2 * h + 1];
+        }
+    }
+    float* out = partial + (((size_t)n * slabs + slab) * 32 + gi) * 2;
+    out[0] = s;
+    out[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int slabs, float count,
+                                   float eps) {
+  const int n = blockIdx.x, gi = threadIdx.x;   // 32 threads
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < slabs; ++k) {
+    const float* p = partial + (((size_t)n * slabs + k) * 32 + gi) * 2;
+    s += p[0];
+    q += p[1];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[(n * 32 + gi) * 2] = (float)mean;
+  stats[(n * 32 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <int DT, bool SILU>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int HW, int C, size_t total_oct) {
+  const int cpg = C >> 5, oct_per_px = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_oct; i += (size_t)gridDim.x * blockDim.x) {
+    const int oct = (int)(i % oct_per_px);
+    const size_t px = i / oct_per_px;
+    const int n = (int)(px / HW);
+    const int c0 = oct * 8;
+    const u32x4 v = *(const u32x4*)(x + i * 8);
+    float f[8];
+    unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
+    unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+    const float4 ga = *(const float4*)(gamma + c0), gb = *(const float4*)(gamma + c0 + 4);
+    const float4 ba = *(const float4*)(beta + c0), bb = *(const float4*)(beta + c0 + 4);
+    const float gam[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    const float bet[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int gi = (c0 + e) / cpg;
+      const float mean = stats[(n * 32 + gi) * 2], rstd = stats[(n * 32 + gi) * 2 + 1];
+      float t = (f[e] - mean) * rstd * gam[e] + bet[e];
+      if constexpr (SILU) t = silu_f(t);
+      o[e] = t;
+    }
+    const u32x4 w = {pack2<DT>(o[0], o[1]), pack2<DT>(o[2], o[3]), pack2<DT>(o[4], o[5]), pack2<DT>(o[6], o[7])};
+    *(u32x4*)(y + i * 8) = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small convs
+// z [N, 4, h, w] fp32 (NCHW, reference layout) * z_scale -> post_quant_conv (1x1, 4 -> 4) -> [N, h, w, 4] fp32
+__global__ void post_quant_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b,
+                                  float* __restrict__ out, int N, int hw, float z_scale) {
+  const int total = N * hw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / hw, p = i - n * hw;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = z[((size_t)n * 4 + c) * hw + p] * z_scale;
+    float4 o;
+    o.x = b[0] + w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+    o.y = b[1] + w[4] * v[0] + w[5] * v[1] + w[6] * v[2] + w[7] * v[3];
+    o.z = b[2] + w[8] * v[0] + w[9] * v[1] + w[10] * v[2] + w[11] * v[3];
+    o.w = b[3] + w[12] * v[0] + w[13] * v[1] + w[14] * v[2] + w[15] * v[3];
+    *(float4*)(out + (size_t)i * 4) = o;
+  }
+}
+
+// conv_in: [N, h, w, 4] fp32 -> [N, h, w, Cout] half, 3x3 pad 1.  wt = [36][Cout] fp32 (k = (ky*3+kx)*4 + ci).
+template <int DT>
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, half_t* __restrict__ out, int N, int H,
+                                                      int W, int Cout) {
+  __shared__ float patch[36];
+  const int p = blockIdx.x;   // output pixel
+  const int n = p / (H * W), rem = p - n * H * W, y = rem / W, xw = rem - y * W;
+  if (threadIdx.x < 36) {
+    const int tap = threadIdx.x >> 2, ci = threadIdx.x & 3;
+    const int yy = y + tap / 3 - 1, xx = xw + tap % 3 - 1;
+    patch[threadIdx.x] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(((size_t)n * H + yy) * W + xx) * 4 + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x * 2; co < Cout; co += 512) {
+    float a0 = bias[co], a1 = bias[co + 1];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+      const float2 w2 = *(const float2*)(wt + (size_t)k * Cout + co);
+      a0 = fmaf(patch[k], w2.x, a0);
+      a1 = fmaf(patch[k], w2.y, a1);
+    }
+    *(unsigned int*)(out + (size_t)p * Cout + co) = pack2<DT>(a0, a1);
+  }
+}
+
+// conv_out: [N, H, W, C] half -> 3 channels, 3x3 pad 1.  wt = [3][9 * C] fp32.  One wave per output pixel row
+// segment: lanes over pixels, channels in the inner loop (16-byte loads).
+// out_mode 0: fp32 NCHW [N, 3, H, W] (the reference's .sample); 1: uint8 NHWC [N, H, W, 3] = sample.py:122
+template <int DT>
+__global__ void __launch_bounds__(256) conv_out_kernel(const half_t* __restrict__ x, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, void* __restrict__ out, int N, int H,
+                                                       int W, int C, int out_mode) {
+  extern __shared__ float wl[];   // [3][9 * C]
+  for (int i = threadIdx.x; i < 27 * C; i += 256) wl[i] = wt[i];
+  __syncthreads();
+  const int total = N * H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  const int n = p / (H * W), rem = p - n * H * W, y = rem / W, xw = rem - y * W;
+  float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yy = y + tap / 3 - 1, xx = xw + tap % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const half_t* px = x + (((size_t)n * H + yy) * W + xx) * C;
+    const float* w0 = wl + tap * C;
+    const float* w1 = wl + 9 * C + tap * C;
+    const float* w2 = wl + 18 * C + tap * C;
+    for (int c = 0; c < C; c += 8) {
+      const u32x4 v = *(const u32x4*)(px + c);
+      float f[8];
+      unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
+      unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a0 = fmaf(f[e], w0[c + e], a0);
+        a1 = fmaf(f[e], w1[c + e], a1);
+        a2 = fmaf(f[e], w2[c + e], a2);
+      }
+    }
+  }
+  if (out_mode == 0) {
+    float* o = (float*)out;
+    const size_t hw = (size_t)H * W;
+    o[((size_t)n * 3 + 0) * hw + rem] = a0;
+    o[((size_t)n * 3 + 1) * hw + rem] = a1;
+    o[((size_t)n * 3 + 2) * hw + rem] = a2;
+  } else {
+#pragma clang fp contract(off)
+    unsigned char* o = (unsigned char*)out + (size_t)p * 3;
+    const float v[3] = {a0, a1, a2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = (v[c] * 0.5f + 0.5f) * 255.0f + 0.5f;     // sample.py:122
+      t = fminf(fmaxf(t, 0.0f), 255.0f);
+      o[c] = (unsigned char)t;                             // .to(torch.uint8) truncates
+    }
+  }
+}
+
+// P[row, :] = softmax(scale * S[row, :]) -> half; one wave per row (L % 64 == 0, L <= 4096)
+template <int DT>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ s, half_t* __restrict__ p, int rows, int L,
+                                                           float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + (size_t)row * L;
+  float mx = -1e30f;
+  for (int c = lane; c < L; c += 64) mx = fmaxf(mx, sr[c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < L; c += 64) sum += __expf(sr[c] * scale - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.0f / sum;
+  half_t* pr = p + (size_t)row * L;
+  for (int c = lane; c < L; c += 64) {
+    const float v = __expf(sr[c] * scale - mx) * inv;
+    if constexpr (DT == LATTE_DTYPE_BF16) {
+      const __bf16 h = (__bf16)v;
+      pr[c] = __builtin_bit_cast(half_t, h);
+    } else {
+      const _Float16 h = (_Float16)v;
+      pr[c] = __builtin_bit_cast(half_t, h);
+    }
+  }
+}
+
+// [Cout, Cin, 3, 3] fp32 -> [Cout, 9 * Cin] half, k = (ky * 3 + kx) * Cin + ci
+template <int DT>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / ((size_t)Cin * 9));
+    const int r = (int)(i - (size_t)co * Cin * 9);
+    const int tap = r / Cin, ci = r - tap * Cin;
+    const float v = w[((size_t)co * Cin + ci) * 9 + tap];
+    if constexpr (DT == LATTE_DTYPE_BF16) {
+      const __bf16 h = (__bf16)v;
+      out[i] = __builtin_bit_cast(half_t, h);
+    } else {
+      const _Float16 h = (_Float16)v;
+      out[i] = __builtin_bit_cast(half_t, h);
+    }
+  }
+}
+
+// [Cout, Cin, 3, 3] fp32 -> [9 * Cin][Cout] fp32 (conv_in) or [Cout][9 * Cin] fp32 (conv_out: tr = 0)
+__global__ void pack_small_w_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int tr) {
+  const int total = Cout * Cin * 9;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i / (Cin * 9), r = i - co * Cin * 9;
+    const int ci = r / 9, tap = r - ci * 9;
+    const int k = tap * Cin + ci;
+    if (tr) out[(size_t)k * Cout + co] = w[i];
+    else out[(size_t)co * 9 * Cin + k] = w[i];
+  }
+}
+
+inline int grid_for(size_t n, int block) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g > 8192 ? 8192 : (g == 0 ? 1 : g));
+}
+
+}  // namespace
+
+int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
+                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st) {
+  if (Cin % 64 != 0 || Cout % 128 != 0) return fail(LATTE_ERR_INVALID, "conv3x3: need Cin % 64 == 0 and Cout % 128 == 0");
+  ConvArgs a{in, w, bias, res, out, zeros, N, Hin, Win, Cin, Cout, ups};
+  const int M = N * (Hin << ups) * (Win << ups);
+  const int tiles = ((M + 127) / 128) * (Cout / 128);
+  constexpr int LDS = 2 * 256 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    LATTE_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<LATTE_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    LATTE_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  if (dtype == LATTE_DTYPE_BF16) {
+    hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_BF16>, dim3(tiles), dim3(256), LDS, st, a);
+  } else {
+    hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);
+  }
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_groupnorm(const half_t* x, half_t* y, const float* gamma, const float* beta, float* partial, float* stats, int N,
+                     int HW, int C, int silu, int dtype, hipStream_t st) {
+  if (C != 128 && C != 256 && C != 512) return fail(LATTE_ERR_INVALID, "groupnorm: C must be 128, 256 or 512");
+  int slabs = HW / 1024;
+  if (slabs < 1) slabs = 1;
+  if (slabs > 64) slabs = 64;
+  const size_t total_oct = (size_t)N * HW * C / 8;
+  const bool bf = dtype == LATTE_DTYPE_BF16;
+  if (bf) hipLaunchKernelGGL(gn_partial_kernel<LATTE_DTYPE_BF16>, dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  else hipLaunchKernelGGL(gn_partial_kernel<LATTE_DTYPE_F16>, dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), 1e-6f);
+  const dim3 grid(grid_for(total_oct, 256));
+#define GN_APPLY(DT, S) hipLaunchKernelGGL((gn_apply_kernel<DT, S>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
+  if (bf) { if (silu) GN_APPLY(LATTE_DTYPE_BF16, true); else GN_APPLY(LATTE_DTYPE_BF16, false); }
+  else    { if (silu) GN_APPLY(LATTE_DTYPE_F16, true); else GN_APPLY(LATTE_DTYPE_F16, false); }
+#undef GN_APPLY
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int groupnorm_max_slabs() { return 64; }
+
+int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st) {
+  hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((size_t)N * hw, 256)), dim3(256), 0, st, z, w, b, out, N, hw, z_scale);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_conv_in(const float* x, const float* wt, const float* bias, half_t* out, int N, int H, int W, int Cout, int dtype,
+                   hipStream_t st) {
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(conv_in_kernel<LATTE_DTYPE_BF16>, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
+  else
+    hipLaunchKernelGGL(conv_in_kernel<LATTE_DTYPE_F16>, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* out, int N, int H, int W, int C, int out_mode,
+                    int dtype, hipStream_t st) {
+  const int total = N * H * W;
+  const size_t lds = (size_t)27 * C * sizeof(float);
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_BF16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
+  else
+    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st) {
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_BF16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_F16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st) {
+  const size_t n = (size_t)Cout * Cin * 9;
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
+  else
+    hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t st) {
+  hipLaunchKernelGGL(pack_small_w_kernel, dim3(grid_for((size_t)Cout * Cin * 9, 256)), dim3(256), 0, st, w, out, Cout, Cin, transpose);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+}  // namespace latte

@@ -1,0 +1,341 @@
+// Host logic of the SD-VAE decoder: weight ingestion by diffusers state-dict key, workspace, decode().
+//
+//   AutoencoderKL.decode(z).sample      diffusers 0.24.0 (un-vendored; oracle/vae_oracle.py restates it)
+//   called by the reference at          /root/reference/sample/sample.py:113-115, sample_ddp.py:165-168
+//   uint8 video conversion              /root/reference/sample/sample.py:122
+//
+// Activation layout: NHWC half.  Four ping-pong buffers sized for the largest map ([N, 8h, 8w, 256]).
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace latte;
+
+namespace {
+
+enum VPack { VP_F32, VP_CONV3, VP_LINEAR_H16, VP_SMALL_T, VP_SMALL };
+struct VSlot {
+  std::string key;
+  int64_t numel;
+  VPack kind;
+  void* dst;
+  int cout, cin;
+  bool loaded = false;
+};
+struct Resnet {
+  int cin, cout;
+  float *n1w, *n1b, *n2w, *n2b, *c1b, *c2b, *scb = nullptr;
+  half_t *c1w, *c2w, *scw = nullptr;
+};
+
+}  // namespace
+
+struct latte_vae {
+  int h = 0, max_frames = 0, dtype = 0;
+  int ch[4] = {128, 256, 512, 512};   // block_out_channels
+  std::vector<VSlot> slots;
+  std::map<std::string, int> index;
+  std::vector<void*> allocs;
+  float *pq_w, *pq_b, *ci_wt, *ci_b, *co_w, *co_b, *no_w, *no_b;
+  Resnet mid[2];
+  Resnet up[4][3];
+  half_t* upc_w[3];
+  float* upc_b[3];
+  float *agn_w, *agn_b, *aq_b, *ak_b, *av_b, *ao_b, *ao_b_eff, *zero_bias;
+  float* ao_w_f32;     // to_out weight in fp32 (for the folded bias  Wo bv + bo)
+  half_t *aq_w, *ak_w, *av_w, *ao_w;
+  half_t* buf[4];
+  half_t* zeros;
+  float *pq_out, *scores, *gn_partial, *gn_stats, *stage;
+  int64_t stage_numel = 0;
+  bool bias_folded = false;
+};
+
+namespace {
+
+template <typename Tp>
+int valloc(latte_vae* v, Tp** p, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = count * sizeof(Tp);
+  LATTE_HIP(hipMalloc(&q, bytes ? bytes : 16));
+  LATTE_HIP(hipMemset(q, 0, bytes ? bytes : 16));
+  v->allocs.push_back(q);
+  *p = (Tp*)q;
+  return LATTE_OK;
+}
+
+void vslot(latte_vae* v, const std::string& key, int64_t numel, VPack kind, void* dst, int cout = 0, int cin = 0) {
+  VSlot s;
+  s.key = key; s.numel = numel; s.kind = kind; s.dst = dst; s.cout = cout; s.cin = cin;
+  v->index[key] = (int)v->slots.size();
+  v->slots.push_back(s);
+  if (numel > v->stage_numel) v->stage_numel = numel;
+}
+
+int make_resnet(latte_vae* v, Resnet& r, const std::string& p, int cin, int cout) {
+  r.cin = cin; r.cout = cout;
+  int rc;
+  if ((rc = valloc(v, &r.n1w, cin)) || (rc = valloc(v, &r.n1b, cin)) || (rc = valloc(v, &r.n2w, cout)) ||
+      (rc = valloc(v, &r.n2b, cout)) || (rc = valloc(v, &r.c1b, cout)) || (rc = valloc(v, &r.c2b, cout)) ||
+      (rc = valloc(v, &r.c1w, (size_t)cout * cin * 9)) || (rc = valloc(v, &r.c2w, (size_t)cout * cout * 9)))
+    return rc;
+  vslot(v, p + "norm1.weight", cin, VP_F32, r.n1w);
+  vslot(v, p + "norm1.bias", cin, VP_F32, r.n1b);
+  vslot(v, p + "conv1.weight", (int64_t)cout * cin * 9, VP_CONV3, r.c1w, cout, cin);
+  vslot(v, p + "conv1.bias", cout, VP_F32, r.c1b);
+  vslot(v, p + "norm2.weight", cout, VP_F32, r.n2w);
+  vslot(v, p + "norm2.bias", cout, VP_F32, r.n2b);
+  vslot(v, p + "conv2.weight", (int64_t)cout * cout * 9, VP_CONV3, r.c2w, cout, cout);
+  vslot(v, p + "conv2.bias", cout, VP_F32, r.c2b);
+  if (cin != cout) {
+    if ((rc = valloc(v, &r.scw, (size_t)cout * cin)) || (rc = valloc(v, &r.scb, cout))) return rc;
+    vslot(v, p + "conv_shortcut.weight", (int64_t)cout * cin, VP_LINEAR_H16, r.scw);
+    vslot(v, p + "conv_shortcut.bias", cout, VP_F32, r.scb);
+  }
+  return LATTE_OK;
+}
+
+int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, const half_t* res, int M, int N, int K, int epi,
+             int dtype, hipStream_t st) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.res = res; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M;
+  return launch_gemm(g, epi, dtype, 1, st);   // plain 128 x 128 kernel: small, oddly shaped problems
+}
+
+// x (buf a) -> ResnetBlock2D -> buf a (in place);  b, c, d scratch.  [N, H, W, C]
+int run_resnet(latte_vae* v, const Resnet& r, half_t* a, half_t* b, half_t* c, half_t* d, int N, int H, int W, hipStream_t st) {
+  int rc;
+  const int HW = H * W, dt = v->dtype;
+  if ((rc = launch_groupnorm(a, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st))) return rc;
+  if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, b, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st))) return rc;
+  if ((rc = launch_groupnorm(b, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st))) return rc;
+  const half_t* res = a;
+  if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels
+    if ((rc = gemm_h16(a, r.scw, r.scb, d, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_H16, dt, st))) return rc;
+    res = d;
+  }
+  return launch_conv3x3(c, r.c2w, r.c2b, res, a, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out) {
+  if (!out || latent_size <= 0 || max_frames <= 0) return fail(LATTE_ERR_INVALID, "vae_create: bad arguments");
+  if (compute_dtype != LATTE_DTYPE_BF16 && compute_dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "vae_create: bad compute dtype");
+  if (latent_size % 16 != 0 || latent_size > 64)
+    return fail(LATTE_ERR_INVALID, "vae_create: latent_size must be a multiple of 16, at most 64");
+  auto* v = new latte_vae();
+  v->h = latent_size; v->max_frames = max_frames; v->dtype = compute_dtype;
+  const int top = v->ch[3];
+  int rc = LATTE_OK;
+#define TRY(x) do { if ((rc = (x))) { latte_vae_destroy(v); return rc; } } while (0)
+  TRY(valloc(v, &v->pq_w, 16)); TRY(valloc(v, &v->pq_b, 4));
+  TRY(valloc(v, &v->ci_wt, (size_t)36 * top)); TRY(valloc(v, &v->ci_b, top));
+  TRY(valloc(v, &v->co_w, (size_t)27 * v->ch[0])); TRY(valloc(v, &v->co_b, 4));
+  TRY(valloc(v, &v->no_w, v->ch[0])); TRY(valloc(v, &v->no_b, v->ch[0]));
+  vslot(v, "post_quant_conv.weight", 16, VP_F32, v->pq_w);
+  vslot(v, "post_quant_conv.bias", 4, VP_F32, v->pq_b);
+  vslot(v, "decoder.conv_in.weight", (int64_t)top * 36, VP_SMALL_T, v->ci_wt, top, 4);
+  vslot(v, "decoder.conv_in.bias", top, VP_F32, v->ci_b);
+  TRY(make_resnet(v, v->mid[0], "decoder.mid_block.resnets.0.", top, top));
+  {
+    const std::string a = "decoder.mid_block.attentions.0.";
+    TRY(valloc(v, &v->agn_w, top)); TRY(valloc(v, &v->agn_b, top));
+    TRY(valloc(v, &v->aq_b, top)); TRY(valloc(v, &v->ak_b, top)); TRY(valloc(v, &v->av_b, top)); TRY(valloc(v, &v->ao_b, top));
+    TRY(valloc(v, &v->ao_b_eff, top)); TRY(valloc(v, &v->zero_bias, 4096));
+    TRY(valloc(v, &v->aq_w, (size_t)top * top)); TRY(valloc(v, &v->ak_w, (size_t)top * top));
+    TRY(valloc(v, &v->av_w, (size_t)top * top)); TRY(valloc(v, &v->ao_w, (size_t)top * top));
+    TRY(valloc(v, &v->ao_w_f32, (size_t)top * top));
+    vslot(v, a + "group_norm.weight", top, VP_F32, v->agn_w);
+    vslot(v, a + "group_norm.bias", top, VP_F32, v->agn_b);
+    vslot(v, a + "to_q.weight", (int64_t)top * top, VP_LINEAR_H16, v->aq_w);
+    vslot(v, a + "to_q.bias", top, VP_F32, v->aq_b);
+    vslot(v, a + "to_k.weight", (int64_t)top * top, VP_LINEAR_H16, v->ak_w);
+    vslot(v, a + "to_k.bias", top, VP_F32, v->ak_b);
+    vslot(v, a + "to_v.weight", (int64_t)top * top, VP_LINEAR_H16, v->av_w);
+    vslot(v, a + "to_v.bias", top, VP_F32, v->av_b);
+    vslot(v, a + "to_out.0.weight", (int64_t)top * top, VP_LINEAR_H16, v->ao_w);
+    vslot(v, a + "to_out.0.bias", top, VP_F32, v->ao_b);
+  }
+  TRY(make_resnet(v, v->mid[1], "decoder.mid_block.resnets.1.", top, top));
+  int prev = top;
+  for (int i = 0; i < 4; ++i) {
+    const int cout = v->ch[3 - i];
+    for (int r = 0; r < 3; ++r)
+      TRY(make_resnet(v, v->up[i][r], "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(r) + ".",
+                      r == 0 ? prev : cout, cout));
+    prev = cout;
+    if (i < 3) {
+      TRY(valloc(v, &v->upc_w[i], (size_t)cout * cout * 9));
+      TRY(valloc(v, &v->upc_b[i], cout));
+      const std::string p = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+      vslot(v, p + "weight", (int64_t)cout * cout * 9, VP_CONV3, v->upc_w[i], cout, cout);
+      vslot(v, p + "bias", cout, VP_F32, v->upc_b[i]);
+    }
+  }
+  vslot(v, "decoder.conv_norm_out.weight", v->ch[0], VP_F32, v->no_w);
+  vslot(v, "decoder.conv_norm_out.bias", v->ch[0], VP_F32, v->no_b);
+  vslot(v, "decoder.conv_out.weight", (int64_t)27 * v->ch[0], VP_SMALL, v->co_w, 3, v->ch[0]);
+  vslot(v, "decoder.conv_out.bias", 3, VP_F32, v->co_b);
+
+  // workspace: the largest NHWC map is [N, 8h, 8w, 256] (output of up_blocks.2's upsampler)
+  const size_t big = (size_t)max_frames * (8 * latent_size) * (8 * latent_size) * 256;
+  for (int i = 0; i < 4; ++i) TRY(valloc(v, &v->buf[i], big));
+  TRY(valloc(v, &v->zeros, 64));
+  TRY(valloc(v, &v->pq_out, (size_t)max_frames * latent_size * latent_size * 4));
+  const size_t L = (size_t)latent_size * latent_size;
+  TRY(valloc(v, &v->scores, L * L));
+  TRY(valloc(v, &v->gn_partial, (size_t)max_frames * groupnorm_max_slabs() * 64));
+  TRY(valloc(v, &v->gn_stats, (size_t)max_frames * 64));
+  TRY(valloc(v, &v->stage, (size_t)v->stage_numel));
+#undef TRY
+  *out = v;
+  return LATTE_OK;
+}
+
+void latte_vae_destroy(latte_vae_t* v) {
+  if (!v) return;
+  for (void* p : v->allocs) (void)hipFree(p);
+  delete v;
+}
+
+int latte_vae_num_keys(const latte_vae_t* v) { return v ? (int)v->slots.size() : 0; }
+const char* latte_vae_key(const latte_vae_t* v, int i) {
+  if (!v || i < 0 || i >= (int)v->slots.size()) return nullptr;
+  return v->slots[i].key.c_str();
+}
+
+int latte_vae_load_tensor(latte_vae_t* v, const char* key, const float* data, int64_t numel, int on_device, void* stream) {
+  if (!v || !key || !data) return fail(LATTE_ERR_INVALID, "vae_load_tensor: null argument");
+  auto it = v->index.find(key);
+  if (it == v->index.end()) return fail(LATTE_ERR_INVALID, std::string("vae_load_tensor: unexpected key '") + key + "'");
+  VSlot& s = v->slots[it->second];
+  if (numel != s.numel)
+    return fail(LATTE_ERR_INVALID, std::string("vae_load_tensor: size mismatch for '") + key + "': got " +
+                                       std::to_string(numel) + ", expected " + std::to_string(s.numel));
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = data;
+  if (!on_device) {
+    LATTE_HIP(hipMemcpyAsync(v->stage, data, sizeof(float) * numel, hipMemcpyHostToDevice, st));
+    src = v->stage;
+  }
+  int rc = LATTE_OK;
+  switch (s.kind) {
+    case VP_F32: LATTE_HIP(hipMemcpyAsync(s.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, st)); break;
+    case VP_CONV3: rc = launch_pack_conv_w(src, (half_t*)s.dst, s.cout, s.cin, v->dtype, st); break;
+    case VP_LINEAR_H16: rc = launch_convert_f32_to_h16(src, (half_t*)s.dst, numel, v->dtype, st); break;
+    case VP_SMALL_T: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 1, st); break;
+    case VP_SMALL: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 0, st); break;
+  }
+  if (rc) return rc;
+  if (s.key == "decoder.mid_block.attentions.0.to_out.0.weight")
+    LATTE_HIP(hipMemcpyAsync(v->ao_w_f32, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, st));
+  if (!on_device) LATTE_HIP(hipStreamSynchronize(st));
+  s.loaded = true;
+  v->bias_folded = false;
+  return LATTE_OK;
+}
+
+int latte_vae_check_weights(latte_vae_t* v) {
+  if (!v) return fail(LATTE_ERR_INVALID, "vae_check_weights: null");
+  for (const auto& s : v->slots)
+    if (!s.loaded) return fail(LATTE_ERR_STATE, "Missing key(s) in state_dict: \"" + s.key + "\"");
+  return LATTE_OK;
+}
+
+static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, void* stream,
+                           int stop_after, float* trace_out, int64_t* trace_numel, int* trace_dims);
+
+int latte_vae_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, void* stream) {
+  return vae_decode_impl(v, z, n_frames, z_scale, out_mode, out, stream, -1, nullptr, nullptr, nullptr);
+}
+
+/* test hook (include/latte_amd_debug.h): run the decoder up to and including stage `stop_after` and return that stage's
+ * NHWC activation as fp32. */
+int latte_debug_vae_trace(latte_vae_t* v, const float* z, int n_frames, float z_scale, int stop_after, float* trace_out,
+                          int64_t* trace_numel, int* trace_dims, void* stream) {
+  if (!trace_out || !trace_numel || !trace_dims || stop_after < 0) return fail(LATTE_ERR_INVALID, "vae_trace: bad arguments");
+  return vae_decode_impl(v, z, n_frames, z_scale, 0, trace_out, stream, stop_after, trace_out, trace_numel, trace_dims);
+}
+
+static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, void* stream,
+                           int stop_after, float* trace_out, int64_t* trace_numel, int* trace_dims) {
+  if (!v || !z || !out) return fail(LATTE_ERR_INVALID, "vae_decode: null argument");
+  if (n_frames <= 0 || n_frames > v->max_frames) return fail(LATTE_ERR_STATE, "vae_decode: n_frames exceeds max_frames");
+  if (out_mode != 0 && out_mode != 1) return fail(LATTE_ERR_INVALID, "vae_decode: out_mode must be 0 (fp32 NCHW) or 1 (uint8 NHWC)");
+  int rc = latte_vae_check_weights(v);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int N = n_frames, dt = v->dtype, top = v->ch[3];
+  int H = v->h, W = v->h;
+  if (!v->bias_folded) {
+    // softmax rows sum to 1, so  to_out(P (V0 + 1 bv^T)) = to_out(P V0) + (Wo bv + bo): the value bias is folded into
+    // the output bias and V^T is produced directly by a GEMM (no transpose kernel)
+    if ((rc = launch_small_linear(IN_PLAIN, v->av_b, nullptr, v->ao_w_f32, v->ao_b, nullptr, nullptr, v->ao_b_eff, 1, top, top, top, st))) return rc;
+    v->bias_folded = true;
+  }
+  half_t *a = v->buf[0], *b = v->buf[1], *c = v->buf[2], *d = v->buf[3];
+  int stage_no = 0, cur_c = top;
+  // stage numbering: 0 conv_in | 1 mid.resnet0 | 2 mid.attention | 3 mid.resnet1 | then per up block: 3 resnets (+ upsampler)
+  auto traced = [&](int& rc_out) -> bool {
+    if (stage_no++ != stop_after) return false;
+    const int64_t n = (int64_t)N * H * W * cur_c;
+    rc_out = launch_convert_h16_to_f32(a, trace_out, n, dt, st);
+    *trace_numel = n;
+    trace_dims[0] = N; trace_dims[1] = H; trace_dims[2] = W; trace_dims[3] = cur_c;
+    return true;
+  };
+  if ((rc = launch_post_quant(z, v->pq_w, v->pq_b, v->pq_out, N, H * W, z_scale, st))) return rc;
+  if ((rc = launch_conv_in(v->pq_out, v->ci_wt, v->ci_b, a, N, H, W, top, dt, st))) return rc;
+  if (traced(rc)) return rc;
+  if ((rc = run_resnet(v, v->mid[0], a, b, c, d, N, H, W, st))) return rc;
+  if (traced(rc)) return rc;
+  {  // mid-block attention: 1 head, dim 512, tokens = H*W per frame
+    const int L = H * W;
+    if (L % 128 != 0) return fail(LATTE_ERR_INVALID, "vae_decode: H*W must be a multiple of 128 for the attention GEMMs");
+    if ((rc = launch_groupnorm(a, c, v->agn_w, v->agn_b, v->gn_partial, v->gn_stats, N, L, top, 0, dt, st))) return rc;
+    if ((rc = gemm_h16(c, v->aq_w, v->aq_b, b, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // q  [N L, 512]
+    if ((rc = gemm_h16(c, v->ak_w, v->ak_b, d, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // k  [N L, 512]
+    half_t* vt = b + (size_t)N * L * top;   // V0^T per frame [512, L], behind q in buffer b
+    half_t* pm = d + (size_t)N * L * top;   // P per frame [L, L], behind k in buffer d
+    half_t* o = c + (size_t)N * L * top;    // attention output [N L, 512], behind the normed input in buffer c
+    const float scale = 1.0f / std::sqrt((float)top);
+    for (int f = 0; f < N; ++f) {
+      const half_t* hf = c + (size_t)f * L * top;
+      if ((rc = gemm_h16(v->av_w, hf, v->zero_bias, vt, nullptr, top, L, top, EPI_BIAS_H16, dt, st))) return rc;          // V0^T = Wv h^T
+      if ((rc = gemm_h16(b + (size_t)f * L * top, d + (size_t)f * L * top, v->zero_bias, v->scores, nullptr, L, L, top,
+                         EPI_BIAS_F32, dt, st))) return rc;                                                               // S = q k^T
+      if ((rc = launch_softmax_rows(v->scores, pm, L, L, scale, dt, st))) return rc;
+      if ((rc = gemm_h16(pm, vt, v->zero_bias, o + (size_t)f * L * top, nullptr, L, top, L, EPI_BIAS_H16, dt, st))) return rc;  // P V0
+    }
+    if ((rc = gemm_h16(o, v->ao_w, v->ao_b_eff, a, a, N * L, top, top, EPI_BIAS_RES_H16, dt, st))) return rc;   // to_out + residual
+  }
+  if (traced(rc)) return rc;
+  if ((rc = run_resnet(v, v->mid[1], a, b, c, d, N, H, W, st))) return rc;
+  if (traced(rc)) return rc;
+  for (int i = 0; i < 4; ++i) {
+    for (int r = 0; r < 3; ++r) {
+      if ((rc = run_resnet(v, v->up[i][r], a, b, c, d, N, H, W, st))) return rc;
+      cur_c = v->up[i][r].cout;
+      if (traced(rc)) return rc;
+    }
+    if (i < 3) {  // Upsample2D: nearest x2 folded into the conv's gather
+      const int cch = v->ch[3 - i];
+      if ((rc = launch_conv3x3(a, v->upc_w[i], v->upc_b[i], nullptr, b, v->zeros, N, H, W, cch, cch, 1, dt, st))) return rc;
+      std::swap(a, b);
+      H *= 2;
+      W *= 2;
+      if (traced(rc)) return rc;
+    }
+  }
+  if (stop_after >= 0) return fail(LATTE_ERR_INVALID, "vae_trace: stage index beyond the last traced stage");
+  if ((rc = launch_groupnorm(a, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
+  return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
+}
+
+}  // extern "C"

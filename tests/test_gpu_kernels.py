@@ -138,3 +138,19 @@ def test_fill_normal_moments(lib, dev):
     out2 = torch.empty(n, device=dev)
     check(lib.latte_debug_fill_normal(ptr(out2), n, 123, 0, stream_ptr()))
     assert torch.equal(out, out2)                      # counter-based: reproducible
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_gemm_bias_residual_half_epilogue(lib, dev, dt):
+    """epi 5 (VAE attention out-projection): out(half) = A W^T + bias + res(half), in place."""
+    M, N, K = 512, 512, 512
+    g = torch.Generator("cpu").manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev).to(TD[dt])
+    want = A.float() @ W.float().t() + bias + res.float()
+    out = res.clone()
+    check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(out), M, N, K, 0, M, 5, dt, 1, stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((out.float() - want).norm() / want.norm()) < OUT_TOL[dt]

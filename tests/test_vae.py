@@ -1,0 +1,162 @@
+"""SD-VAE decoder: oracle self-checks on CPU (parity with real diffusers is UNPINNED: oracle/vae_oracle.py),
+host-shim behaviour, and — on the GPU — every VAE kernel and the whole decode against the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import rel_l2
+from oracle import vae_oracle as vo
+
+TD = {0: torch.bfloat16, 1: torch.float16}
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_key_set_matches_diffusers_layout():
+    ks = vo.decoder_keys()
+    assert len(ks) == 140
+    assert ks["decoder.conv_in.weight"] == (512, 4, 3, 3)
+    assert ks["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"] == (256, 512, 1, 1)
+    assert ks["decoder.up_blocks.3.resnets.0.conv_shortcut.weight"] == (128, 256, 1, 1)
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in ks
+    assert ks["decoder.mid_block.attentions.0.to_out.0.weight"] == (512, 512)
+    assert sum(int(torch.tensor(s).prod()) for s in ks.values()) == 49_490_199   # decoder + post_quant parameters
+
+
+def test_oracle_shapes_and_determinism():
+    sd = vo.init_state_dict(seed=3)
+    z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    a, b = vo.decode(sd, z), vo.decode(sd, z)
+    assert a.shape == (1, 3, 64, 64) and torch.equal(a, b) and torch.isfinite(a).all()
+    u8 = vo.to_uint8_video(a)
+    assert u8.dtype == torch.uint8 and u8.shape == (1, 64, 64, 3)
+
+
+def test_engine_key_set_equals_oracle_key_set(lib):
+    import ctypes
+    h = ctypes.c_void_p()
+    # creating a VAE engine allocates device memory -> only the key enumeration of a failed create is host-only;
+    # compare against the binding's expectation instead: every oracle key must be a slot the loader asks for.
+    from latte_amd.vae import AutoencoderKL
+    vae = AutoencoderKL()
+    vae.load_state_dict({**vo.init_state_dict(0), "encoder.conv_in.weight": torch.zeros(1), "quant_conv.bias": torch.zeros(1)})
+    assert set(vae.state_dict()) == set(vo.decoder_keys())
+    legacy = {k.replace("to_q", "query").replace("to_k", "key").replace("to_v", "value").replace("to_out.0", "proj_attn"): v
+              for k, v in vo.init_state_dict(0).items()}
+    vae.load_state_dict(legacy)
+    assert set(vae.state_dict()) == set(vo.decoder_keys())
+    with pytest.raises(Exception):
+        vae.decode(torch.zeros(1, 4, 16, 16))            # no GPU / not moved to cuda: must raise, never fall back
+    with pytest.raises(Exception):
+        vae.encode(torch.zeros(1, 3, 128, 128))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0, False), (1, 16, 16, 128, 256, 1, False), (1, 8, 24, 256, 128, 0, True),
+                                  (3, 5, 7, 64, 128, 1, True)])
+def test_conv3x3_kernel(lib, dt, case):
+    from latte_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout, ups, use_res = case
+    g = torch.Generator("cpu").manual_seed(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(TD[dt])
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = H << ups, W << ups
+    res = torch.randn(N, Cout, Ho, Wo, generator=g).to(TD[dt]) if use_res else None
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xin, w.to(TD[dt]).float(), b, padding=1)
+    if use_res:
+        want = want + res.float()
+    dev = torch.device("cuda")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    out = torch.zeros(N, Ho, Wo, Cout, dtype=TD[dt], device=dev)
+    wd, bd = w.to(dev), b.to(dev)        # keep the device copies alive across the (asynchronous) call
+    check(lib.latte_debug_conv3x3(ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(out), N, H, W, Cin, Cout, ups, dt,
+                                  stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, want) < (6e-3 if dt == 0 else 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", [(2, 256, 128, 1), (1, 1024, 512, 1), (1, 4096, 256, 0), (3, 100, 128, 1)])
+def test_groupnorm_kernel(lib, dt, case):
+    from latte_amd._lib import check, ptr, stream_ptr
+    N, HW, C, silu = case
+    g = torch.Generator("cpu").manual_seed(HW + C)
+    x = (torch.randn(N, HW, C, generator=g) * 2 + 0.7).to(TD[dt])
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    want = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-6)
+    if silu:
+        want = F.silu(want)
+    dev = torch.device("cuda")
+    y = torch.zeros(N, HW, C, dtype=TD[dt], device=dev)
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    check(lib.latte_debug_groupnorm(ptr(xd), ptr(y), ptr(gd), ptr(bd), N, HW, C, silu, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(y.float().permute(0, 2, 1).cpu(), want) < (5e-3 if dt == 0 else 8e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd,tol", [("bf16", 3e-2), ("f16", 4e-3)])
+def test_vae_decode_vs_oracle(lib, cd, tol):
+    """Whole decoder on random weights, latent 16x16 -> 128x128, 2 frames (oracle: seconds on CPU)."""
+    from latte_amd.vae import AutoencoderKL
+    sd = vo.init_state_dict(seed=1)
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    want = vo.decode(sd, z)
+    vae = AutoencoderKL(latent_size=16, max_frames=2, compute_dtype=cd)
+    vae.load_state_dict(sd)
+    vae.to("cuda")
+    got = vae.decode(z.cuda()).sample
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    err = rel_l2(got, want)
+    print(f"vae decode [{cd}] rel-L2 vs oracle: {err:.3e}")
+    assert err < tol
+    # fused uint8 path = sample.py:122 applied to the fp32 result (one LSB of slack at rounding boundaries)
+    lat = (z * 0.18215).view(1, 2, 4, 16, 16).cuda()
+    u8 = vae.decode_video_uint8(lat)
+    same_path = vae._run(lat.view(2, 4, 16, 16), 1.0 / 0.18215, 0)          # identical arithmetic, fp32 out
+    ref8 = vo.to_uint8_video(same_path.cpu().clone())
+    assert torch.equal(u8.view(2, 128, 128, 3).cpu(), ref8)
+    # and against the oracle's own uint8 video: half-precision noise moves a few pixels by a few levels
+    d = (u8.view(2, 128, 128, 3).cpu().int() - vo.to_uint8_video(want.clone()).int()).abs()
+    print(f"uint8 video vs oracle: max level diff {int(d.max())}, mean {float(d.float().mean()):.3f}")
+    assert float(d.float().mean()) < (1.5 if cd == "bf16" else 0.3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd,tol", [("bf16", 2.5e-2), ("f16", 4e-3)])
+def test_vae_stagewise_vs_oracle(lib, cd, tol):
+    """Every traced decoder stage (conv_in, mid block, each up-block resnet / upsampler) against the oracle."""
+    import ctypes
+    from latte_amd._lib import check, ptr, stream_ptr
+    from latte_amd.vae import AutoencoderKL
+    sd = vo.init_state_dict(seed=2)
+    z = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(9))
+    trace = []
+    vo.decode(sd, z, trace=trace)
+    assert len(trace) == 19
+    vae = AutoencoderKL(latent_size=16, max_frames=1, compute_dtype=cd)
+    vae.load_state_dict(sd)
+    vae.to("cuda")
+    zd = z.cuda()
+    eng = vae._engine(1, 16)
+    buf = torch.empty(1 * 128 * 128 * 256, device="cuda")
+    numel, dims = ctypes.c_int64(), (ctypes.c_int * 4)()
+    errs = []
+    for k, want in enumerate(trace):
+        check(lib.latte_debug_vae_trace(eng, ptr(zd), 1, 1.0, k, ptr(buf), ctypes.byref(numel), dims, stream_ptr()))
+        torch.cuda.synchronize()
+        n, h, w, c = list(dims)
+        got = buf[:numel.value].view(n, h, w, c).permute(0, 3, 1, 2).cpu()
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        errs.append(rel_l2(got, want))
+    print(f"vae stages [{cd}] rel-L2:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) < tol, errs
