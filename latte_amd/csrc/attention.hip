@@ -17,6 +17,8 @@
 //               k-slot order) so the V^T fragment is one ds_read_b128.
 //  attn_small : L <= 16 (temporal attention over frames); one wave per (sequence, head), Q/K
 //               fragments straight from global memory, V through a wave-private LDS patch.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace latte {
@@ -197,6 +199,227 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_full : 128 < L <= 256 (the spatial attention of every 256-pixel Latte config: T = 256 tokens per frame).
+// One workgroup per (sequence, head); ALL keys and values of that head are staged once, row-major, in LDS
+// (2 x 40 KB: two workgroups per CU), so there is no key-tile loop, no barrier after the staging and no online
+// rescale: a wave computes the complete S^T for 32 of its 64 queries (2 x 16 MFMA column groups sharing every K
+// fragment read), takes an exact softmax over the 256 scores it holds in registers, and feeds P straight into
+// the PV MFMAs.  V^T fragments come from the row-major V image through ds_read_b64_tr_b16 (the hardware
+// transpose read: lane i of a 16-lane group supplies the address of 4 d-values of key (i >> 2) and receives the
+// 4 keys of d-column i), so V is never transposed in memory.
+// Row pitch 160 B (10 chunks) for both images: conflict-free for the b128 K reads (row 10r + chunk distinct mod 16
+// inside every 16-lane service group) and for the tr reads (8 rows x 32 B tile the 64 banks).
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short i16v4;
+template <int DT>
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {   // 16-bit elements: the bit pattern is dtype-agnostic
+  i16v4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16v4*)p);
+  return __builtin_bit_cast(u32x2, v);
+}
+
+template <int HD, int DT>
+__global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int DF = (HD + 15) / 16;
+  constexpr int NCH = HD / 8;
+  constexpr int RP = 160;            // row pitch of the K and V images (bytes)
+  constexpr int NKT = 16;            // 16-key tiles
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  char* const k_lds = smem_attn;
+  char* const v_lds = smem_attn + 256 * RP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fl = lane & 15, g = lane >> 4;
+  // Block -> (sequence, head): blocks are dispatched round-robin over the 8 XCDs, and the 16 head slices of one
+  // token row share 128-byte lines (144 B per head at hd = 72), so all heads of a sequence are kept on ONE XCD
+  // (blocks b, b + 8, b + 16, ... walk the heads): the straddling lines are fetched from HBM once, not per XCD.
+  int head, seq;
+  if ((a.num_seq & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    head = slot % a.heads;
+    seq = (slot / a.heads) * 8 + xcd;
+  } else {
+    head = blockIdx.x % a.heads;
+    seq = blockIdx.x / a.heads;
+  }
+  const int64_t base = seq_base_row(a, seq);
+  const size_t ld = (size_t)3 * a.D;
+  const half_t* qkv_h = a.qkv + (size_t)head * HD;
+
+  // ---- stage K and V by LDS DMA: 2 x 2560 16-byte chunks, 20 back-to-back instructions per wave, ONE wait.
+  // The image is lane-linear (chunk index = 64 * instruction + lane -> row = idx / 10, chunk = idx % 10), the source
+  // address is per lane.  Pad chunk 9 (d 72..79 at hd = 72; chunks 8, 9 at hd = 64) and rows >= L re-read a valid
+  // chunk: they only ever meet a zero Q chunk, an unused O row or P = 0, and the data is finite.
+  if (a.variant != 3) {   // (variant 2 / 3: measurement ablations -- staging only / compute only)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int inst = wave_u * 10 + j;                 // 40 instructions per image, 10 per wave
+      const int idx = inst * 64 + lane;                 // chunk index 0..2559
+      const int key = idx / 10, ch = idx - key * 10;
+      const int key_ld = min(key, a.L - 1), ch_ld = min(ch, NCH - 1);
+      const half_t* rowp = qkv_h + (size_t)(base + (int64_t)key_ld * a.row_stride) * ld + ch_ld * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + a.D),
+                                       (__attribute__((address_space(3))) void*)(k_lds + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + 2 * a.D),
+                                       (__attribute__((address_space(3))) void*)(v_lds + inst * 1024), 16, 0, 0);
+    }
+  }
+  // Q fragments of the two 16-query groups of a pass (B operand of S^T = K Q^T): lane = (query fl, chunk g + 4 ks).
+  // Pass 0's are fetched under the staging DMA, pass 1's under pass 0's softmax / PV phase.
+  u32x4 qf[2][KS];
+  auto load_q = [&](int pass_, u32x4 (&dst)[2][KS]) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const int q_ld = min(wave * 64 + pass_ * 32 + gq * 16 + fl, a.L - 1);
+      const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ch = g + 4 * ks;
+        dst[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
+        if (ch < NCH) dst[gq][ks] = *(const u32x4*)(qrow + ch * 8);
+      }
+    }
+  };
+  load_q(0, qf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (a.variant == 2) {
+    if (tid == 0) a.out[(size_t)base * a.D + head * HD] = *(const half_t*)(k_lds + 2 * (seq & 63));
+    return;
+  }
+
+  const float c = a.scale * 1.4426950408889634f;  // softmax in the exp2 domain
+  const char* kbase = k_lds + fl * RP + g * 16;
+  // tr-read address of this lane: key row (fl >> 2) of a 4-key block, d-bytes (fl & 3) * 8 of a 16-d block
+  const char* vbase = v_lds + (4 * g + (fl >> 2)) * RP + (fl & 3) * 8;
+
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int q0 = wave * 64 + pass * 32;
+    if (q0 >= a.L) break;
+    // S^T[key][q] for all 256 keys x 2 x 16 queries.  K fragments are software-pipelined two key tiles ahead
+    // through four rotating register sets; sched_barrier pins the order (the compiler's own schedule waited
+    // lgkmcnt(0) after every few MFMAs and exposed the LDS latency).
+    f32x4 st[2][NKT];
+    u32x4 kf[4][KS];
+    auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        // chunks >= NCH (pad chunk 9, and 10 / 11 = the next row's first chunks) hold finite data and only ever
+        // multiply the zero Q chunks: no select here, it would force a wait on the load just issued
+        dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+      }
+    };
+    load_k(0, kf[0]);
+    load_k(1, kf[1]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st[0][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[0][ks], st[0][kt]);
+        st[1][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[1][ks], st[1][kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    u32x4 qn[2][KS];
+    if (pass == 0) load_q(1, qn);
+    // exact softmax over the key axis: in-lane over 64 values, then the 4 lanes g = 0..3 of a query.
+    // max on the raw scores (c > 0), p = exp2(s * c - max * c): one max, one fma, one exp2, one add per element
+    float inv[2];
+    const bool ragged = a.L < 256;
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * kt + 4 * g + r >= a.L) st[gq][kt][r] = NEG_BIG;
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float nm = -mx * c;
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[gq][kt][r], c, nm));
+          st[gq][kt][r] = p;
+          ls += p;
+        }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      inv[gq] = 1.0f / ls;
+    }
+    // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
+    f32x4 o[2][DF];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+      for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 vfr[2][DF];   // V^T fragments, one 32-key step ahead
+    auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const u32x2 lo = lds_tr16<DT>(vbase + (32 * ks2) * RP + d * 32);
+        const u32x2 hi = lds_tr16<DT>(vbase + (32 * ks2 + 16) * RP + d * 32);
+        dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+    };
+    load_v(0, vfr[0]);
+#pragma unroll
+    for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+      if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
+      u32x4 pb[2];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+        pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        o[0][d] = mfma_k32<DT>(vfr[ks2 & 1][d], pb[0], o[0][d]);
+        o[1][d] = mfma_k32<DT>(vfr[ks2 & 1][d], pb[1], o[1][d]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      const int q_idx = q0 + gq * 16 + fl;
+      if (q_idx < a.L) {
+        half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          const int dd = 16 * d + 4 * g;
+          if (dd < HD) {
+            u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
+                        pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
+            *(u32x2*)(orow + dd) = pk;
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[gq][ks] = qn[gq][ks];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int HD, int DT>
 __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
@@ -273,18 +496,32 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
 
 }  // namespace
 
-int launch_attention(const AttnArgs& a, int dtype, hipStream_t st) {
-  if (a.hd != 64 && a.hd != 72) return fail(LATTE_ERR_INVALID, "attention: head_dim must be 64 or 72");
-  if (a.L <= 0) return fail(LATTE_ERR_INVALID, "attention: empty sequence");
-  const bool small = a.L <= 16;
+int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
+  const AttnArgs& a0 = a_in;
+  if (a0.hd != 64 && a0.hd != 72) return fail(LATTE_ERR_INVALID, "attention: head_dim must be 64 or 72");
+  if (a0.L <= 0) return fail(LATTE_ERR_INVALID, "attention: empty sequence");
+  const bool small = a0.L <= 16;
+  AttnArgs a = a_in;
+  if (const char* ab = getenv("LATTE_ATTN_ABLATE")) a.variant = atoi(ab);   // measurement only (tools/attn_pmc.py)
+  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1;   // variant 1 forces the generic flash kernel (tests)
+  constexpr int FULL_LDS = 2 * 256 * 160;
   dim3 block(256);
-  dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64));
-#define ATTN_LAUNCH(HD, DT)                                                       \
-  do {                                                                            \
-    if (small)                                                                    \
-      hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);     \
-    else                                                                          \
-      hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);     \
+  dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4)
+                    : (full ? dim3(a.num_seq * a.heads) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64)));
+#define ATTN_LAUNCH(HD, DT)                                                                                   \
+  do {                                                                                                        \
+    if (small)                                                                                                \
+      hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);                                 \
+    else if (full) {                                                                                          \
+      static bool attr_done = false;                                                                          \
+      if (!attr_done) {                                                                                       \
+        LATTE_HIP(hipFuncSetAttribute((const void*)attn_full_kernel<HD, DT>,                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, FULL_LDS));                 \
+        attr_done = true;                                                                                     \
+      }                                                                                                       \
+      hipLaunchKernelGGL((attn_full_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                           \
+    } else                                                                                                    \
+      hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);                                 \
   } while (0)
   if (dtype == LATTE_DTYPE_BF16) {
     if (a.hd == 64) ATTN_LAUNCH(64, LATTE_DTYPE_BF16); else ATTN_LAUNCH(72, LATTE_DTYPE_BF16);

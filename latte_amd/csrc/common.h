@@ -71,6 +71,7 @@ struct AttnArgs {
   int64_t seq_stride;     // row offset between consecutive sequences of a sample (T spatial, 1 temporal)
   int64_t row_stride;     // row offset between consecutive tokens of a sequence (1 spatial, T temporal)
   float scale;            // hd^-0.5
+  int variant;            // 0 = pick by L; 1 = force the generic flash kernel for L > 16 (test hook)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t st);
 

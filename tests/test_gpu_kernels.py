@@ -61,7 +61,7 @@ def test_gemm_epilogues(lib, dev, dt, variant, shape):
 
 
 CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),
-         (2, 4, 4, 2, 64)]
+         (2, 4, 4, 2, 64), (1, 2, 200, 2, 72), (1, 3, 144, 3, 64), (2, 2, 256, 4, 64), (1, 2, 129, 1, 72)]
 
 
 @pytest.mark.parametrize("dt", [0, 1])
