@@ -4,10 +4,12 @@
 
 One "step" = one pass of the hot path (denoiser forward + sampler update) over the rank's batch of
 latents, inputs resident in HBM.  Workload = BASELINE.json configs[1]: Latte-XL/2, FaceForensics
-(unconditional) config, 16 frames of 32x32 latents, per-GPU batch = the YAML's per_proc_batch_size (2),
-DDIM eta=0 over the "250" respacing, random-init weights (adaLN/final layers re-drawn N(0, 0.02) so
-the network is not the identity), synthetic N(0,1) latents.  Weak scaling: every rank runs its own
-samples, no data-path collective (the reference's sample_ddp.py has none either).
+(unconditional) config, 16 frames of 32x32 latents, per-GPU batch 8 (= BASELINE config 3's per-GPU share
+of its batch 64; `--batch 2` is the reference YAML's per_proc_batch_size), DDIM eta=0 over the "250"
+respacing, random-init weights (adaLN/final layers re-drawn N(0, 0.02) so the network is not the
+identity), synthetic N(0,1) latents.  Weak scaling: every rank runs its own samples, no data-path
+collective (the reference's sample_ddp.py has none either); the only payload collective is the one-off
+RCCL broadcast of the timestep-embedding table before the timed region.
 `value` = aggregate denoising sample-steps/s = n_gpus * batch * K / max-over-ranks time.
 """
 import argparse
@@ -31,7 +33,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=250)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=2, help="samples per GPU (ffs_sample.yaml per_proc_batch_size)")
+    p.add_argument("--batch", type=int, default=8, help="samples per GPU (8 = config 3's share; 2 = ffs_sample.yaml)")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--method", default="ddim", choices=["ddim", "ddpm"])
     p.add_argument("--gemm-variant", type=int, default=0)
@@ -90,6 +92,18 @@ def cpu_baseline(n_forwards):
                       "the sampler update is negligible on CPU (<0.1%)"}
 
 
+def pmc_traffic(kernel_class, M):
+    """HBM bytes per launch of the dominant GEMM from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE); None when that shape was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        tab = json.load(f)
+    rec = tab.get(f"{kernel_class}:M={M}")
+    return rec["hbm_bytes_per_launch"] if rec else None
+
+
 def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -118,6 +132,10 @@ def main():
         model.set_engine_option("gemm_variant", args.gemm_variant, args.batch)
     diffusion = latte_amd.create_diffusion("250")
     B = args.batch
+    if dist is not None:
+        # rank 0's timestep-embedding table [250, 1152] fp32 to every rank over RCCL/xGMI (outside the timed region)
+        from latte_amd import parallel
+        parallel.broadcast_temb_table(model, diffusion, batch=B)
     g = torch.Generator("cpu").manual_seed(1000 + rank)
     x = torch.randn(B, 16, 4, 32, 32, generator=g).to(device)
 
@@ -168,7 +186,7 @@ def main():
             "finite": finite,
             "roofline": {"bound": "mfma", "kernel": f"gemm_kernel ({dom}: M={M})", "achieved": round(achieved, 1),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "avg_launch_ms": round(avg_ms, 4)},
+                         "traffic": pmc_traffic(dom, M), "avg_launch_ms": round(avg_ms, 4)},
             "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
             "forward_ms_eager_events": round(total_ms, 4),
         }

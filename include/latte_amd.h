@@ -95,6 +95,15 @@ int latte_engine_check_weights(latte_engine_t* e);
 int latte_engine_num_keys(const latte_engine_t* e);
 const char* latte_engine_key(const latte_engine_t* e, int i);
 
+/* Timestep-embedding table of a schedule: out[i, :] = t_embedder(timestep_map[i]) for every respaced step i
+ * (TimestepEmbedder, latte.py:84-123, through respace.py:125-130) -- [num_timesteps, hidden] fp32, device.  It depends on
+ * nothing but the schedule and the weights, so the multi-GPU driver lets rank 0 compute it and broadcasts it over RCCL
+ * (250 x 1152 x 4 B = 1.15 MB, the only payload collective of the sampling path); latte_engine_set_temb_table installs
+ * a received table (copied), which latte_sample_loop then uses for every schedule with that number of steps.
+ * table == NULL uninstalls. */
+int latte_engine_temb_table(latte_engine_t* e, const latte_schedule_t* s, float* out, void* stream);
+int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_timesteps, void* stream);
+
 /* Latte.forward (latte.py:314-377).  x:[B,F,C,H,W] fp32, t: int64[B] ORIGINAL timesteps (device),
  * y: int64[B] labels (device) or NULL when extras == 1, out:[B,F,Cout,H,W] fp32. */
 int latte_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,

@@ -91,6 +91,8 @@ int launch_patch_embed(const float* x, const float* Wt /* [C*p*p][D] */, const f
 int launch_final_layer(const float* x, const float* shift, const float* scale, int mod_stride,
                        const float* Wt /* [D][P] */, const float* bias, float* out, int M, int D,
                        int rows_per_sample, int T, int p, int Cout, int H, hipStream_t st);
+int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, float* out, int n_steps, int bu, int D,
+                     hipStream_t st);
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
 int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);

@@ -9,6 +9,7 @@
 //   GEMM operands    xn    half [rows, D], qkv half [rows, 3D], h half [rows, mlp]
 //   conditioning     mod   fp32 [B, depth*6D + 2D]  (all adaLN outputs of one forward, computed once per
 //                    SAMPLE; the reference recomputes them on F or T repeated rows, latte.py:333-339)
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -66,6 +67,11 @@ struct latte_engine {
   half_t *xn = nullptr, *qkv = nullptr, *hbuf = nullptr;
   int64_t* tmap_dev = nullptr;
   int64_t tmap_cap = 0;
+  // conditioning of a whole chain (latte_sample_loop): timestep-embedding table (own or installed after the RCCL
+  // broadcast), per-(step, sample) conditioning rows and all adaLN outputs
+  float *temb_table = nullptr, *temb_own = nullptr, *temb_work = nullptr, *cond_rows = nullptr, *mod_all = nullptr;
+  int temb_table_n = 0;        // > 0: an installed table of that many respaced steps
+  int64_t temb_table_cap = 0, temb_own_cap = 0, temb_cap = 0, cond_cap = 0, mod_all_cap = 0;
   int64_t stage_numel = 0;
   std::vector<TensorSlot> slots;
   std::map<std::string, int> slot_index;
@@ -113,11 +119,13 @@ struct Timer {  // optional per-launch HIP events (latte_profile_forward)
 };
 enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATCH, C_FINAL, C_NONE = -1 };
 
+// mod_override != nullptr: the adaLN outputs of this step were precomputed ([B or 1 rows, nmod], row stride mod_stride;
+// stride 0 = one row shared by every sample) and the conditioning launches are skipped.
 int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t* y, int B, bool cfg_dup, float* out,
-                hipStream_t st, Prof* prof) {
+                hipStream_t st, Prof* prof, const float* mod_override = nullptr, int mod_stride_override = 0) {
   const auto& c = e->cfg;
   if (B <= 0 || B > e->max_batch) return fail(LATTE_ERR_STATE, "forward: batch exceeds max_batch of the engine");
-  if (c.extras == 2 && y == nullptr) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
+  if (c.extras == 2 && y == nullptr && !mod_override) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
   if (cfg_dup && (B % 2)) return fail(LATTE_ERR_INVALID, "forward_with_cfg: batch must be even");
   const int D = e->D, T = e->T, F = e->F, dt = c.compute_dtype;
   const int M = B * F * T;
@@ -126,11 +134,18 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   int rc;
   tm.mark(C_NONE);
   // --- conditioning: t_emb = MLP(sincos(t)) (latte.py:119-123); c = t_emb (+ y_emb) (:337,:348); all adaLN at once
-  if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t0_w, e->t0_b, nullptr, nullptr, e->temb0, B, D, 256, D, st))) return rc;
-  if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, c.extras == 2 ? e->ytab : nullptr, y,
-                                e->cvec, B, D, D, D, st))) return rc;
-  if ((rc = launch_small_linear(IN_SILU, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
-                                e->nmod, st))) return rc;
+  const float* modp = e->mod;
+  int mstride = e->nmod;
+  if (mod_override) {
+    modp = mod_override;
+    mstride = mod_stride_override;
+  } else {
+    if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t0_w, e->t0_b, nullptr, nullptr, e->temb0, B, D, 256, D, st))) return rc;
+    if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, c.extras == 2 ? e->ytab : nullptr, y,
+                                  e->cvec, B, D, D, D, st))) return rc;
+    if ((rc = launch_small_linear(IN_SILU, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
+                                  e->nmod, st))) return rc;
+  }
   tm.mark(C_COND);
   // --- patch embed + pos_embed (latte.py:330-331)
   if (cfg_dup) {
@@ -146,13 +161,13 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   for (int i = 0; i < c.depth; ++i) {
     const bool spatial = (i % 2) == 0;  // latte.py:345-346
     const BlockW& w = e->blocks[i];
-    const float* mb = e->mod + (size_t)i * 6 * D;  // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    const float* mb = modp + (size_t)i * 6 * D;  // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     // x + temp_embed once, after the first spatial block (latte.py:357-358)
     const float* te = (i == 1) ? e->temp : nullptr;
-    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, e->nmod, M, D, rps, te, T, F, dt, st))) return rc;
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
     tm.mark(C_LN);
     GemmArgs g{};
-    g.M = M; g.rows_per_sample = rps; g.gate_stride = e->nmod;
+    g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
     g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
     if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant, st))) return rc;
     tm.mark(C_QKV);
@@ -166,7 +181,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
-    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, e->nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
     tm.mark(C_LN);
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant, st))) return rc;
@@ -176,8 +191,8 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     tm.mark(C_FC2);
   }
   // --- final layer (latte.py:197-201) + unpatchify (:297-310)
-  const float* fm = e->mod + (size_t)c.depth * 6 * D;  // chunk(2): shift, scale
-  if ((rc = launch_final_layer(e->xres, fm, fm + D, e->nmod, e->fin_wt, e->fin_b, out, M, D, rps, T, c.patch_size,
+  const float* fm = modp + (size_t)c.depth * 6 * D;  // chunk(2): shift, scale
+  if ((rc = launch_final_layer(e->xres, fm, fm + D, mstride, e->fin_wt, e->fin_b, out, M, D, rps, T, c.patch_size,
                                e->Cout, e->H, st))) return rc;
   tm.mark(C_FINAL);
   return LATTE_OK;
@@ -185,6 +200,42 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
 
 // fp32 emulation of the reference's per-step tensor arithmetic (gaussian_diffusion.py:869-881: fp64 table ->
 // .float()); compiled with -ffp-contract=off.
+int grow(latte_engine* e, float** p, int64_t* cap, int64_t need) {
+  if (*cap >= need) return LATTE_OK;
+  if (*p) {   // release the smaller block (setup path: the implicit device synchronisation of hipFree is fine here)
+    e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void*)*p), e->allocs.end());
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+  }
+  int rc = dev_alloc(e, p, (size_t)need, false);
+  if (!rc) *cap = need;
+  return rc;
+}
+
+// Timestep-embedding table of a schedule: row i = t_embedder(timestep_map[i]) (latte.py:84-123, respace.py:125-130).
+// This is the [steps, D] fp32 table rank 0 broadcasts over RCCL in the multi-GPU driver (1.15 MB for 250 x 1152).
+int compute_temb_table(latte_engine* e, const latte_schedule_t* s, float* out, hipStream_t st) {
+  const int n = s->num_timesteps, D = e->D;
+  int rc;
+  if (e->tmap_cap < n) {
+    if ((rc = dev_alloc(e, &e->tmap_dev, (size_t)n, false))) return rc;
+    e->tmap_cap = n;
+  }
+  LATTE_HIP(hipMemcpyAsync(e->tmap_dev, s->timestep_map.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+  LATTE_HIP(hipStreamSynchronize(st));   // the host vector may be freed by the caller
+  if ((rc = grow(e, &e->temb_work, &e->temb_cap, (int64_t)n * D))) return rc;
+  constexpr int CH = 64;   // rows per launch: the kernel keeps a weight row in registers and loops over the rows
+  for (int r0 = 0; r0 < n; r0 += CH) {
+    const int rows = std::min(CH, n - r0);
+    if ((rc = launch_small_linear(IN_TFREQ, nullptr, e->tmap_dev + r0, e->t0_w, e->t0_b, nullptr, nullptr,
+                                  e->temb_work + (size_t)r0 * D, rows, D, 256, D, st))) return rc;
+    if ((rc = launch_small_linear(IN_SILU, e->temb_work + (size_t)r0 * D, nullptr, e->t2_w, e->t2_b, nullptr, nullptr,
+                                  out + (size_t)r0 * D, rows, D, D, D, st))) return rc;
+  }
+  return LATTE_OK;
+}
+
 SamplerCoefs make_coefs(const latte_schedule_t* s, int method, int i, float eta, int clip) {
   SamplerCoefs c{};
   c.method = method;
@@ -385,6 +436,27 @@ int latte_engine_check_weights(latte_engine_t* e) {
   return LATTE_OK;
 }
 
+int latte_engine_temb_table(latte_engine_t* e, const latte_schedule_t* s, float* out, void* stream) {
+  if (!e || !s || !out) return fail(LATTE_ERR_INVALID, "temb_table: null argument");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  return compute_temb_table(e, s, out, (hipStream_t)stream);
+}
+
+int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_timesteps, void* stream) {
+  if (!e) return fail(LATTE_ERR_INVALID, "set_temb_table: null engine");
+  if (!table || num_timesteps <= 0) {   // uninstall: the engine computes its own table again
+    e->temb_table_n = 0;
+    return LATTE_OK;
+  }
+  int rc = grow(e, &e->temb_table, &e->temb_table_cap, (int64_t)num_timesteps * e->D);
+  if (rc) return rc;
+  LATTE_HIP(hipMemcpyAsync(e->temb_table, table, sizeof(float) * (size_t)num_timesteps * e->D, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  e->temb_table_n = num_timesteps;
+  return LATTE_OK;
+}
+
 int latte_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
                   void* stream) {
   if (!e || !x || !t || !out) return fail(LATTE_ERR_INVALID, "forward: null argument");
@@ -430,25 +502,39 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   const bool use_cfg = cfg_scale > 1.0f;  // sample.py:51
   if (use_cfg && (batch % 2)) return fail(LATTE_ERR_INVALID, "sample_loop: guidance needs the doubled batch");
   hipStream_t st = (hipStream_t)stream;
-  // device copy of respace.py:126-127's map_tensor[ts], one row of `batch` entries per respaced index
-  const int64_t need = (int64_t)n * e->max_batch;
-  if (e->tmap_cap < need) {
-    rc = dev_alloc(e, &e->tmap_dev, (size_t)need, false);
-    if (rc) return rc;
-    e->tmap_cap = need;
+  // ---- conditioning of the whole chain, once: it depends on (timestep, label) only, never on x.
+  //   temb[i]      = t_embedder(timestep_map[i])           (own, or the table installed after the RCCL broadcast)
+  //   c[i, b]      = temb[i] (+ y_embedder(y[b]))           latte.py:337,348
+  //   mod[i, b, :] = all 28 adaLN_modulation + the final layer's, = Linear(SiLU(c))   latte.py:172-178,192-198
+  // Unconditional models have one row per step shared by every sample (row stride 0).  The adaLN weights (0.9 GB
+  // fp32) are then streamed once per 64 rows instead of once per denoising step.
+  const int D = e->D;
+  const int n_run = start_index - end_index + 1;
+  const int bu = e->cfg.extras == 2 ? batch : 1;
+  if (e->cfg.extras == 2 && y == nullptr) return fail(LATTE_ERR_INVALID, "sample_loop: class-conditional model needs y");
+  const float* temb = nullptr;
+  if (e->temb_table_n == n) {
+    temb = e->temb_table;
+  } else {
+    if ((rc = grow(e, &e->temb_own, &e->temb_own_cap, (int64_t)n * D))) return rc;
+    if ((rc = compute_temb_table(e, s, e->temb_own, st))) return rc;
+    temb = e->temb_own;
   }
-  {
-    std::vector<int64_t> host((size_t)need);
-    for (int i = 0; i < n; ++i)
-      for (int b = 0; b < e->max_batch; ++b) host[(size_t)i * e->max_batch + b] = s->timestep_map[i];
-    LATTE_HIP(hipMemcpyAsync(e->tmap_dev, host.data(), sizeof(int64_t) * need, hipMemcpyHostToDevice, st));
-    LATTE_HIP(hipStreamSynchronize(st));
+  const int64_t rows_all = (int64_t)n_run * bu;
+  if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_all * D))) return rc;
+  if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_all * e->nmod))) return rc;
+  // rows are ordered by respaced index ascending: row (i - end_index) * bu + b
+  if ((rc = launch_cond_rows(temb + (size_t)end_index * D, e->cfg.extras == 2 ? e->ytab : nullptr, y, e->cond_rows, n_run, bu, D, st))) return rc;
+  for (int64_t r0 = 0; r0 < rows_all; r0 += 64) {
+    const int rows = (int)std::min<int64_t>(64, rows_all - r0);
+    if ((rc = launch_small_linear(IN_SILU, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
+                                  e->mod_all + (size_t)r0 * e->nmod, rows, e->nmod, D, e->nmod, st))) return rc;
   }
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
   int k = 0;
   for (int i = start_index; i >= end_index; --i, ++k) {
-    const int64_t* t = e->tmap_dev + (size_t)i * e->max_batch;
-    if ((rc = run_forward(e, x, t, y, batch, use_cfg, e->model_out, st, nullptr))) return rc;
+    const float* mod_i = e->mod_all + (size_t)(i - end_index) * bu * e->nmod;
+    if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod))) return rc;
     SamplerCoefs c = make_coefs(s, method, i, eta, clip_denoised);
     c.cfg_scale = cfg_scale;
     const bool need_noise = (method == LATTE_METHOD_DDPM) ? (i != 0) : (c.sigma != 0.0f && i != 0);

@@ -260,6 +260,20 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// c[(i, b), :] = temb[i, :] (+ ytab[y[b], :]): the conditioning vector of step i, sample b (latte.py:337,348)
+__global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __restrict__ ytab, const int64_t* __restrict__ y,
+                                 float* __restrict__ out, int n_steps, int bu, int D) {
+  const size_t total = (size_t)n_steps * bu * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const size_t r = i / D;
+    const int b = (int)(r % bu), step = (int)(r / bu);
+    float v = temb[(size_t)step * D + d];
+    if (ytab != nullptr) v += ytab[(size_t)y[b] * D + d];
+    out[i] = v;
+  }
+}
+
 __global__ void cfg_combine_kernel(float* out, int half_batch, int F, int Cout, int HW, float s) {
   // eps channels are [0, 4) (hard-coded 4 in the reference, latte.py:394)
   const size_t per_sample = (size_t)F * 4 * HW;
@@ -478,6 +492,14 @@ int launch_final_layer(const float* x, const float* shift, const float* scale, i
                      rows_per_sample, T, p, Cout, H)
   LATTE_NCH_SWITCH(D, FL_LAUNCH)
 #undef FL_LAUNCH
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, float* out, int n_steps, int bu, int D,
+                     hipStream_t st) {
+  const size_t n = (size_t)n_steps * bu * D;
+  hipLaunchKernelGGL(cond_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, temb, ytab, y, out, n_steps, bu, D);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -189,3 +189,33 @@ def test_engine_errors_are_loud():
     sd.pop("blocks.3.mlp.fc2.bias")
     with pytest.raises(RuntimeError):
         m.load_state_dict(sd)                     # strict key check (sample.py:64)
+
+
+def test_temb_table_and_chain_conditioning(lib):
+    """latte_engine_temb_table == the per-step t_embedder path, and a loop run from an INSTALLED table (the RCCL
+    broadcast payload) is bit-identical to a loop that computes its own."""
+    import latte_amd
+    from latte_amd._lib import check, ptr, stream_ptr
+    kw, sd, r = load_golden_model("tiny_classcond")
+    x, y = torch.from_numpy(r["x"]).cuda(), torch.from_numpy(r["y"]).cuda()
+    m = engine_model(kw, sd, "bf16")
+    d = latte_amd.create_diffusion("10")
+    eng = m.engine(x.shape[0])
+    table = torch.zeros(d.num_timesteps, m.hidden_size, device="cuda")
+    check(lib.latte_engine_temb_table(eng, d._h, ptr(table), stream_ptr()))
+    torch.cuda.synchronize()
+    from oracle import latte_oracle as lo
+    import torch.nn.functional as F
+    tf = lo.timestep_embedding(torch.tensor(d.timestep_map), 256)                       # latte.py:97-117
+    want = F.linear(F.silu(F.linear(tf, sd["t_embedder.mlp.0.weight"], sd["t_embedder.mlp.0.bias"])),
+                    sd["t_embedder.mlp.2.weight"], sd["t_embedder.mlp.2.bias"])          # latte.py:90-94
+    assert rel_l2(table, want) < 1e-5
+    a = d.ddim_sample_loop(m.forward, x.shape, x.clone(), clip_denoised=False, model_kwargs=dict(y=y))
+    check(lib.latte_engine_set_temb_table(eng, ptr(table), d.num_timesteps, stream_ptr()))
+    b = d.ddim_sample_loop(m.forward, x.shape, x.clone(), clip_denoised=False, model_kwargs=dict(y=y))
+    check(lib.latte_engine_set_temb_table(eng, None, 0, stream_ptr()))
+    assert torch.equal(a, b)
+    # and the fused loop (precomputed conditioning) equals stepping the model callable by hand
+    c = d.ddim_sample_loop(lambda xx, tt, **k: m.forward(xx, tt, **k), x.shape, x.clone(), clip_denoised=False,
+                           model_kwargs=dict(y=y), device="cuda")
+    assert rel_l2(a, c) < 1e-6
