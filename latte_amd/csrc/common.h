@@ -50,6 +50,7 @@ struct GemmArgs {
   int M, N, K;        // M = valid rows; grid covers ceil(M / BM) tiles
   int gate_stride;
   int rows_per_sample;
+  int stagger;        // persistent kernel: number of start cohorts (0/1 = none); cohort c sleeps c/stagger of a tile time
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,

@@ -584,6 +584,8 @@ int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, c
 }
 
 int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int iters, float* ms_per_launch, void* stream) {
+  int stagger = 0;
+  if (variant >= 100) { stagger = variant / 100; variant %= 100; }   // measurement: variant + 100 * cohorts
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(LATTE_ERR_INVALID, "bench_gemm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int64_t Mp = ((int64_t)M + 255) / 256 * 256;
@@ -609,7 +611,7 @@ int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int i
   if (!rc) rc = launch_fill_normal(gate, (size_t)N, 8, 0, st);
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate; g.M = M; g.N = N; g.K = K;
-  g.gate_stride = 0; g.rows_per_sample = M;
+  g.gate_stride = 0; g.rows_per_sample = M; g.stagger = stagger;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);

@@ -375,6 +375,15 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int cnt = q + (xcd < r ? 1 : 0);
   if (slot >= cnt) return;
+  if (g.stagger > 1) {
+    // De-synchronise the CUs: all workgroups otherwise reach their epilogue together and the store bursts (32 MB per
+    // round) cost their full HBM time because an in-order vmcnt cannot confirm later DMA past them.  Cohort c of the
+    // workgroups of an XCD starts c / stagger of a tile time late (only used when a workgroup walks many tiles).
+    const int cohort = slot % g.stagger;
+    const long long wait = (long long)cohort * (K / 64) * 2200 / g.stagger;   // ~2200 cycles per K tile (two segments)
+    const long long t0 = __builtin_readcyclecounter();
+    while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   auto decode = [&](int wg, int& tm, int& tn) {
     const int per_group = GROUP_M * tiles_n;
     const int group = wg / per_group;
@@ -705,8 +714,17 @@ int gemm_auto_variant(int M, int N) {
   return best;
 }
 
-int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st) {
-  if (variant == 0) variant = gemm_auto_variant(a.M, a.N);
+int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
+  GemmArgs a = a_in;
+  if (variant == 0) {
+    variant = gemm_auto_variant(a.M, a.N);
+    // start cohorts (gemm_pps_kernel): measured +7 % on the GELU epilogue shape when a workgroup walks >= 8 tiles
+    // (M = 32768: 355 -> 332 us), neutral-to-negative everywhere else
+    if (variant == 9 && epi == EPI_BIAS_GELU_H16 && a.stagger == 0) {
+      const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+      if (tiles >= 8 * 256) a.stagger = 4;
+    }
+  }
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)

@@ -285,6 +285,17 @@ def gemm_epi_ablation():
         log(f"epi_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
 
 
+def gemm_stagger():
+    ms = _lib.c_f32()
+    for (M, N, K, epi, v, nm) in [(32768, 4608, 1152, 1, 9, "fc1"), (32768, 3456, 1152, 0, 9, "qkv"), (32768, 1152, 4608, 2, 8, "fc2"),
+                                  (32768, 1152, 1152, 2, 8, "proj"), (8192, 4608, 1152, 1, 8, "fc1 B=2")]:
+        row = []
+        for st in (0, 2, 4, 8):
+            check(lib.latte_bench_gemm(M, N, K, epi, 0, v + 100 * st, 20, ctypes.byref(ms), stream_ptr()))
+            row.append(f"st{st}: {ms.value*1e3:6.1f}us {2.0*M*N*K/(ms.value*1e-3)/1e12:5.0f}TF")
+        log(f"stagger {nm} v{v}: " + " | ".join(row))
+
+
 def xl_profile():
     from oracle import latte_oracle as lo
     from latte_amd.models import Latte_models
