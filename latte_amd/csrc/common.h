@@ -58,7 +58,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);
-int gemm_auto_variant(int M, int N);
+int gemm_auto_variant(int M, int N, int epi);
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {

@@ -58,6 +58,7 @@ struct latte_engine {
   int nmod = 0;           // depth*6D + 2D
   int64_t rows_max = 0, rows_pad = 0;
   int gemm_variant = 0;  // 0 = per-shape choice (gemm_auto_variant)
+  int gemm_variant_of[4] = {0, 0, 0, 0};   // per-GEMM override (qkv, proj, fc1, fc2); 0 = gemm_variant
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
         *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr, *ytab = nullptr, *fin_wt = nullptr,
@@ -169,7 +170,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     GemmArgs g{};
     g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
     g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
-    if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant, st))) return rc;
+    if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant_of[0] ? e->gemm_variant_of[0] : e->gemm_variant, st))) return rc;
     tm.mark(C_QKV);
     AttnArgs a{};
     a.qkv = e->qkv; a.out = e->xn; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
@@ -179,15 +180,15 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     if ((rc = launch_attention(a, dt, st))) return rc;
     tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D;
-    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant, st))) return rc;
+    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
     tm.mark(C_LN);
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
-    if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant, st))) return rc;
+    if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC1);
     g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm;
-    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant, st))) return rc;
+    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[3] ? e->gemm_variant_of[3] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC2);
   }
   // --- final layer (latte.py:197-201) + unpatchify (:297-310)
@@ -387,6 +388,14 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
     e->gemm_variant = (int)value;
     return LATTE_OK;
+  }
+  for (int gi = 0; gi < 4; ++gi) {
+    static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
+    if (k == names[gi]) {
+      if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..9");
+      e->gemm_variant_of[gi] = (int)value;
+      return LATTE_OK;
+    }
   }
   if (k == "seed") {
     e->seed = (uint64_t)value;

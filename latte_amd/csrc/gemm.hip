@@ -15,6 +15,8 @@
 //    and float4 bias / gate loads in the epilogue;
 //  * XCD-aware, grouped block->tile mapping so that co-resident tiles of one XCD share A/W panels in
 //    that XCD's private L2.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma_util.h"
 
@@ -459,7 +461,6 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   // stages leave free) so that every global store instruction writes 8 complete 128-byte rows instead of
   // 16 rows x 32 bytes: the direct form is store-ISSUE bound (measured: 25-30 % of the fc1 / qkv launch).
   constexpr bool LDS_EPI = (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) && BN == 256;
-  constexpr int NST = LDS_EPI ? 16 : 8 * FN;   // store instructions one wave issues per (full) tile
   auto epilogue = [&](int tm_, int tn_) {
     int le = lane;
     asm volatile("" : "+v"(le));   // opaque: keeps every lane-derived epilogue index out of the K loop's live set
@@ -513,6 +514,9 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
       for (int i = 0; i < 8; ++i) {
         const int m = mbase + i * 16;
         if (m < g.M) {
+          // (fp32 read-modify-write epilogue: issuing all residual loads of half a wave tile up front was measured
+          //  24 % SLOWER inside the model -- 337 -> 418 us for fc2 -- than this just-in-time form, whose loads and
+          //  stores interleave)
           const float* gate_row = nullptr;
           if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
 #pragma unroll
@@ -530,12 +534,12 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   //   then  : issue DMA(u+2) into stage(u) -- group 1 BEFORE the barrier ending its C(u) (it only writes its
   //           own A rows, which nobody else reads), group 0 AFTER the barrier ending its C(u) (by then group 1
   //           has finished L(u), the last reader of stage(u)); at a tile boundary the epilogue follows.
-  // vmcnt retires in issue order and counts stores, so the DMA is issued BEFORE the epilogue's stores and
-  // the wait at the end of the next C segment is vmcnt(NST): everything older than the youngest NST
-  // operations -- i.e. the DMA -- has landed, while the stores keep draining under the next tile's loop.
-  // (A tile with rows >= M issues fewer stores: that boundary waits vmcnt(0).)
+  // vmcnt retires in issue order and counts stores, so the DMA is issued BEFORE the epilogue: the epilogue's own
+  // first use of a loaded value (bias / residual) then implies that DMA has landed, and the C segment that follows
+  // a boundary needs no wait at all while the stores keep draining under the next tile's loop.
+  // (Tiles with rows >= M, and waves whose columns lie beyond N, take the plain vmcnt(0) path.)
   int it = 0;
-  bool counted = false;   // the DMA waited for in this iteration was followed by exactly NST stores
+  bool counted = false;   // the DMA needed by this iteration was issued before an epilogue that loaded and used data
   for (;;) {
     const int npos = pos + per;
     const bool has_next = npos < cnt;
@@ -563,13 +567,10 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
-      if (counted) {
-        if constexpr (NST == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if constexpr (NST == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // DMA(u+1) must have landed.  After a tile boundary it provably has: the epilogue began with global loads
+      // (bias / residual) that were issued AFTER DMA(u) and DMA(u+1) and were consumed before its first store, and
+      // vmcnt retires in issue order -- so no wait here, and the epilogue's stores keep draining under this tile.
+      if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = false;
       // K tile u+2: same tile, or the next tile's K tile kt + 2 - nk
       const bool last = kt + 1 == nk;
@@ -578,6 +579,7 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
       const int stm = in_tile ? tm : ntm, stn = in_tile ? tn : ntn, skt = in_tile ? kt + 2 : kt + 2 - nk;
       if (grp == 1) {
         if (do_dma) dma_a_half(stm, skt, it & 1);
+        asm volatile("" ::: "memory");   // the epilogue's loads must stay BEHIND the DMA issue (in-order vmcnt argument)
         if (last) epilogue(tm, tn);
       }
       __builtin_amdgcn_s_barrier();
@@ -586,6 +588,7 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
           dma_a_half(stm, skt, it & 1);
           dma_b_all(stn, skt, it & 1);
         }
+        asm volatile("" ::: "memory");
         if (last) epilogue(tm, tn);
       }
       if (last) counted = do_dma && full_rows && (tn * BN + wn * WTN < g.N);
@@ -695,10 +698,14 @@ int gemm_tile_n(int variant) {
 // variant 0: pick the tile by a wave-quantisation model.  score = (tiles / (rounds * slots)) * rate where
 // slots = resident workgroups on 256 CUs (ping-pong: 1 per CU; 128x128: 2 per CU) and rate is the kernel's
 // relative throughput at full occupancy (microbenchmarks).
-int gemm_auto_variant(int M, int N) {
+int gemm_auto_variant(int M, int N, int epi) {
   struct Cand { int variant, bm, bn, slots; float rate; };
-  static const Cand cands[] = {{9, 256, 256, 256, 1.00f}, {8, 256, 192, 256, 0.97f}, {7, 256, 128, 256, 0.82f},
-                               {1, 128, 128, 512, 0.80f}};
+  // relative throughput at full occupancy (M = 32768 microbenchmarks): the 256-wide persistent tile has the
+  // full-line LDS-transposed epilogue for half-precision outputs (qkv: 220 us vs 250-266 us at 192), for the fp32
+  // read-modify-write epilogue the two are within 3 %
+  const bool half_out = epi == EPI_BIAS_H16 || epi == EPI_BIAS_GELU_H16;
+  const Cand cands[] = {{9, 256, 256, 256, 1.00f}, {8, 256, 192, 256, half_out ? 0.86f : 0.97f}, {7, 256, 128, 256, 0.80f},
+                        {1, 128, 128, 512, 0.78f}};
   int best = 1;
   float best_score = -1.f;
   for (const Cand& c : cands) {
@@ -717,13 +724,9 @@ int gemm_auto_variant(int M, int N) {
 int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
   GemmArgs a = a_in;
   if (variant == 0) {
-    variant = gemm_auto_variant(a.M, a.N);
-    // start cohorts (gemm_pps_kernel): measured +7 % on the GELU epilogue shape when a workgroup walks >= 8 tiles
-    // (M = 32768: 355 -> 332 us), neutral-to-negative everywhere else
-    if (variant == 9 && epi == EPI_BIAS_GELU_H16 && a.stagger == 0) {
-      const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-      if (tiles >= 8 * 256) a.stagger = 4;
-    }
+    variant = gemm_auto_variant(a.M, a.N, epi);
+    // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
+    //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
   }
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths

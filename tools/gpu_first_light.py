@@ -285,6 +285,34 @@ def gemm_epi_ablation():
         log(f"epi_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
 
 
+def gemm_in_model():
+    """Per-GEMM tile variants measured INSIDE the XL/2 forward (cache state of the real pipeline), B = 8 and 2."""
+    from latte_amd.models import Latte_models
+    for B in (8, 2):
+        m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if float(p_.abs().max()) == 0.0:
+                    p_.normal_(0, 0.02)
+        m = m.to(dev)
+        x = torch.randn(B, 16, 4, 32, 32, device=dev)
+        t = torch.full((B,), 500, device=dev, dtype=torch.int64)
+        for gname, key in (("qkv", "gemm_qkv"), ("proj", "gemm_proj"), ("fc1", "gemm_fc1"), ("fc2", "gemm_fc2")):
+            row = []
+            for v in (1, 5, 6, 7, 8, 9):
+                try:
+                    m.set_engine_option("gemm_variant_" + gname, v, B)
+                    m.profile_forward(x, t)
+                    ms = min(m.profile_forward(x, t)[key][0] for _ in range(3))
+                    row.append(f"v{v}: {ms/28*1e3:6.1f}us")
+                except Exception as ex:
+                    row.append(f"v{v}: n/a")
+            m.set_engine_option("gemm_variant_" + gname, 0, B)
+            log(f"in-model B={B} {gname}: " + " | ".join(row))
+        del m
+        torch.cuda.empty_cache()
+
+
 def gemm_stagger():
     ms = _lib.c_f32()
     for (M, N, K, epi, v, nm) in [(32768, 4608, 1152, 1, 9, "fc1"), (32768, 3456, 1152, 0, 9, "qkv"), (32768, 1152, 4608, 2, 8, "fc2"),
