@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--method", default="ddim", choices=["ddim", "ddpm"])
     p.add_argument("--gemm-variant", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode rate report")
     p.add_argument("--cpu-forwards", type=int, default=2)
     return p.parse_args()
 
@@ -104,6 +105,27 @@ def pmc_traffic(kernel_class, M):
     return rec["hbm_bytes_per_launch"] if rec else None
 
 
+def vae_decode_rate(device):
+    """VAE decode of one 16-frame video (latents 16x4x32x32 -> 16x256x256x3 uint8), random sd-vae-ft-shaped weights;
+    reported beside the headline, outside its timed region (decode is ~1.5 % of a 250-step chain)."""
+    import latte_amd
+    from oracle import vae_oracle as vo
+    vae = latte_amd.AutoencoderKL(latent_size=32, max_frames=16, compute_dtype="f16")
+    vae.load_state_dict(vo.init_state_dict(0))
+    vae.to(device)
+    lat = torch.randn(1, 16, 4, 32, 32, device=device) * 0.18215
+    vae.decode_video_uint8(lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        out = vae.decode_video_uint8(lat)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"ms_per_video": round(dt * 1e3, 2), "frames_per_sec": round(16 / dt, 1), "dtype": "f16",
+            "algorithmic_tflops_per_s": round(16 * 0.62 / dt, 1), "finite_and_nonconstant": bool(out.float().std() > 0)}
+
+
 def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -114,13 +136,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  LATTE_BENCH_BACKEND=gloo exists only to exercise the N > 1 code path on a box
+        # with fewer GPUs than ranks (RCCL refuses two ranks on one device); it is never used for reported numbers.
+        backend = os.environ.get("LATTE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import latte_amd
     from latte_amd._lib import load_library
@@ -192,6 +221,8 @@ def main():
             "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
             "forward_ms_eager_events": round(total_ms, 4),
         }
+        if world == 1 and not args.no_vae:
+            res["vae_decode"] = vae_decode_rate(device)
         if world == 1 and not args.no_cpu_baseline:
             note('cpu baseline (oracle on host cores)')
             res["cpu_baseline"] = cpu_baseline(args.cpu_forwards)

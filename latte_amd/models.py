@@ -152,6 +152,26 @@ class Latte(nn.Module):
         self._synced = False
         return r
 
+    def to(self, *args, **kwargs):
+        """``model.to(device)`` / ``model.to(dtype=torch.float16)`` (sample.py:56,75).  A half dtype selects the MFMA
+        operand type of the engine (f16 like the reference's ``use_fp16`` path, or bf16); the parameters themselves
+        stay fp32 masters on the host side and are packed by the engine."""
+        dt = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dt = a
+        if dt in (torch.float16, torch.bfloat16):
+            self.compute_dtype = "f16" if dt == torch.float16 else "bf16"
+            kwargs.pop("dtype", None)
+            args = tuple(a for a in args if not isinstance(a, torch.dtype))
+            self._synced = False
+            if not args and not kwargs:
+                return self
+        return super().to(*args, **kwargs)
+
+    def half(self):
+        return self.to(dtype=torch.float16)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self._synced = False

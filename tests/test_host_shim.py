@@ -90,3 +90,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_half_dtype_selects_engine_operand_type():
+    """sample.py:72-75: model.to(dtype=torch.float16) under use_fp16 -> f16 MFMA operands, fp32 master weights."""
+    import torch
+    from latte_amd.models import Latte_models
+    m = Latte_models["Latte-S/2"](input_size=8, num_frames=4, extras=1)
+    assert m.compute_dtype == "bf16"
+    m.to(dtype=torch.float16)
+    assert m.compute_dtype == "f16" and m.pos_embed.dtype == torch.float32
+    m.to(torch.bfloat16)
+    assert m.compute_dtype == "bf16"
