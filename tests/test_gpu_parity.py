@@ -219,3 +219,50 @@ def test_temb_table_and_chain_conditioning(lib):
     c = d.ddim_sample_loop(lambda xx, tt, **k: m.forward(xx, tt, **k), x.shape, x.clone(), clip_denoised=False,
                            model_kwargs=dict(y=y), device="cuda")
     assert rel_l2(a, c) < 1e-6
+
+
+def test_xl_guided_ddim_chain_matches_oracle():
+    """Headline size, class-conditional with classifier-free guidance (BASELINE config 3's model): two DDIM steps of the
+    '250' respacing from the oracle's loop vs the fused engine loop on the doubled batch, identical noise."""
+    from oracle import diffusion_oracle as do
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=32, num_frames=16, num_classes=101, extras=2)
+    cfg = lo.preset_config("Latte-XL/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=3)
+    g = torch.Generator("cpu").manual_seed(4)
+    z = torch.randn(1, 16, 4, 32, 32, generator=g)
+    x = torch.cat([z, z])
+    y = torch.tensor([17, 101])
+    scale = 4.0
+    s = do.Schedule("250")
+    want = x.clone()
+    with torch.no_grad():
+        for i in (249, 248):                                   # the loop body of gd:637-684 for two steps
+            t = torch.full((2,), s.timestep_map[i], dtype=torch.int64)
+            out = lo.latte_forward_with_cfg(sd, cfg, want, t, y, scale)
+            want = do.ddim_sample(s, out, want, i, None, 0.0, False)["sample"]
+    m = latte_amd.Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=2, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    d = latte_amd.create_diffusion("250")
+    xx = x.cuda().contiguous()
+    check(load_library().latte_sample_loop(m.engine(2), d._h, 1, 0.0, 0, scale, ptr(xx), ptr(y.cuda()), 2, 249, 248, None, None,
+                                           None, stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(xx, want) < TOL
+
+
+def test_results_do_not_depend_on_batch_composition():
+    """Sharding claim: a sample's chain is the same whether it runs alone or inside a batch —
+    different M means different GEMM tile shapes and workgroup schedules, the K order of every dot product does not."""
+    kw, sd, r = load_golden_model("tiny_uncond")
+    g = torch.Generator("cpu").manual_seed(11)
+    xs = torch.randn(5, *r["x"].shape[1:], generator=g).cuda()
+    d = latte_amd.create_diffusion("6")
+    m5 = engine_model(kw, sd, "bf16", max_batch=5)
+    all5 = d.ddim_sample_loop(m5.forward, xs.shape, xs.clone(), clip_denoised=False, model_kwargs=dict(y=None))
+    m1 = engine_model(kw, sd, "bf16", max_batch=1)
+    for b in (0, 3):
+        one = d.ddim_sample_loop(m1.forward, xs[b:b + 1].shape, xs[b:b + 1].clone(), clip_denoised=False,
+                                 model_kwargs=dict(y=None))
+        assert torch.equal(one[0], all5[b])
