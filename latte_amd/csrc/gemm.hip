@@ -510,13 +510,52 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
     } else {
       const int ncol = ncol0 + (le >> 4) * 4;
       const int mbase = tm_ * BM + grp * 128 + fr;
+      if constexpr (EPI == EPI_GATE_RES_F32 && FN <= 3) {
+        // res[m, n] += gate[sample, n] * (acc + bias), fast path for tiles inside one sample (rows_per_sample % 256 == 0:
+        // every Latte config at F*T >= 256).  vmcnt retires in issue order and counts stores, so in the plain
+        // load / wait / store sequence every load also waits for the previous store: a chain of 24 load + store round
+        // trips per tile.  Here the residual loads run TWO fragments ahead of the stores, so a wait only ever covers a
+        // load issued before the last stores.  (Issuing ALL 24 loads first was measured 24 % slower in the model --
+        // fc2 337 -> 417 us: 6 MB of loaded lines per XCD overflow the 4 MB L2 before the stores arrive.)
+        if ((g.rows_per_sample % BM) == 0) {
+          float* const outp = (float*)g.out;
+          const float* gr = g.gate + (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
+          float4 b4[FN], g1[FN];
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            b4[j] = *(const float4*)(g.bias + ncol + j * 16);
+            g1[j] = *(const float4*)(gr + j * 16);
+          }
+          // fragments in (i, j) order, residual loads running two fragments ahead of the stores
+          constexpr int NF = 8 * FN;
+          auto frag_ptr = [&](int f) -> float* {
+            const int mc = min(mbase + (f / FN) * 16, g.M - 1);      // clamped row: the load is unconditional
+            return outp + (size_t)mc * g.N + ncol + (f % FN) * 16;
+          };
+          float4 q0 = *(const float4*)frag_ptr(0), q1 = *(const float4*)frag_ptr(1);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            float4 q2 = q1;
+            if (f + 2 < NF) q2 = *(const float4*)frag_ptr(f + 2);
+            asm volatile("" ::: "memory");                           // keep the prefetch ahead of this fragment's store
+            const int i = f / FN, j = f % FN;
+            float4 r = q0;
+            r.x += g1[j].x * (acc[i][j][0] + b4[j].x);
+            r.y += g1[j].y * (acc[i][j][1] + b4[j].y);
+            r.z += g1[j].z * (acc[i][j][2] + b4[j].z);
+            r.w += g1[j].w * (acc[i][j][3] + b4[j].w);
+            if (mbase + i * 16 < g.M) *(float4*)(outp + (size_t)(mbase + i * 16) * g.N + ncol + j * 16) = r;
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            q0 = q1;
+            q1 = q2;
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int m = mbase + i * 16;
         if (m < g.M) {
-          // (fp32 read-modify-write epilogue: issuing all residual loads of half a wave tile up front was measured
-          //  24 % SLOWER inside the model -- 337 -> 418 us for fc2 -- than this just-in-time form, whose loads and
-          //  stores interleave)
           const float* gate_row = nullptr;
           if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
 #pragma unroll
