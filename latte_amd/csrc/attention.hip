@@ -430,7 +430,15 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fl = lane & 15, g = lane >> 4;
   const int items = a.num_seq * a.heads;
-  int item = blockIdx.x * 4 + wave;
+  // Block -> 4 (sequence, head) items.  As in attn_full_kernel the head slices of a token row share 128-byte lines, so the
+  // blocks that cover the heads of one sequence are kept on ONE XCD (blocks b, b + 8, ... walk the head groups).
+  int blk = blockIdx.x;
+  const int hgroups = a.heads >> 2;
+  if ((a.heads & 3) == 0 && (a.num_seq & 7) == 0) {
+    const int xcd = blk & 7, slot = blk >> 3;
+    blk = ((slot / hgroups) * 8 + xcd) * hgroups + slot % hgroups;
+  }
+  int item = blk * 4 + wave;
   const bool active = item < items;
   item = min(item, items - 1);
   const int seq = item / a.heads, head = item % a.heads;
