@@ -24,9 +24,10 @@ namespace latte {
 namespace {
 
 // GELU(tanh approximation) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (latte.py:170)
+// = x / (1 + exp2(x (a + b x^2))) with a = -2 log2(e) sqrt(2/pi), b = 0.044715 a: 3 mul + 1 fma + 1 add + exp2 + rcp
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+  const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
 }
 
 // One accumulator fragment -> memory.  Lane holds 4 consecutive columns n..n+3 of row m.
