@@ -69,7 +69,7 @@ typedef struct latte_model_config {
   int num_frames;    /*                                          latte.py:217 */
   int num_classes;   /* label table has num_classes+1 rows       latte.py:131 */
   int learn_sigma;   /* out_channels = 2*in_channels if set      latte.py:226 */
-  int extras;        /* 1 = unconditional, 2 = class-conditional latte.py:221 */
+  int extras;        /* 1 = unconditional, 2 = class-conditional, 78 = text embedding (latte.py:221,235-242) */
   int compute_dtype; /* LATTE_DTYPE_* for the MFMA operands */
 } latte_model_config_t;
 
@@ -104,6 +104,13 @@ const char* latte_engine_key(const latte_engine_t* e, int i);
  * table == NULL uninstalls. */
 int latte_engine_temb_table(latte_engine_t* e, const latte_schedule_t* s, float* out, void* stream);
 int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_timesteps, void* stream);
+
+/* Text-conditioned variant (extras == 78; latte.py:238-242,340-363): project a batch of text embeddings once,
+ * text_embedding:[batch, 77*768] fp32 (device), Linear(SiLU(.)) -> [batch, D] kept inside the engine.  Every later
+ * latte_forward / latte_forward_with_cfg / latte_sample_loop with the same batch conditions the 28 blocks on
+ * t_emb + projected text and the final layer on t_emb alone (latte.py:372-373); y is ignored.  For guidance pass the
+ * doubled batch [text, null text] (forward_with_cfg forwards text_embedding unchanged, latte.py:388). */
+int latte_engine_set_text_embedding(latte_engine_t* e, const float* text_embedding, int batch, void* stream);
 
 /* Latte.forward (latte.py:314-377).  x:[B,F,C,H,W] fp32, t: int64[B] ORIGINAL timesteps (device),
  * y: int64[B] labels (device) or NULL when extras == 1, out:[B,F,Cout,H,W] fp32. */

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "latte_engine_key": (c_char, [c_void, c_int]),
     "latte_engine_temb_table": (c_int, [c_void, c_void, c_void, c_void]),
     "latte_engine_set_temb_table": (c_int, [c_void, c_void, c_int, c_void]),
+    "latte_engine_set_text_embedding": (c_int, [c_void, c_void, c_int, c_void]),
     "latte_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void]),
     "latte_forward_with_cfg": (c_int, [c_void, c_void, c_void, c_void, c_int, c_f32, c_void, c_void]),
     "latte_sampler_step": (c_int, [c_void, c_int, c_int, c_f32, c_int, c_void, c_void, c_void, c_int, c_int, c_int,

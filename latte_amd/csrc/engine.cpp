@@ -68,6 +68,13 @@ struct latte_engine {
   half_t *xn = nullptr, *qkv = nullptr, *hbuf = nullptr;
   int64_t* tmap_dev = nullptr;
   int64_t tmap_cap = 0;
+  // extras == 78 (latte.py:238-242): text projection weights, the projected rows of the current text batch, identity
+  // row index (the projected rows enter the conditioning exactly where the label-table rows do), t-only vector / rows
+  // for the final layer, whose conditioning never includes the text (latte.py:372-373)
+  float *txt_w = nullptr, *txt_b = nullptr, *txt_proj = nullptr, *cvec_t = nullptr, *cond_rows_t = nullptr;
+  int64_t* iota = nullptr;
+  int64_t cond_t_cap = 0;
+  int txt_rows = 0;
   // conditioning of a whole chain (latte_sample_loop): timestep-embedding table (own or installed after the RCCL
   // broadcast), per-(step, sample) conditioning rows and all adaLN outputs
   float *temb_table = nullptr, *temb_own = nullptr, *temb_work = nullptr, *cond_rows = nullptr, *mod_all = nullptr;
@@ -127,6 +134,8 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   const auto& c = e->cfg;
   if (B <= 0 || B > e->max_batch) return fail(LATTE_ERR_STATE, "forward: batch exceeds max_batch of the engine");
   if (c.extras == 2 && y == nullptr && !mod_override) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
+  if (c.extras == 78 && e->txt_rows != B && !mod_override)
+    return fail(LATTE_ERR_STATE, "forward: text-conditioned model needs latte_engine_set_text_embedding with one row per sample first");
   if (cfg_dup && (B % 2)) return fail(LATTE_ERR_INVALID, "forward_with_cfg: batch must be even");
   const int D = e->D, T = e->T, F = e->F, dt = c.compute_dtype;
   const int M = B * F * T;
@@ -142,10 +151,17 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     mstride = mod_stride_override;
   } else {
     if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t0_w, e->t0_b, nullptr, nullptr, e->temb0, B, D, 256, D, st))) return rc;
-    if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, c.extras == 2 ? e->ytab : nullptr, y,
-                                  e->cvec, B, D, D, D, st))) return rc;
+    const float* add_tab = c.extras == 2 ? e->ytab : c.extras == 78 ? e->txt_proj : nullptr;
+    const int64_t* add_idx = c.extras == 78 ? e->iota : y;
+    if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, add_tab, add_idx, e->cvec, B, D, D, D, st))) return rc;
     if ((rc = launch_small_linear(IN_SILU, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
                                   e->nmod, st))) return rc;
+    if (c.extras == 78) {   // final layer: c = t only (latte.py:372-373) -> redo its 2D columns from the plain t_emb
+      const size_t fo = (size_t)c.depth * 6 * D;
+      if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, nullptr, nullptr, e->cvec_t, B, D, D, D, st))) return rc;
+      if ((rc = launch_small_linear(IN_SILU, e->cvec_t, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr, nullptr,
+                                    e->mod + fo, B, 2 * D, D, e->nmod, st))) return rc;
+    }
   }
   tm.mark(C_COND);
   // --- patch embed + pos_embed (latte.py:330-331)
@@ -275,7 +291,8 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   if (hd != 64 && hd != 72) return fail(LATTE_ERR_INVALID, "engine_create: head_dim must be 64 or 72");
   if (c.patch_size <= 0 || c.input_size % c.patch_size) return fail(LATTE_ERR_INVALID, "engine_create: input_size % patch_size != 0");
   if (c.mlp_hidden % 128 != 0) return fail(LATTE_ERR_INVALID, "engine_create: mlp_hidden must be a multiple of 128");
-  if (c.extras != 1 && c.extras != 2) return fail(LATTE_ERR_INVALID, "engine_create: extras must be 1 (uncond) or 2 (class-cond)");
+  if (c.extras != 1 && c.extras != 2 && c.extras != 78)
+    return fail(LATTE_ERR_INVALID, "engine_create: extras must be 1 (uncond), 2 (class-cond) or 78 (text embedding)");
   if (c.in_channels != 4) return fail(LATTE_ERR_INVALID, "engine_create: in_channels must be 4 (guidance is hard-wired to 4 channels, latte.py:394)");
   if (c.compute_dtype != LATTE_DTYPE_BF16 && c.compute_dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "engine_create: bad compute dtype");
 
@@ -322,6 +339,18 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   if (c.extras == 2) {
     TRY(dev_alloc(e, &e->ytab, (size_t)(c.num_classes + 1) * D));
     add_slot(e, "y_embedder.embedding_table.weight", (int64_t)(c.num_classes + 1) * D, PK_F32, e->ytab);
+  }
+  if (c.extras == 78) {
+    constexpr int64_t TK = 77 * 768;   // latte.py:241
+    TRY(dev_alloc(e, &e->txt_w, (size_t)D * TK));
+    TRY(dev_alloc(e, &e->txt_b, (size_t)D));
+    TRY(dev_alloc(e, &e->txt_proj, (size_t)max_batch * D));
+    TRY(dev_alloc(e, &e->cvec_t, (size_t)max_batch * D));
+    TRY(dev_alloc(e, &e->iota, (size_t)max_batch));
+    TRY(launch_iota(e->iota, max_batch, nullptr));
+    LATTE_HIP(hipStreamSynchronize(nullptr));
+    add_slot(e, "text_embedding_projection.1.weight", (int64_t)D * TK, PK_F32, e->txt_w);
+    add_slot(e, "text_embedding_projection.1.bias", D, PK_F32, e->txt_b);
   }
   e->blocks.resize(c.depth);
   for (int i = 0; i < c.depth; ++i) {
@@ -466,6 +495,17 @@ int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_t
   return LATTE_OK;
 }
 
+int latte_engine_set_text_embedding(latte_engine_t* e, const float* text_embedding, int batch, void* stream) {
+  if (!e || !text_embedding) return fail(LATTE_ERR_INVALID, "set_text_embedding: null argument");
+  if (e->cfg.extras != 78) return fail(LATTE_ERR_STATE, "set_text_embedding: the model has no text_embedding_projection (extras != 78)");
+  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "set_text_embedding: batch exceeds max_batch of the engine");
+  int rc = latte_engine_check_weights(e);
+  if (rc) return rc;
+  if ((rc = launch_text_proj(text_embedding, e->txt_w, e->txt_b, e->txt_proj, batch, e->D, 77 * 768, (hipStream_t)stream))) return rc;
+  e->txt_rows = batch;
+  return LATTE_OK;
+}
+
 int latte_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
                   void* stream) {
   if (!e || !x || !t || !out) return fail(LATTE_ERR_INVALID, "forward: null argument");
@@ -519,8 +559,11 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   // fp32) are then streamed once per 64 rows instead of once per denoising step.
   const int D = e->D;
   const int n_run = start_index - end_index + 1;
-  const int bu = e->cfg.extras == 2 ? batch : 1;
-  if (e->cfg.extras == 2 && y == nullptr) return fail(LATTE_ERR_INVALID, "sample_loop: class-conditional model needs y");
+  const int ex = e->cfg.extras;
+  const int bu = ex == 1 ? 1 : batch;
+  if (ex == 2 && y == nullptr) return fail(LATTE_ERR_INVALID, "sample_loop: class-conditional model needs y");
+  if (ex == 78 && e->txt_rows != batch)
+    return fail(LATTE_ERR_STATE, "sample_loop: text-conditioned model needs latte_engine_set_text_embedding with one row per sample first");
   const float* temb = nullptr;
   if (e->temb_table_n == n) {
     temb = e->temb_table;
@@ -533,11 +576,20 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_all * D))) return rc;
   if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_all * e->nmod))) return rc;
   // rows are ordered by respaced index ascending: row (i - end_index) * bu + b
-  if ((rc = launch_cond_rows(temb + (size_t)end_index * D, e->cfg.extras == 2 ? e->ytab : nullptr, y, e->cond_rows, n_run, bu, D, st))) return rc;
+  if ((rc = launch_cond_rows(temb + (size_t)end_index * D, ex == 2 ? e->ytab : ex == 78 ? e->txt_proj : nullptr,
+                             ex == 78 ? e->iota : y, e->cond_rows, n_run, bu, D, st))) return rc;
+  if (ex == 78) {   // t-only rows for the final layer (latte.py:372-373)
+    if ((rc = grow(e, &e->cond_rows_t, &e->cond_t_cap, rows_all * D))) return rc;
+    if ((rc = launch_cond_rows(temb + (size_t)end_index * D, nullptr, nullptr, e->cond_rows_t, n_run, bu, D, st))) return rc;
+  }
+  const size_t fo = (size_t)e->cfg.depth * 6 * D;
   for (int64_t r0 = 0; r0 < rows_all; r0 += 64) {
     const int rows = (int)std::min<int64_t>(64, rows_all - r0);
     if ((rc = launch_small_linear(IN_SILU, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
                                   e->mod_all + (size_t)r0 * e->nmod, rows, e->nmod, D, e->nmod, st))) return rc;
+    if (ex == 78 &&
+        (rc = launch_small_linear(IN_SILU, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
+                                  nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return rc;
   }
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
   int k = 0;

@@ -274,6 +274,46 @@ __global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __
   }
 }
 
+// text_embedding_projection (latte.py:238-242,341): out[b, n] = bias[n] + sum_k silu(text[b, k]) * W[n, k], K = 77*768.
+// Once per chain.  One wave per output feature streams its 236 KB weight row once per group of TP_B samples (the rows
+// of W are the HBM traffic: 272 MB at D = 1152; the [B, K] input stays cache resident).
+constexpr int TP_B = 8;
+__global__ void __launch_bounds__(256) text_proj_kernel(const float* __restrict__ text, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                        int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float2* wr = (const float2*)(W + (size_t)n * K);
+  const int nch = K >> 7;   // K % 128 == 0 (launcher)
+  for (int b0 = 0; b0 < B; b0 += TP_B) {
+    float acc[TP_B];
+#pragma unroll
+    for (int u = 0; u < TP_B; ++u) acc[u] = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const float2 w = wr[c * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < TP_B; ++u) {
+        if (b0 + u < B) {
+          const float2 a = ((const float2*)(text + (size_t)(b0 + u) * K))[c * 64 + lane];
+          acc[u] = fmaf(silu(a.x), w.x, acc[u]);
+          acc[u] = fmaf(silu(a.y), w.y, acc[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TP_B; ++u) {
+      const float r = wave_sum(acc[u]);
+      if (lane == 0 && b0 + u < B) out[(size_t)(b0 + u) * N + n] = r + bias[n];
+    }
+  }
+}
+
+__global__ void iota_kernel(int64_t* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
 __global__ void cfg_combine_kernel(float* out, int half_batch, int F, int Cout, int HW, float s) {
   // eps channels are [0, 4) (hard-coded 4 in the reference, latte.py:394)
   const size_t per_sample = (size_t)F * 4 * HW;
@@ -500,6 +540,20 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
                      hipStream_t st) {
   const size_t n = (size_t)n_steps * bu * D;
   hipLaunchKernelGGL(cond_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, temb, ytab, y, out, n_steps, bu, D);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K,
+                     hipStream_t st) {
+  if (K % 128) return fail(LATTE_ERR_INVALID, "text_proj: K must be a multiple of 128");
+  hipLaunchKernelGGL(text_proj_kernel, dim3((N + 3) / 4), dim3(256), 0, st, text, W, bias, out, B, N, K);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_iota(int64_t* p, int n, hipStream_t st) {
+  hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

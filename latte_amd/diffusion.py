@@ -144,12 +144,13 @@ class SpacedDiffusion:
         needs_noise = method == "ddpm" or eta != 0.0
         owner, uses_cfg = self._engine_model(model)
         known = {"y", "use_fp16", "cfg_scale", "text_embedding"}
-        if owner is not None and set(model_kwargs) <= known and model_kwargs.get("text_embedding") is None:
+        if owner is not None and set(model_kwargs) <= known:
             # ---- whole chain inside the engine
             B = img.shape[0]
             y = model_kwargs.get("y")
             x32, _, y64 = owner._prep(img, torch.zeros(B, dtype=torch.int64), y)
             eng = owner.engine(B)
+            owner._set_text(model_kwargs.get("text_embedding"), B)
             cfg_scale = float(model_kwargs.get("cfg_scale", 7.0)) if uses_cfg else 1.0
             if uses_cfg and cfg_scale <= 1.0:
                 raise LatteError("forward_with_cfg inside the fused loop needs cfg_scale > 1 (sample.py:51)")

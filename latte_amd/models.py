@@ -64,9 +64,9 @@ class Latte(nn.Module):
         super().__init__()
         if hidden_size % num_heads != 0:
             raise AssertionError("dim should be divisible by num_heads")          # latte.py:38
-        if extras not in (1, 2):
-            raise LatteError("latte_amd supports extras=1 (unconditional) and extras=2 (class-conditional); "
-                             "the text-embedding variant (extras=78) is outside the accelerated path")
+        if extras not in (1, 2, 78):
+            raise LatteError("latte_amd supports extras=1 (unconditional), 2 (class-conditional) and 78 (text embedding), "
+                             "the three conditioning modes of latte.py:235-242")
         if attention_mode not in ("math", "flash", "xformers"):
             raise NotImplementedError(attention_mode)                             # latte.py:73
         self.learn_sigma = learn_sigma
@@ -98,6 +98,8 @@ class Latte(nn.Module):
             self.y_embedder.embedding_table = _Holder()
             self.y_embedder.embedding_table.weight = nn.Parameter(
                 torch.empty(self.num_classes + int(use_cfg_embedding), D))
+        if extras == 78:                                                          # latte.py:238-242
+            self.text_embedding_projection = nn.ModuleList([nn.SiLU(), _linear(D, 77 * 768)])
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, D), requires_grad=False)
         self.temp_embed = nn.Parameter(torch.zeros(1, num_frames, D), requires_grad=False)
         blocks = []
@@ -239,6 +241,20 @@ class Latte(nn.Module):
         check(load_library().latte_engine_set_option(self.engine(batch), name.encode(), int(value)))
 
     # ------------------------------------------------------------------ the model-callable protocol
+    def _set_text(self, text_embedding, B):
+        """extras == 78: project the [B, 77, 768] text embeddings inside the engine (latte.py:341)."""
+        if self.extras != 78:
+            return
+        if text_embedding is None:
+            raise LatteError("text-conditioned Latte (extras=78) needs text_embedding [B, 77, 768]")
+        dev = self.pos_embed.device
+        te = text_embedding.to(device=dev, dtype=torch.float32).reshape(text_embedding.shape[0], -1).contiguous()
+        if te.shape != (B, 77 * 768):
+            raise LatteError(f"text_embedding must be [B, 77, 768] with B = {B}, got {tuple(text_embedding.shape)}")
+        with torch.cuda.device(dev):
+            check(load_library().latte_engine_set_text_embedding(self.engine(B), ptr(te), B, stream_ptr()))
+        self._text_keepalive = te     # the projection kernel is stream-ordered; keep its input alive
+
     def _prep(self, x, t, y):
         if x.dim() != 5:
             raise LatteError("x must be [B, F, C, H, W]")
@@ -265,6 +281,7 @@ class Latte(nn.Module):
         x32, t64, y64 = self._prep(x, t, y)
         B = x32.shape[0]
         eng = self.engine(B)
+        self._set_text(text_embedding, B)
         out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
                           device=x32.device, dtype=torch.float32)
         with torch.cuda.device(x32.device):
@@ -278,6 +295,7 @@ class Latte(nn.Module):
         if B % 2:
             raise LatteError("forward_with_cfg expects the doubled batch [2b, ...] (sample.py:88-94)")
         eng = self.engine(B)
+        self._set_text(text_embedding, B)
         out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
                           device=x32.device, dtype=torch.float32)
         with torch.cuda.device(x32.device):

@@ -84,6 +84,22 @@ def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 1000
 
 
 # ----------------------------------------------------------------------------- weights
+TEXT_TOKENS, TEXT_DIM = 77, 768          # latte.py:241: nn.Linear(77 * 768, hidden_size)
+
+
+def text_projection_weight(D: int, seed: int = 0, scale: float = 0.01) -> torch.Tensor:
+    """[D, 77*768] weight of ``text_embedding_projection`` (latte.py:238-242) from a closed-form integer hash, so that
+    golden fixtures need not store 30+ MB: value(i) = (lcg(i + seed * 2^32) >> 40) / 2^23 - 1, times ``scale``.
+    uint64 wrap-around arithmetic in numpy is exact and platform independent."""
+    n = D * TEXT_TOKENS * TEXT_DIM
+    i = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(1 << 32)
+    h = i * np.uint64(6364136223846793005) + np.uint64(1442695040888963407)
+    h ^= h >> np.uint64(29)
+    h = h * np.uint64(0xBF58476D1CE4E5B9)
+    v = (h >> np.uint64(40)).astype(np.float64) / float(1 << 23) - 1.0
+    return torch.from_numpy((v * scale).astype(np.float32)).reshape(D, TEXT_TOKENS * TEXT_DIM)
+
+
 def init_state_dict(cfg: LatteConfig, seed: int = 0, gate_std: float = 0.02) -> dict:
     """Synthetic reference-format weights.  Same *distributions* as ``initialize_weights``
     (latte.py:257-295) but NOT the same RNG stream; every tensor the reference zero-inits
@@ -110,6 +126,9 @@ def init_state_dict(cfg: LatteConfig, seed: int = 0, gate_std: float = 0.02) -> 
     sd["t_embedder.mlp.2.bias"] = normal(D)
     if cfg.extras == 2:
         sd["y_embedder.embedding_table.weight"] = normal(cfg.num_classes + 1, D)
+    if cfg.extras == 78:
+        sd["text_embedding_projection.1.weight"] = text_projection_weight(D, seed)
+        sd["text_embedding_projection.1.bias"] = normal(D)
     for i in range(cfg.depth):
         pre = f"blocks.{i}."
         sd[pre + "attn.qkv.weight"] = xavier(3 * D, D)
@@ -164,9 +183,9 @@ def _block(sd, i, x, c, num_heads):
     return x + g2.unsqueeze(1) * h
 
 
-def latte_forward(sd: dict, cfg: LatteConfig, x: torch.Tensor, t: torch.Tensor, y=None) -> torch.Tensor:
-    """``Latte.forward`` (latte.py:314-377), fp32.  x:[B,F,C,H,W], t:int64[B], y:int64[B]|None
-    -> [B,F,out_channels,H,W]."""
+def latte_forward(sd: dict, cfg: LatteConfig, x: torch.Tensor, t: torch.Tensor, y=None, text_embedding=None) -> torch.Tensor:
+    """``Latte.forward`` (latte.py:314-377), fp32.  x:[B,F,C,H,W], t:int64[B], y:int64[B]|None,
+    text_embedding:[B,77,768]|None (extras == 78)  -> [B,F,out_channels,H,W]."""
     B, Fr, C, H, W = x.shape
     p, D = cfg.patch_size, cfg.hidden_size
     T = (H // p) * (W // p)
@@ -176,9 +195,15 @@ def latte_forward(sd: dict, cfg: LatteConfig, x: torch.Tensor, t: torch.Tensor, 
     temb = timestep_embedding(t, 256)                                                       # :332
     temb = F.linear(temb, sd["t_embedder.mlp.0.weight"], sd["t_embedder.mlp.0.bias"])
     temb = F.linear(F.silu(temb), sd["t_embedder.mlp.2.weight"], sd["t_embedder.mlp.2.bias"])
-    c = temb
+    c = c_final = temb
     if cfg.extras == 2:
-        c = temb + sd["y_embedder.embedding_table.weight"][y]                               # :337,:348
+        c = c_final = temb + sd["y_embedder.embedding_table.weight"][y]                     # :337,:348,:370-371
+    elif cfg.extras == 78:
+        # :238-242,:341: Sequential(SiLU, Linear(77*768, D)) on the flattened text embedding; the blocks see
+        # t + text (:350,:363), the final layer sees t only (:372-373)
+        txt = F.linear(F.silu(text_embedding.reshape(B, -1).float()), sd["text_embedding_projection.1.weight"],
+                       sd["text_embedding_projection.1.bias"])
+        c = temb + txt
     c_spatial = c.repeat_interleave(Fr, dim=0)        # 'n d -> (n c) d', c=frames   (:333)
     c_temp = c.repeat_interleave(T, dim=0)            # 'n d -> (n c) d', c=tokens   (:334)
     h = tok
@@ -190,7 +215,7 @@ def latte_forward(sd: dict, cfg: LatteConfig, x: torch.Tensor, t: torch.Tensor, 
         h = _block(sd, i + 1, h, c_temp, cfg.num_heads)                                      # :367
         h = h.reshape(B, T, Fr, D).permute(0, 2, 1, 3).reshape(B * Fr, T, D)                 # :368
     # FinalLayer (latte.py:197-201); conditioning is t (+y), never the text embedding (:370-373)
-    mod = F.linear(F.silu(c_spatial), sd["final_layer.adaLN_modulation.1.weight"],
+    mod = F.linear(F.silu(c_final.repeat_interleave(Fr, dim=0)), sd["final_layer.adaLN_modulation.1.weight"],
                    sd["final_layer.adaLN_modulation.1.bias"])
     shift, scale = mod.chunk(2, dim=1)
     h = _modulate(F.layer_norm(h, (D,), eps=1e-6), shift, scale)
@@ -202,12 +227,12 @@ def latte_forward(sd: dict, cfg: LatteConfig, x: torch.Tensor, t: torch.Tensor, 
     return h.reshape(B, Fr, co, H, W)
 
 
-def latte_forward_with_cfg(sd, cfg, x, t, y, cfg_scale):
+def latte_forward_with_cfg(sd, cfg, x, t, y, cfg_scale, text_embedding=None):
     """``Latte.forward_with_cfg`` (latte.py:379-398): first half duplicated, guidance on the first
     4 channels only (hard-coded 4 at :394), variance channels of both halves kept."""
     half = x[: len(x) // 2]
     combined = torch.cat([half, half], dim=0)
-    out = latte_forward(sd, cfg, combined, t, y)
+    out = latte_forward(sd, cfg, combined, t, y, text_embedding)
     eps, rest = out[:, :, :4], out[:, :, 4:]
     cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
     half_eps = uncond + cfg_scale * (cond - uncond)

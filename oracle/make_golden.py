@@ -11,6 +11,7 @@ import os
 import numpy as np
 import torch
 
+from oracle import latte_oracle as lo
 from oracle.reference_loader import (load_reference_diffusion, load_reference_latte,
                                      randomize_zero_init)
 
@@ -20,6 +21,9 @@ TINY = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, n
             num_classes=5, extras=2, learn_sigma=True)
 TINY4 = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=16,
              num_classes=1000, extras=1, learn_sigma=True)
+
+TINY78 = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=4,
+              num_classes=1000, extras=78, learn_sigma=True)
 
 TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
           "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
@@ -60,6 +64,11 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
         for n_, p_ in model.named_parameters():
             if n_.endswith(".bias") and float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+    if kw["extras"] == 78:
+        # the [D, 59136] text projection comes from a closed-form hash (oracle.latte_oracle.text_projection_weight)
+        # and is NOT stored in the fixture; tests rebuild it from text_w_seed
+        with torch.no_grad():
+            model.text_embedding_projection[1].weight.copy_(lo.text_projection_weight(kw["hidden_size"], seed))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = torch.Generator("cpu").manual_seed(seed + 3)
     B, Fr, C, S = 2, kw["num_frames"], 4, kw["input_size"]
@@ -67,7 +76,10 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
     t = torch.tensor([999, 37], dtype=torch.int64)
     out = {"cfg_json": np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8)}
     for k, v in sd.items():
-        out["sd::" + k] = v.numpy()
+        if k != "text_embedding_projection.1.weight":
+            out["sd::" + k] = v.numpy()
+    if kw["extras"] == 78:
+        out["text_w_seed"] = np.int64(seed)
     out["x"] = x.numpy()
     out["t"] = t.numpy()
     with torch.no_grad():
@@ -81,6 +93,15 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
             out["x_cfg"], out["y_cfg"] = xc.numpy(), yc.numpy()
             out["cfg_scale"] = np.float32(7.0)
             out["forward_with_cfg"] = model.forward_with_cfg(xc, t, y=yc, cfg_scale=7.0).numpy()
+        elif kw["extras"] == 78:
+            # text-conditioned variant (latte.py:238-242,340-363): [B,77,768] embeddings, guidance batch = [text, null text]
+            te = torch.randn(B, 77, 768, generator=g)
+            out["text_embedding"] = te.numpy()
+            out["forward"] = model(x, t, text_embedding=te).numpy()
+            xc = torch.cat([x[:1], x[:1]], 0)
+            out["x_cfg"] = xc.numpy()
+            out["cfg_scale"] = np.float32(7.0)
+            out["forward_with_cfg"] = model.forward_with_cfg(xc, t, cfg_scale=7.0, text_embedding=te).numpy()
         else:
             out["forward"] = model(x, t).numpy()
 
@@ -91,11 +112,13 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
             z = out["x_cfg"]
             z = torch.from_numpy(z)
             fn = model.forward_with_cfg
-            mk = dict(y=torch.from_numpy(out["y_cfg"]), cfg_scale=7.0)
+            mk = (dict(y=torch.from_numpy(out["y_cfg"]), cfg_scale=7.0) if kw["extras"] == 2
+                  else dict(text_embedding=te, cfg_scale=7.0))
         else:
             z = x
             fn = model.forward
-            mk = dict(y=torch.from_numpy(out["y"])) if kw["extras"] == 2 else dict(y=None)
+            mk = (dict(y=torch.from_numpy(out["y"])) if kw["extras"] == 2
+                  else dict(text_embedding=te) if kw["extras"] == 78 else dict(y=None))
         out["loop_steps"] = np.int64(steps)
         for method, gen in (("ddim", diff.ddim_sample_loop_progressive), ("ddpm", diff.p_sample_loop_progressive)):
             torch.manual_seed(seed + 10)
@@ -121,6 +144,7 @@ def main():
     schedules(rd)
     tiny_model(rl, rd, "tiny_classcond", TINY, use_cfg=True, seed=100)
     tiny_model(rl, rd, "tiny_uncond", TINY4, use_cfg=False, seed=200)
+    tiny_model(rl, rd, "tiny_textcond", TINY78, use_cfg=True, seed=300)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

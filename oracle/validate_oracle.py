@@ -35,7 +35,8 @@ def main():
     # --- denoiser
     cases = [("Latte-S/2 F=4 latent 8x8 class-cond", "Latte-S/2", dict(input_size=8, num_frames=4, num_classes=101, extras=2)),
              ("Latte-S/2 F=4 latent 16x16 uncond", "Latte-S/2", dict(input_size=16, num_frames=4, extras=1)),
-             ("Latte-B/2 F=16 latent 8x8 uncond", "Latte-B/2", dict(input_size=8, num_frames=16, extras=1))]
+             ("Latte-B/2 F=16 latent 8x8 uncond", "Latte-B/2", dict(input_size=8, num_frames=16, extras=1)),
+             ("Latte-S/2 F=4 latent 8x8 text-cond (extras=78)", "Latte-S/2", dict(input_size=8, num_frames=4, extras=78))]
     if "--xl" in sys.argv:
         cases.append(("Latte-XL/2 F=16 latent 32x32 class-cond", "Latte-XL/2",
                       dict(input_size=32, num_frames=16, num_classes=101, extras=2)))
@@ -50,29 +51,30 @@ def main():
         x = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
         t = torch.tensor([999, 12][:B])
         y = torch.tensor([7, 101][:B]) if kw["extras"] == 2 else None
+        te = torch.randn(B, 77, 768, generator=g) if kw["extras"] == 78 else None
         with torch.no_grad():
-            t0 = time.time(); ref = model(x, t, y=y); t_ref = time.time() - t0
-            t0 = time.time(); ora = lo.latte_forward(sd, cfg, x, t, y); t_or = time.time() - t0
+            t0 = time.time(); ref = model(x, t, y=y, text_embedding=te); t_ref = time.time() - t0
+            t0 = time.time(); ora = lo.latte_forward(sd, cfg, x, t, y, te); t_or = time.time() - t0
         rows.append((f"{title}: forward", f"rel-L2 {rel(ora, ref):.2e}, max|d| {float((ora-ref).abs().max()):.2e} (ref {t_ref:.2f}s, oracle {t_or:.2f}s)"))
         assert rel(ora, ref) < 1e-5
-        if kw["extras"] == 2 and B == 2:
+        if kw["extras"] in (2, 78) and B == 2:
             with torch.no_grad():
                 xc = torch.cat([x[:1], x[:1]])
-                refc = model.forward_with_cfg(xc, t, y=y, cfg_scale=7.0)
-                orac = lo.latte_forward_with_cfg(sd, cfg, xc, t, y, 7.0)
+                refc = model.forward_with_cfg(xc, t, y=y, cfg_scale=7.0, text_embedding=te)
+                orac = lo.latte_forward_with_cfg(sd, cfg, xc, t, y, 7.0, te)
             rows.append((f"{title}: forward_with_cfg(7.0)", f"rel-L2 {rel(orac, refc):.2e}"))
             assert rel(orac, refc) < 1e-5
         if name == "Latte-S/2" and kw["input_size"] == 8:
             for method in ("ddim", "ddpm"):
                 steps = 10
                 d = rd.create_diffusion(str(steps)); s = do.Schedule(str(steps))
-                mk = dict(y=y)
+                mk = dict(y=y, text_embedding=te) if te is not None else dict(y=y)
                 torch.manual_seed(5); noises = [torch.randn_like(x) for _ in range(steps)]
                 torch.manual_seed(5)
                 with torch.no_grad():
                     loop = d.ddim_sample_loop if method == "ddim" else d.p_sample_loop
                     refs = loop(model.forward, x.shape, x, clip_denoised=False, model_kwargs=mk, device="cpu")
-                    oras = do.sample_loop(s, lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt, y), x, method=method, noises=noises)
+                    oras = do.sample_loop(s, lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt, y, te), x, method=method, noises=noises)
                 rows.append((f"{title}: {method.upper()}-{steps} loop final latents", f"rel-L2 {rel(oras, refs):.2e}"))
                 assert rel(oras, refs) < 1e-5
     with open("oracle/VALIDATION.md", "w") as f:

@@ -20,6 +20,9 @@ def load_golden_model(name):
     kw = json.loads(bytes(z["cfg_json"]).decode())
     sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
     rest = {k: z[k] for k in z.files if not k.startswith("sd::") and k != "cfg_json"}
+    if "text_w_seed" in rest:   # extras == 78: the [D, 77*768] projection is a closed-form hash, not stored (oracle/make_golden.py)
+        from oracle.latte_oracle import text_projection_weight
+        sd["text_embedding_projection.1.weight"] = text_projection_weight(kw["hidden_size"], int(rest["text_w_seed"]))
     return kw, sd, rest
 
 
