@@ -39,6 +39,13 @@ enum GemmEpi : int {
   EPI_BIAS_F32 = 3,       // out(fp32) = acc + bias
   EPI_ABLATE_NOSTORE = 4, // measurement only: bias add, nothing written (persistent kernel only)
   EPI_BIAS_RES_H16 = 5,   // out(half) = acc + bias + res(half)[m,n]   (plain kernel only; VAE attention out-proj)
+  // measurement only, persistent kernel only, nothing written: main-loop ablations (results are garbage)
+  EPI_ABLATE_NODMA = 6,     // no operand DMA inside the K loop
+  EPI_ABLATE_NOLDSREAD = 7, // fragments read from LDS once, then reused
+  EPI_ABLATE_NOMFMA = 8,    // DMA + fragment reads, no MFMA
+  EPI_ABLATE_HOTSRC = 9,    // every K tile's DMA reads K tile 0 again (cache-hot source)
+  EPI_ABLATE_DMA_A = 10,    // only the A operand is DMA'd in the loop
+  EPI_ABLATE_DMA_B = 11,    // only the B operand is DMA'd in the loop
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)

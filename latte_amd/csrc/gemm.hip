@@ -36,7 +36,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4& a
   const float4 b4 = *(const float4*)(g.bias + n);
   float v0 = a[0] + b4.x, v1 = a[1] + b4.y, v2 = a[2] + b4.z, v3 = a[3] + b4.w;
   const size_t o = (size_t)m * g.N + n;
-  if constexpr (EPI == EPI_ABLATE_NOSTORE) {
+  if constexpr (EPI == EPI_ABLATE_NOSTORE || EPI >= EPI_ABLATE_NODMA) {
     asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
   } else if constexpr (EPI == EPI_BIAS_RES_H16) {
     const u32x2 r2 = *(const u32x2*)(g.res + o);
@@ -580,6 +580,10 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   // (Tiles with rows >= M, and waves whose columns lie beyond N, take the plain vmcnt(0) path.)
   int it = 0;
   bool counted = false;   // the DMA needed by this iteration was issued before an epilogue that loaded and used data
+  // main-loop ablations (measurement only)
+  constexpr bool NO_DMA = EPI == EPI_ABLATE_NODMA, NO_LDSR = EPI == EPI_ABLATE_NOLDSREAD, NO_MFMA = EPI == EPI_ABLATE_NOMFMA;
+  u32x4 hold_b[NO_LDSR ? 2 : 1][NO_LDSR ? FN : 1], hold_a[NO_LDSR ? 2 : 1][NO_LDSR ? 8 : 1];
+  constexpr bool DO_A = EPI != EPI_ABLATE_DMA_B, DO_B = EPI != EPI_ABLATE_DMA_A;
   for (;;) {
     const int npos = pos + per;
     const bool has_next = npos < cnt;
@@ -588,45 +592,77 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
     const bool full_rows = (tm + 1) * BM <= g.M;
 
     for (int kt = 0; kt < nk; ++kt, ++it) {
+      // (scalar bookkeeping of this iteration first: it then runs under the fragment reads, not between the last MFMA
+      //  and the barrier that releases the other group)
+      const bool last = kt + 1 == nk;
+      const bool in_tile = kt + 2 < nk;
+      const bool do_dma = !NO_DMA && (in_tile || has_next);
+      const int stm = in_tile ? tm : ntm, stn = in_tile ? tn : ntn;
+      const int skt = EPI == EPI_ABLATE_HOTSRC ? 0 : in_tile ? kt + 2 : kt + 2 - nk;
       const char* sbuf = smem + (it & 1) * STAGE;
       u32x4 bf[2][FN], af[2][8];
+      if (!NO_LDSR || it == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+          for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+          for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+        }
+      }
+
+      if constexpr (NO_LDSR) {   // ablation: keep the first K tile's fragments
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) { if (it == 0) hold_b[ks][j] = bf[ks][j]; else bf[ks][j] = hold_b[ks][j]; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { if (it == 0) hold_a[ks][i] = af[ks][i]; else af[ks][i] = hold_a[ks][i]; }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (NO_MFMA) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+          for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bf[ks][j]));
 #pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+          for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(af[ks][i]));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+      }
       __builtin_amdgcn_s_setprio(0);
       // DMA(u+1) must have landed.  After a tile boundary it provably has: the epilogue began with global loads
       // (bias / residual) that were issued AFTER DMA(u) and DMA(u+1) and were consumed before its first store, and
       // vmcnt retires in issue order -- so no wait here, and the epilogue's stores keep draining under this tile.
       if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = false;
-      // K tile u+2: same tile, or the next tile's K tile kt + 2 - nk
-      const bool last = kt + 1 == nk;
-      const bool in_tile = kt + 2 < nk;
-      const bool do_dma = in_tile || has_next;
-      const int stm = in_tile ? tm : ntm, stn = in_tile ? tn : ntn, skt = in_tile ? kt + 2 : kt + 2 - nk;
-      if (grp == 1) {
-        if (do_dma) dma_a_half(stm, skt, it & 1);
-        asm volatile("" ::: "memory");   // the epilogue's loads must stay BEHIND the DMA issue (in-order vmcnt argument)
-        if (last) epilogue(tm, tn);
+      // K tile u+2 (same tile, or the next tile's K tile kt + 2 - nk) into the stage just consumed.
+      // Group 1's own A rows may be overwritten as soon as its L(u) is done, but the issue (4 buffer loads per wave,
+      // which stall when the address unit's queue is full) must not sit between its last MFMA and the barrier that
+      // releases group 0's compute segment.  So it follows the barrier -- except at a tile boundary, where it has to
+      // precede the epilogue (in-order vmcnt argument above).
+      if (grp == 1 && last) {
+        if (do_dma && DO_A) dma_a_half(stm, skt, it & 1);
+        asm volatile("" ::: "memory");   // the epilogue's loads must stay BEHIND the DMA issue
+        epilogue(tm, tn);
       }
       __builtin_amdgcn_s_barrier();
+      if (grp == 1 && !last) {
+        if (do_dma && DO_A) dma_a_half(stm, skt, it & 1);
+      }
       if (grp == 0) {
         if (do_dma) {
-          dma_a_half(stm, skt, it & 1);
-          dma_b_all(stn, skt, it & 1);
+          if (DO_A) dma_a_half(stm, skt, it & 1);
+          if (DO_B) dma_b_all(stn, skt, it & 1);
         }
         asm volatile("" ::: "memory");
         if (last) epilogue(tm, tn);
@@ -670,6 +706,12 @@ int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
     LATTE_GEMM_CASE(EPI_GATE_RES_F32)
     LATTE_GEMM_CASE(EPI_BIAS_F32)
     LATTE_GEMM_CASE(EPI_ABLATE_NOSTORE)
+    LATTE_GEMM_CASE(EPI_ABLATE_NODMA)
+    LATTE_GEMM_CASE(EPI_ABLATE_NOLDSREAD)
+    LATTE_GEMM_CASE(EPI_ABLATE_NOMFMA)
+    LATTE_GEMM_CASE(EPI_ABLATE_HOTSRC)
+    LATTE_GEMM_CASE(EPI_ABLATE_DMA_A)
+    LATTE_GEMM_CASE(EPI_ABLATE_DMA_B)
     default:
       return fail(LATTE_ERR_INVALID, "gemm: unknown epilogue");
   }

@@ -285,6 +285,20 @@ def gemm_epi_ablation():
         log(f"epi_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
 
 
+def gemm_loop_ablation():
+    """Main-loop ablations of the persistent kernel (no stores in all of them): 4 = full loop, 6 = no DMA in the loop,
+    7 = no LDS fragment reads, 8 = no MFMA, 9 = DMA from a cache-hot source, 10 / 11 = only A / only B DMA'd."""
+    ms = _lib.c_f32()
+    for (M, N, K, variant) in [(8192, 4096, 4096, 9), (32768, 4608, 1152, 9), (32768, 1152, 4608, 8), (8192, 4608, 4096, 8)]:
+        row = []
+        check(lib.latte_bench_gemm(M, N, K, 4, 0, variant, 20, ctypes.byref(ms), stream_ptr()))   # warm-up (clocks)
+        for epi in (4, 6, 7, 8, 9, 10, 11):
+            check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
+            tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+            row.append(f"epi{epi}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
+        log(f"loop_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
+
+
 def gemm_in_model():
     """Per-GEMM tile variants measured INSIDE the XL/2 forward (cache state of the real pipeline), B = 8 and 2."""
     from latte_amd.models import Latte_models
