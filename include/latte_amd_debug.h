@@ -45,6 +45,12 @@ struct latte_vae;
 int latte_debug_vae_trace(struct latte_vae* v, const float* z, int n_frames, float z_scale, int stop_after, float* trace_out,
                           int64_t* trace_numel, int* trace_dims, void* stream);
 
+/* Operand-path probe (measurement): 256 workgroups x `waves` waves, every wave issues `reps` bursts of 16 loads over a
+ * cache-hot 16 KB window of `src` (>= 8 MiB readable).  mode 0: buffer_load_dwordx4 ... lds, 1: buffer_load_dword ... lds,
+ * 2: global_load_dwordx4 into registers, 3: 2 + ds_write_b128.  out: int64 [8][2] = {issue ticks, landed ticks} of
+ * workgroup 0 (s_memtime ticks, summed over the bursts). */
+int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, int reps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),
     "latte_debug_fill_normal": (c_int, [c_void, c_i64, c_u64, c_u64, c_void]),
     "latte_debug_tr16_probe": (c_int, [c_void, c_void]),
+    "latte_debug_dma_probe": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
     "latte_debug_conv3x3": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void]),
     "latte_debug_vae_trace": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_void, c_void]),

@@ -46,6 +46,8 @@ enum GemmEpi : int {
   EPI_ABLATE_HOTSRC = 9,    // every K tile's DMA reads K tile 0 again (cache-hot source)
   EPI_ABLATE_DMA_A = 10,    // only the A operand is DMA'd in the loop
   EPI_ABLATE_DMA_B = 11,    // only the B operand is DMA'd in the loop
+  EPI_ABLATE_TRACE = 12,    // full loop, no stores; workgroup 0 writes per-wave phase times (s_memtime ticks) to `out`:
+                            // int64 [8 waves][8] = {L, barrier-1 wait, C issue, vmcnt wait, barrier-2 wait, DMA issue, total, K tiles}
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)

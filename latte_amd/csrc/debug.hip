@@ -15,10 +15,135 @@ __global__ void tr16_probe_kernel(uint16_t* out) {
   u16x4 u = __builtin_bit_cast(u16x4, v);
   for (int j = 0; j < 4; ++j) out[lane * 4 + j] = u[j];
 }
+
+// ---- operand-path probe: how fast can the waves of one CU move L2-resident data towards LDS / VGPRs?
+// mode 0: buffer_load_dwordx4 ... lds (16 B per lane straight into LDS), 1: buffer_load_dword ... lds (4 B per lane),
+// 2: global_load_dwordx4 into VGPRs (no LDS), 3: global_load_dwordx4 + ds_write_b128.
+// Every wave issues `reps` bursts of 16 instructions over its own 16 KB source window (cache-hot) and reports the
+// ticks (s_memtime) it spent ISSUING them and the ticks until they had all landed.
+typedef __attribute__((address_space(3))) void lds_void_t;
+__global__ void __launch_bounds__(512) dma_probe_kernel(const char* src, long long* out, int mode, int reps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1u << 30, 0x00020000);
+  char* my = smem + wave * 16384;
+  const unsigned base = ((blockIdx.x & 63) * 8 + wave) * 16384u;
+  long long t_issue = 0, t_all = 0;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  u4 sink = {0, 0, 0, 0};
+  __syncthreads();
+  if (mode >= 7 && mode <= 9 && wave >= 4) {
+    // companion waves (one per SIMD next to a DMA wave): back-to-back MFMAs like a GEMM compute segment.
+    // mode 7: at s_setprio 1, mode 8: default priority, mode 9: default priority while the DMA waves run at priority 3
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    bf8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(lane + i); b[i] = (__bf16)(float)(lane - i); }
+    f4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (mode == 7) __builtin_amdgcn_s_setprio(1);
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    for (int r = 0; r < reps * 3; ++r) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    __builtin_amdgcn_s_setprio(0);
+    f4 sum = acc[0];
+    for (int i = 1; i < 16; ++i) sum += acc[i];
+    if (lane == 0 && blockIdx.x == 0) {
+      out[wave * 2] = t1 - t0;             // ticks for reps * 3 * 64 MFMAs
+      out[wave * 2 + 1] = (long long)reps * 3 * 64;
+    }
+    if (sum[0] == 12345.f) out[101] = 1;
+    return;
+  }
+  if (mode == 9) __builtin_amdgcn_s_setprio(3);
+  const int dmode = (mode >= 7 && mode <= 9) ? 0 : mode;
+  for (int r = 0; r < reps; ++r) {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    if (dmode == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 1024), 16, lane * 16u, base + j * 1024u, 0, 0);
+    } else if (dmode == 1) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 256), 4, lane * 4u, base + j * 256u, 0, 0);
+    } else if (dmode == 10 || dmode == 11) {
+      // the GEMM's operand pattern: per instruction 8 rows x 128 B (row pitch 2304 B), K tile r of an own 256-row panel,
+      // a new panel every 18 K tiles: never TCP-resident.  mode 11: all workgroups of an XCD share 4 panels (L2 reuse).
+      const unsigned panel = (dmode == 10 ? blockIdx.x : (blockIdx.x & 7) * 4 + ((blockIdx.x >> 3) & 3)) + 256u * ((unsigned)r / 18u % 4u);
+      const unsigned so = panel * 256u * 2304u + (unsigned)(r % 18) * 128u + (unsigned)(wave & 3) * 8u * 2304u;
+      const unsigned vo = (unsigned)(lane >> 3) * 2304u + (unsigned)(lane & 7) * 16u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 1024), 16, vo, so + (unsigned)j * 32u * 2304u, 0, 0);
+    } else if (dmode == 4) {   // one M0 value for the whole burst (same LDS destination), only the source moves
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)my, 16, lane * 16u, base + j * 1024u, 0, 0);
+    } else if (dmode == 5) {   // one M0 value, LDS destination and source moved by the instruction's immediate offset
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 4096), 16, lane * 16u, base + j * 4096u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 4096), 16, lane * 16u, base + j * 4096u, 1024, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 4096), 16, lane * 16u, base + j * 4096u, 2048, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(my + j * 4096), 16, lane * 16u, base + j * 4096u, 3072, 0);
+      }
+    } else if (dmode == 6) {   // global_load ... lds (flat-global addressing) instead of the buffer form
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + j * 1024 + lane * 16),
+                                         (lds_void_t*)(my + j * 1024), 16, 0, 0);
+    } else {
+      u4 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = *(const u4*)(src + base + j * 1024 + lane * 16);
+      const long long t1 = (long long)__builtin_readcyclecounter();   // (forces the loads to have been ISSUED only)
+      t_issue += t1 - t0;
+      if (dmode == 3) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *(u4*)(my + j * 1024 + lane * 16) = v[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sink += v[j];
+      }
+      t_all += (long long)__builtin_readcyclecounter() - t0;
+      continue;
+    }
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t_issue += t1 - t0;
+    t_all += (long long)__builtin_readcyclecounter() - t0;
+  }
+  if (lane == 0 && blockIdx.x == 0) {
+    out[wave * 2] = t_issue;
+    out[wave * 2 + 1] = t_all;
+  }
+  if (sink[0] == 0x12345678u && sink[1] == 1u) out[100] = sink[2];
+}
 }  // namespace
 
 using namespace latte;
 extern "C" {
+
+// out: int64 [8 waves][2] = {ticks spent issuing, ticks until landed}, each summed over `reps` bursts of 16 instructions.
+int latte_debug_dma_probe(const void* src_1gib_window, long long* out, int mode, int waves, int reps, void* stream) {
+  if (waves < 1 || waves > 8) return fail(LATTE_ERR_INVALID, "dma_probe: waves must be 1..8");
+  static bool attr_done = false;
+  if (!attr_done) {
+    LATTE_HIP(hipFuncSetAttribute((const void*)dma_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(dma_probe_kernel, dim3(256), dim3(64 * waves), 8 * 16384, (hipStream_t)stream, (const char*)src_1gib_window,
+                     out, mode, reps);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
 
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N, int K,
                      int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream) {

@@ -410,19 +410,21 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   };
   const unsigned off_main = lane_off(wn * 8);   // rows wn*8 + 32 j (32 j does not move the swizzle)
 
+  unsigned step32 = 32u * row_bytes;   // 32 rows further: one instruction step of a 4-wave DMA
+  asm volatile("" : "+s"(step32));     // opaque: keeps the per-instruction offsets as one s_add each (not s_mul)
   // own 128 A rows of K tile kt of tile-row tm_: row-groups wn + 4 j
   auto dma_a_half = [&](int tm_, int kt, int stg) {
     char* sA = smem + stg * STAGE + grp * 128 * 128 + wn * 1024;
     const unsigned so = (unsigned)(tm_ * BM + grp * 128 + wn * 8) * row_bytes + (unsigned)kt * 128u;
 #pragma unroll
-    for (int j = 0; j < AH_INSTR; ++j) bload_lds16(rsA, sA + j * 4 * 1024, off_main, so + (unsigned)(32 * j) * row_bytes);
+    for (int j = 0; j < AH_INSTR; ++j) bload_lds16(rsA, sA + j * 4 * 1024, off_main, so + (unsigned)j * step32);
   };
   // whole B tile by ONE group's 4 waves
   auto dma_b_all = [&](int tn_, int kt, int stg) {
     char* sB = smem + stg * STAGE + A_BYTES + wn * 1024;
     const unsigned so = (unsigned)(tn_ * BN + wn * 8) * row_bytes + (unsigned)kt * 128u;
 #pragma unroll
-    for (int j = 0; j < BG_INSTR; ++j) bload_lds16(rsB, sB + j * 4 * 1024, off_main, so + (unsigned)(32 * j) * row_bytes);
+    for (int j = 0; j < BG_INSTR; ++j) bload_lds16(rsB, sB + j * 4 * 1024, off_main, so + (unsigned)j * step32);
   };
 
   const int sw = (lane >> 1) & 7;
@@ -584,6 +586,15 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   constexpr bool NO_DMA = EPI == EPI_ABLATE_NODMA, NO_LDSR = EPI == EPI_ABLATE_NOLDSREAD, NO_MFMA = EPI == EPI_ABLATE_NOMFMA;
   u32x4 hold_b[NO_LDSR ? 2 : 1][NO_LDSR ? FN : 1], hold_a[NO_LDSR ? 2 : 1][NO_LDSR ? 8 : 1];
   constexpr bool DO_A = EPI != EPI_ABLATE_DMA_B, DO_B = EPI != EPI_ABLATE_DMA_A;
+  constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
+  if constexpr (TRACE) tstart = tprev = (long long)__builtin_readcyclecounter();
+#define LATTE_TS(IDX)                                                \
+  if constexpr (TRACE) {                                             \
+    const long long now_ = (long long)__builtin_readcyclecounter();  \
+    tacc[IDX] += now_ - tprev;                                       \
+    tprev = now_;                                                    \
+  }
   for (;;) {
     const int npos = pos + per;
     const bool has_next = npos < cnt;
@@ -621,7 +632,9 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      LATTE_TS(0)
       __builtin_amdgcn_s_barrier();
+      LATTE_TS(1)
       __builtin_amdgcn_s_setprio(1);
       if constexpr (NO_MFMA) {
 #pragma unroll
@@ -640,11 +653,13 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
             for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
       }
       __builtin_amdgcn_s_setprio(0);
+      LATTE_TS(2)
       // DMA(u+1) must have landed.  After a tile boundary it provably has: the epilogue began with global loads
       // (bias / residual) that were issued AFTER DMA(u) and DMA(u+1) and were consumed before its first store, and
       // vmcnt retires in issue order -- so no wait here, and the epilogue's stores keep draining under this tile.
       if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       counted = false;
+      LATTE_TS(3)
       // K tile u+2 (same tile, or the next tile's K tile kt + 2 - nk) into the stage just consumed.
       // Group 1's own A rows may be overwritten as soon as its L(u) is done, but the issue (4 buffer loads per wave,
       // which stall when the address unit's queue is full) must not sit between its last MFMA and the barrier that
@@ -656,6 +671,7 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
         epilogue(tm, tn);
       }
       __builtin_amdgcn_s_barrier();
+      LATTE_TS(4)
       if (grp == 1 && !last) {
         if (do_dma && DO_A) dma_a_half(stm, skt, it & 1);
       }
@@ -668,11 +684,22 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
         if (last) epilogue(tm, tn);
       }
       if (last) counted = do_dma && full_rows && (tn * BN + wn * WTN < g.N);
+      LATTE_TS(5)
     }
     if (!has_next) break;
     pos = npos; tm = ntm; tn = ntn;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+#undef LATTE_TS
+  if constexpr (TRACE) {   // phase times of workgroup 0 (tools/gpu_first_light.py gemm_trace)
+    if (blockIdx.x == 0 && lane == 0) {
+      long long* o = (long long*)g.out + wave * 8;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+      o[6] = (long long)__builtin_readcyclecounter() - tstart;
+      o[7] = it;
+    }
+  }
 }
 
 template <int BN, int DT>
@@ -712,6 +739,7 @@ int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
     LATTE_GEMM_CASE(EPI_ABLATE_HOTSRC)
     LATTE_GEMM_CASE(EPI_ABLATE_DMA_A)
     LATTE_GEMM_CASE(EPI_ABLATE_DMA_B)
+    LATTE_GEMM_CASE(EPI_ABLATE_TRACE)
     default:
       return fail(LATTE_ERR_INVALID, "gemm: unknown epilogue");
   }

@@ -299,6 +299,59 @@ def gemm_loop_ablation():
         log(f"loop_ablation v{variant} M={M} N={N} K={K}: " + " | ".join(row))
 
 
+def gemm_trace():
+    """Per-wave phase times of the persistent kernel's main loop (workgroup 0), s_memtime ticks."""
+    names = ["L(reads)", "bar1 wait", "C issue", "vmcnt", "bar2 wait", "DMA issue"]
+    for (M, N, K, v) in [(32768, 4608, 1152, 9), (32768, 1152, 4608, 8)]:
+        Mp = (M + 255) // 256 * 256
+        A = torch.randn(Mp, K, device=dev).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+        out = torch.zeros(Mp * N, dtype=torch.float32, device=dev)
+        gate = torch.randn(2 * N, device=dev)
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 0, M, 12, 0, v, stream_ptr()))
+            e1.record()
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3
+        t = out.view(torch.int64)[:64].cpu().view(8, 8)
+        log(f"trace v{v} M={M} N={N} K={K}: launch {us:.1f} us; wave rows: per-K-tile ticks; total ticks, K tiles")
+        for w in range(8):
+            kt = int(t[w, 7])
+            row = " ".join(f"{names[i]} {float(t[w, i]) / kt:7.1f}" for i in range(6))
+            log(f"   wave {w} (grp {w >> 2}): {row} | total {int(t[w, 6])} ticks = {int(t[w, 6]) / us:.1f} ticks/us, {kt} K tiles, {float(t[w, 6]) / kt:.1f} ticks/K tile")
+
+
+def dma_probe():
+    """Issue / completion cost of the operand paths (cache-hot source), ticks per 1 KB (or 256 B) wave instruction."""
+    src = torch.randn(16 << 20, device=dev)           # 64 MiB window
+    out = torch.zeros(128, dtype=torch.int64, device=dev)
+    reps = 200
+    names = {0: "buffer_load x4 -> lds", 1: "buffer_load x1 -> lds", 2: "global_load x4 -> vgpr", 3: "global_load x4 + ds_write_b128",
+             4: "buffer_load x4 -> lds, one M0", 5: "buffer_load x4 -> lds, imm offsets", 6: "global_load x4 -> lds"}
+    for mode in (7, 8, 9):   # 4 DMA waves + 4 MFMA companion waves
+        for _ in range(2):
+            check(lib.latte_debug_dma_probe(ptr(src), ptr(out), mode, 8, reps, stream_ptr()))
+        torch.cuda.synchronize()
+        t = out[:16].cpu().view(8, 2).double()
+        log(f"dma_probe mode {mode} (4 DMA waves next to 4 MFMA waves; 7: MFMA at prio 1, 8: no prio, 9: DMA at prio 3): "
+            f"DMA issue {(t[:4, 0] / (reps * 16)).mean():6.1f} landed {(t[:4, 1] / (reps * 16)).mean():6.1f} ticks/instr/wave; "
+            f"MFMA {(t[4:, 0] / t[4:, 1]).mean():5.1f} ticks per MFMA (total MFMA ticks {t[4:, 0].mean():.0f}, DMA ticks {t[:4, 1].mean():.0f})")
+    names[10] = "GEMM A pattern, own panels (8 instr/burst)"
+    names[11] = "GEMM A pattern, shared panels (8 instr/burst)"
+    src = torch.randn(160 << 20, device=dev)          # 640 MiB: 1024 panels of 256 rows x 2304 B
+    for mode in (10, 11):
+        for waves in (4, 8):
+            for _ in range(2):
+                check(lib.latte_debug_dma_probe(ptr(src), ptr(out), mode, waves, reps, stream_ptr()))
+            torch.cuda.synchronize()
+            t = out[:16].cpu().view(8, 2).double() / (reps * (8 if mode >= 10 else 16))
+            log(f"dma_probe {names[mode]:32s} waves/CU {waves}: issue {t[:waves, 0].mean():7.1f} ticks/instr/wave, "
+                f"landed {t[:waves, 1].mean():7.1f} ticks/instr/wave -> CU-wide {t[:waves, 1].mean() / waves:6.1f} ticks/instr")
+
+
 def gemm_in_model():
     """Per-GEMM tile variants measured INSIDE the XL/2 forward (cache state of the real pipeline), B = 8 and 2."""
     from latte_amd.models import Latte_models
@@ -343,7 +396,7 @@ def xl_profile():
     from latte_amd.models import Latte_models
     import latte_amd
     kw = dict(input_size=32, num_frames=16, extras=1)
-    for B in (2, 8):
+    for B in [int(v) for v in os.environ.get("LATTE_FL_B", "2,8").split(",")]:
         m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, **kw)
         with torch.no_grad():
             for n_, p_ in m.named_parameters():
