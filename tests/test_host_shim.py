@@ -102,3 +102,20 @@ def test_half_dtype_selects_engine_operand_type():
     assert m.compute_dtype == "f16" and m.pos_embed.dtype == torch.float32
     m.to(torch.bfloat16)
     assert m.compute_dtype == "bf16"
+
+
+def test_avi_round_trip(tmp_path):
+    """Video hand-off (sample.py:124-126 writes .mp4 through imageio; offline: uncompressed AVI): header fields and every
+    frame survive a write / read round trip, including a width whose rows need DIB padding."""
+    import numpy as np
+    from latte_amd import read_avi, write_avi
+    for shape in [(4, 8, 8, 3), (3, 6, 7, 3), (16, 32, 30, 3)]:
+        v = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
+        path = str(tmp_path / "v.avi")
+        write_avi(path, torch.from_numpy(v), fps=8)
+        back, fps = read_avi(path)
+        assert fps == 8.0 and np.array_equal(back, v)
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and int.from_bytes(raw[4:8], "little") == len(raw) - 8
+    with pytest.raises(ValueError):
+        write_avi(str(tmp_path / "bad.avi"), np.zeros((2, 4, 4), dtype=np.uint8))
