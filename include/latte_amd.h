@@ -132,6 +132,18 @@ int latte_sampler_step(const latte_schedule_t* s, int method, int index, float e
                        const float* x, const float* model_out, const float* noise,
                        int batch, int frames, int channels, int hw /* H*W */,
                        float* sample_out, float* pred_xstart_out /* may be NULL */, void* stream);
+/* The same step with the two caller hooks of gaussian_diffusion.py:
+ *   denoised_fn (process_xstart, :316-321): call once with predict_only = 1 to get the raw x_start prediction in
+ *     pred_xstart_out, apply the function, and pass its result as pred_xstart_in (it replaces the prediction BEFORE the
+ *     clamp);
+ *   cond_fn (:345-375; the hook sees ORIGINAL timesteps, respace.py:100-104): pass cond_grad = cond_fn(x, t).  DDPM
+ *     adds variance * gradient to the mean (condition_mean), DDIM shifts eps by sqrt(1 - alpha_bar) * gradient and
+ *     re-derives pred_xstart from it (condition_score).
+ * Either pointer may be NULL. */
+int latte_sampler_step_ex(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised,
+                          const float* x, const float* model_out, const float* noise, const float* pred_xstart_in,
+                          const float* cond_grad, int predict_only, int batch, int frames, int channels, int hw,
+                          float* sample_out, float* pred_xstart_out, void* stream);
 
 /* ------------------------------------------------------------------ fused sampling loop
  * Replaces gaussian_diffusion.py:423-515 p_sample_loop / :604-684 ddim_sample_loop driving the

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "latte_engine_set_text_embedding": (c_int, [c_void, c_void, c_int, c_void]),
     "latte_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void]),
     "latte_forward_with_cfg": (c_int, [c_void, c_void, c_void, c_void, c_int, c_f32, c_void, c_void]),
+    "latte_sampler_step_ex": (c_int, [c_void, c_int, c_int, c_f32, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_int,
+                                      c_int, c_int, c_int, c_void, c_void, c_void]),
     "latte_sampler_step": (c_int, [c_void, c_int, c_int, c_f32, c_int, c_void, c_void, c_void, c_int, c_int, c_int,
                                    c_int, c_void, c_void, c_void]),
     "latte_sample_loop": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_f32, c_void, c_void, c_int, c_int, c_int,

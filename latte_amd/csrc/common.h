@@ -133,10 +133,14 @@ struct SamplerCoefs {  // fp32 values of the fp64 tables at the step (gaussian_d
   float sqrt_ab_prev, dir_coef, sigma;  // ddim: sqrt(ab_prev), sqrt(1-ab_prev-sigma^2), sigma
   float nonzero;                        // 0 when index == 0
   float cfg_scale;                      // > 1: model_out is a raw doubled batch, combine here
+  float sqrt_one_minus_ab;              // condition_score: (1 - alpha_bar).sqrt() in fp32 (gd:368)
   int method, clip;
 };
+// x0_in: pred_xstart after the caller's denoised_fn (replaces the computed one BEFORE the clamp); grad: cond_fn(x, t);
+// predict_only: write the raw (unclamped) x_start prediction to x0_out and nothing else.
 int launch_sampler_update(const SamplerCoefs& c, const float* x, const float* model_out, const float* noise,
                           int batch, int frames, int channels, int hw, int raw_cfg, float* sample_out,
-                          float* x0_out, hipStream_t st);
+                          float* x0_out, hipStream_t st, const float* x0_in = nullptr, const float* grad = nullptr,
+                          int predict_only = 0);
 
 }  // namespace latte

@@ -271,6 +271,7 @@ SamplerCoefs make_coefs(const latte_schedule_t* s, int method, int i, float eta,
   c.dir_coef = std::sqrt((1.0f - abp) - sigma * sigma);  // gd:558: sqrt(1 - abp - sigma**2)
   c.nonzero = i == 0 ? 0.0f : 1.0f;
   c.cfg_scale = 1.0f;
+  c.sqrt_one_minus_ab = std::sqrt(1.0f - ab);   // gd:368 on the fp32 alpha_bar
   return c;
 }
 
@@ -523,19 +524,28 @@ int latte_forward_with_cfg(latte_engine_t* e, const float* x, const int64_t* t, 
   return launch_cfg_combine(out, batch / 2, e->F, e->Cout, e->H * e->H, cfg_scale, (hipStream_t)stream);
 }
 
-int latte_sampler_step(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised, const float* x,
-                       const float* model_out, const float* noise, int batch, int frames, int channels, int hw,
-                       float* sample_out, float* pred_xstart_out, void* stream) {
-  if (!s || !x || !model_out || !sample_out) return fail(LATTE_ERR_INVALID, "sampler_step: null argument");
+int latte_sampler_step_ex(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised, const float* x,
+                          const float* model_out, const float* noise, const float* pred_xstart_in, const float* cond_grad,
+                          int predict_only, int batch, int frames, int channels, int hw, float* sample_out,
+                          float* pred_xstart_out, void* stream) {
+  if (!s || !x || !model_out) return fail(LATTE_ERR_INVALID, "sampler_step: null argument");
+  if (predict_only ? !pred_xstart_out : !sample_out) return fail(LATTE_ERR_INVALID, "sampler_step: null output");
   if (index < 0 || index >= s->num_timesteps) return fail(LATTE_ERR_INVALID, "sampler_step: index out of range");
   if (method != LATTE_METHOD_DDPM && method != LATTE_METHOD_DDIM) return fail(LATTE_ERR_INVALID, "sampler_step: bad method");
   if (s->num_timesteps < 2) return fail(LATTE_ERR_INVALID, "sampler_step: learned-range variance needs >= 2 timesteps");
   SamplerCoefs c = make_coefs(s, method, index, eta, clip_denoised);
-  if (method == LATTE_METHOD_DDPM && index != 0 && noise == nullptr)
+  if (!predict_only && method == LATTE_METHOD_DDPM && index != 0 && noise == nullptr)
     return fail(LATTE_ERR_INVALID, "sampler_step: DDPM needs noise for index > 0");
   const bool need_noise = (method == LATTE_METHOD_DDPM) ? (index != 0) : (c.sigma != 0.0f && index != 0);
   return launch_sampler_update(c, x, model_out, need_noise ? noise : nullptr, batch, frames, channels, hw, 0, sample_out,
-                               pred_xstart_out, (hipStream_t)stream);
+                               pred_xstart_out, (hipStream_t)stream, pred_xstart_in, cond_grad, predict_only);
+}
+
+int latte_sampler_step(const latte_schedule_t* s, int method, int index, float eta, int clip_denoised, const float* x,
+                       const float* model_out, const float* noise, int batch, int frames, int channels, int hw,
+                       float* sample_out, float* pred_xstart_out, void* stream) {
+  return latte_sampler_step_ex(s, method, index, eta, clip_denoised, x, model_out, noise, nullptr, nullptr, 0, batch, frames,
+                               channels, hw, sample_out, pred_xstart_out, stream);
 }
 
 int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised,

@@ -332,7 +332,8 @@ __global__ void cfg_combine_kernel(float* out, int half_batch, int F, int Cout, 
 
 __global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ x, const float* __restrict__ mo,
                                       const float* __restrict__ noise, int batch, int frames, int C, int hw,
-                                      int raw_cfg, float* sample_out, float* x0_out) {
+                                      int raw_cfg, float* sample_out, float* x0_out, const float* __restrict__ x0_in,
+                                      const float* __restrict__ grad, int predict_only) {
 #pragma clang fp contract(off)
   // op-for-op the fp32 tensor arithmetic of gaussian_diffusion.py (no FMA contraction)
   const size_t chw = (size_t)C * hw;
@@ -354,15 +355,26 @@ __global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ 
     const float v = mo[o + chw];
     const float xv = x[i];
     float x0 = c.sqrt_recip * xv - c.sqrt_recipm1 * eps;               // gd:338-343
+    if (predict_only) {                                                // the caller applies its denoised_fn to this
+      x0_out[i] = x0;
+      continue;
+    }
+    if (x0_in != nullptr) x0 = x0_in[i];                               // process_xstart: denoised_fn, then the clamp (gd:316-321)
     if (c.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
     float s;
     if (c.method == LATTE_METHOD_DDPM) {
       const float frac = (v + 1.0f) / 2.0f;                            // gd:295
       const float log_var = frac * c.max_log + (1.0f - frac) * c.min_log;
-      const float mean = c.coef1 * x0 + c.coef2 * xv;                  // gd:232-241
+      float mean = c.coef1 * x0 + c.coef2 * xv;                        // gd:232-241
+      if (grad != nullptr) mean = mean + expf(log_var) * grad[i];      // condition_mean, gd:354-355 (variance = exp(log_var), gd:297)
       const float nz = noise != nullptr ? noise[i] : 0.0f;
       s = mean + (c.nonzero * expf(0.5f * log_var)) * nz;              // gd:420
     } else {
+      if (grad != nullptr) {                                           // condition_score, gd:366-373
+        float e = (c.sqrt_recip * xv - x0) / c.sqrt_recipm1;
+        e = e - c.sqrt_one_minus_ab * grad[i];
+        x0 = c.sqrt_recip * xv - c.sqrt_recipm1 * e;
+      }
       const float e2 = (c.sqrt_recip * xv - x0) / c.sqrt_recipm1;      // gd:545
       const float mean_pred = x0 * c.sqrt_ab_prev + c.dir_coef * e2;   // gd:556-559
       s = mean_pred;
@@ -567,10 +579,10 @@ int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, floa
 
 int launch_sampler_update(const SamplerCoefs& c, const float* x, const float* model_out, const float* noise,
                           int batch, int frames, int channels, int hw, int raw_cfg, float* sample_out, float* x0_out,
-                          hipStream_t st) {
+                          hipStream_t st, const float* x0_in, const float* grad, int predict_only) {
   const size_t n = (size_t)batch * frames * channels * hw;
   hipLaunchKernelGGL(sampler_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, c, x, model_out, noise, batch,
-                     frames, channels, hw, raw_cfg, sample_out, x0_out);
+                     frames, channels, hw, raw_cfg, sample_out, x0_out, x0_in, grad, predict_only);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -78,7 +78,11 @@ class SpacedDiffusion:
         owner = getattr(model, "__self__", model)
         return next(owner.parameters()).device                                     # gd:487-488
 
-    def _step(self, method, model_output, x, index, noise, eta, clip_denoised):
+    def _step(self, method, model_output, x, index, noise, eta, clip_denoised, denoised_fn=None, cond_fn=None,
+              model_kwargs=None):
+        """p_mean_variance + p_sample / ddim_sample of one step on the engine (gd:254-336, :380-421, :517-564), with the
+        two caller hooks: ``denoised_fn`` on the x_start prediction before the clamp (gd:316-321) and ``cond_fn(x, t)``
+        with ORIGINAL timesteps (rs:100-104; condition_mean for DDPM, condition_score for DDIM)."""
         _lib.require_gpu()
         B, F, C = x.shape[:3]
         if model_output.shape != (B, F, C * 2, *x.shape[3:]):                      # gd:290
@@ -89,10 +93,21 @@ class SpacedDiffusion:
         sample = torch.empty_like(x32)
         x0 = torch.empty_like(x32)
         hw = int(np.prod(x.shape[3:]))
+        lib = load_library()
+        args = (self._h, _METHOD[method], int(index), float(eta), int(bool(clip_denoised)), ptr(x32), ptr(mo), ptr(nz))
+        x0_in = grad = None
         with torch.cuda.device(x32.device):
-            check(load_library().latte_sampler_step(self._h, _METHOD[method], int(index), float(eta),
-                                                    int(bool(clip_denoised)), ptr(x32), ptr(mo), ptr(nz), B, F, C, hw,
-                                                    ptr(sample), ptr(x0), stream_ptr()))
+            if denoised_fn is not None:
+                check(lib.latte_sampler_step_ex(*args, None, None, 1, B, F, C, hw, None, ptr(x0), stream_ptr()))
+                x0_in = denoised_fn(x0).float().contiguous()
+                if x0_in.shape != x32.shape:
+                    raise AssertionError("denoised_fn must keep the shape of its argument")
+            if cond_fn is not None:
+                t = torch.full((B,), self.timestep_map[index], device=x32.device, dtype=torch.int64)
+                grad = cond_fn(x, t, **(model_kwargs or {})).float().contiguous()
+                if grad.shape != x32.shape:
+                    raise AssertionError("cond_fn must return a gradient of x's shape")
+            check(lib.latte_sampler_step_ex(*args, ptr(x0_in), ptr(grad), 0, B, F, C, hw, ptr(sample), ptr(x0), stream_ptr()))
         return {"sample": sample, "pred_xstart": x0}
 
     def _call_model(self, model, x, index, model_kwargs):
@@ -105,22 +120,16 @@ class SpacedDiffusion:
 
     # ------------------------------------------------------------------ single steps (gd:380-421, :517-564)
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
-        self._no_hooks(denoised_fn, cond_fn)
         index = self._uniform_index(t)
         out = self._call_model(model, x, index, model_kwargs or {})
-        return self._step("ddpm", out, x, index, torch.randn_like(x.float()), 0.0, clip_denoised)
+        return self._step("ddpm", out, x, index, torch.randn_like(x.float()), 0.0, clip_denoised, denoised_fn, cond_fn,
+                          model_kwargs)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
-        self._no_hooks(denoised_fn, cond_fn)
         index = self._uniform_index(t)
         out = self._call_model(model, x, index, model_kwargs or {})
-        return self._step("ddim", out, x, index, torch.randn_like(x.float()), eta, clip_denoised)
-
-    @staticmethod
-    def _no_hooks(denoised_fn, cond_fn):
-        if denoised_fn is not None or cond_fn is not None:
-            raise LatteError("denoised_fn / cond_fn hooks are not part of the accelerated sampling path "
-                             "(sample.py never passes them)")
+        return self._step("ddim", out, x, index, torch.randn_like(x.float()), eta, clip_denoised, denoised_fn, cond_fn,
+                          model_kwargs)
 
     @staticmethod
     def _uniform_index(t):
@@ -133,7 +142,6 @@ class SpacedDiffusion:
     # ------------------------------------------------------------------ loops (gd:423-515, :604-684)
     def _loop(self, method, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               eta, progressive):
-        self._no_hooks(denoised_fn, cond_fn)
         _lib.require_gpu()
         model_kwargs = dict(model_kwargs or {})
         device = self._device(model, device)
@@ -144,7 +152,7 @@ class SpacedDiffusion:
         needs_noise = method == "ddpm" or eta != 0.0
         owner, uses_cfg = self._engine_model(model)
         known = {"y", "use_fp16", "cfg_scale", "text_embedding"}
-        if owner is not None and set(model_kwargs) <= known:
+        if owner is not None and set(model_kwargs) <= known and denoised_fn is None and cond_fn is None:
             # ---- whole chain inside the engine
             B = img.shape[0]
             y = model_kwargs.get("y")
@@ -179,7 +187,7 @@ class SpacedDiffusion:
         for i in indices:
             out = self._call_model(model, img, i, model_kwargs)
             nz = torch.randn_like(img) if needs_noise else None
-            r = self._step(method, out, img, i, nz, eta, clip_denoised)
+            r = self._step(method, out, img, i, nz, eta, clip_denoised, denoised_fn, cond_fn, model_kwargs)
             yield r
             img = r["sample"]
 

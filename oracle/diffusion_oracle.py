@@ -88,9 +88,10 @@ def _coef(arr: np.ndarray, i: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- per-step math
-def p_mean_variance(s: Schedule, model_out: torch.Tensor, x: torch.Tensor, i: int, clip_denoised=False):
+def p_mean_variance(s: Schedule, model_out: torch.Tensor, x: torch.Tensor, i: int, clip_denoised=False, denoised_fn=None):
     """gd:254-336, EPSILON mean + LEARNED_RANGE variance (what create_diffusion builds, init:32-46).
-    ``model_out`` is [B,F,2C,H,W]; ``i`` is the respaced index."""
+    ``model_out`` is [B,F,2C,H,W]; ``i`` is the respaced index.  ``denoised_fn`` is applied to the x_start
+    prediction BEFORE the clamp (process_xstart, gd:316-321)."""
     C = x.shape[2]
     eps, v = torch.split(model_out, C, dim=2)                                    # gd:291
     min_log = _coef(s.posterior_log_variance_clipped, i)
@@ -98,24 +99,34 @@ def p_mean_variance(s: Schedule, model_out: torch.Tensor, x: torch.Tensor, i: in
     frac = (v + 1) / 2
     log_var = frac * max_log + (1 - frac) * min_log                              # gd:296
     x0 = _coef(s.sqrt_recip_alphas_cumprod, i) * x - _coef(s.sqrt_recipm1_alphas_cumprod, i) * eps
+    if denoised_fn is not None:
+        x0 = denoised_fn(x0)
     if clip_denoised:
         x0 = x0.clamp(-1, 1)
     mean = _coef(s.posterior_mean_coef1, i) * x0 + _coef(s.posterior_mean_coef2, i) * x
     return {"mean": mean, "log_variance": log_var, "variance": torch.exp(log_var), "pred_xstart": x0}
 
 
-def p_sample(s, model_out, x, i, noise, clip_denoised=False):
-    """gd:380-421 (DDPM ancestral step); no noise at i == 0."""
-    out = p_mean_variance(s, model_out, x, i, clip_denoised)
+def p_sample(s, model_out, x, i, noise, clip_denoised=False, denoised_fn=None, cond_grad=None):
+    """gd:380-421 (DDPM ancestral step); no noise at i == 0.  ``cond_grad`` = cond_fn(x, t) of condition_mean
+    (gd:345-356): mean += variance * gradient; pred_xstart stays the unconditioned one."""
+    out = p_mean_variance(s, model_out, x, i, clip_denoised, denoised_fn)
+    if cond_grad is not None:
+        out["mean"] = out["mean"].float() + out["variance"] * cond_grad.float()
     mask = 0.0 if i == 0 else 1.0
     sample = out["mean"] + mask * torch.exp(0.5 * out["log_variance"]) * noise
     return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
 
-def ddim_sample(s, model_out, x, i, noise=None, eta=0.0, clip_denoised=False):
-    """gd:517-564."""
-    out = p_mean_variance(s, model_out, x, i, clip_denoised)
+def ddim_sample(s, model_out, x, i, noise=None, eta=0.0, clip_denoised=False, denoised_fn=None, cond_grad=None):
+    """gd:517-564.  ``cond_grad`` = cond_fn(x, t) of condition_score (gd:358-375): eps -= sqrt(1 - alpha_bar) * gradient,
+    pred_xstart re-derived from that eps (not clamped again)."""
+    out = p_mean_variance(s, model_out, x, i, clip_denoised, denoised_fn)
     x0 = out["pred_xstart"]
+    if cond_grad is not None:
+        e = (_coef(s.sqrt_recip_alphas_cumprod, i) * x - x0) / _coef(s.sqrt_recipm1_alphas_cumprod, i)
+        e = e - (1 - _coef(s.alphas_cumprod, i)).sqrt() * cond_grad
+        x0 = _coef(s.sqrt_recip_alphas_cumprod, i) * x - _coef(s.sqrt_recipm1_alphas_cumprod, i) * e
     eps = (_coef(s.sqrt_recip_alphas_cumprod, i) * x - x0) / _coef(s.sqrt_recipm1_alphas_cumprod, i)
     ab = _coef(s.alphas_cumprod, i)
     ab_prev = _coef(s.alphas_cumprod_prev, i)
@@ -128,7 +139,7 @@ def ddim_sample(s, model_out, x, i, noise=None, eta=0.0, clip_denoised=False):
 
 
 def sample_loop(s: Schedule, model_fn, x: torch.Tensor, method="ddim", eta=0.0, noises=None,
-                clip_denoised=False, progressive=False):
+                clip_denoised=False, progressive=False, denoised_fn=None, cond_fn=None):
     """gd:423-515 / gd:604-684.  ``model_fn(x, t_original:int64[B]) -> [B,F,2C,H,W]``; the loop
     index ``i`` is mapped through ``timestep_map`` exactly as ``_WrappedModel`` does (rs:125-130).
     ``noises[k]`` is the noise used at the k-th executed step (k=0 is i=T-1) so both sides of a
@@ -139,11 +150,24 @@ def sample_loop(s: Schedule, model_fn, x: torch.Tensor, method="ddim", eta=0.0, 
         t = torch.full((B,), s.timestep_map[i], dtype=torch.int64)
         out = model_fn(x, t)
         nz = None if noises is None else noises[k]
+        grad = None if cond_fn is None else cond_fn(x, t)          # the wrapped cond_fn sees ORIGINAL timesteps (rs:100-104)
         if method == "ddim":
-            r = ddim_sample(s, out, x, i, nz, eta, clip_denoised)
+            r = ddim_sample(s, out, x, i, nz, eta, clip_denoised, denoised_fn, grad)
         else:
-            r = p_sample(s, out, x, i, nz if nz is not None else torch.zeros_like(x), clip_denoised)
+            r = p_sample(s, out, x, i, nz if nz is not None else torch.zeros_like(x), clip_denoised, denoised_fn, grad)
         x = r["sample"]
         if progressive:
             trail.append(r)
     return (x, trail) if progressive else x
+
+
+# ----------------------------------------------------------------------------- hook fixtures
+def example_denoised_fn(x0):
+    """A deterministic ``denoised_fn`` for parity fixtures (the reference never ships one; sample.py passes none)."""
+    return 0.9 * x0 + 0.05
+
+
+def example_cond_fn(x, t, **kwargs):
+    """A deterministic ``cond_fn``: stands in for grad log p(y | x); depends on x AND on the ORIGINAL timestep, so a
+    wrong timestep mapping (rs:100-104) shows."""
+    return 0.05 * torch.tanh(x) * (t.float().view(-1, 1, 1, 1, 1) / 1000.0 + 0.5)

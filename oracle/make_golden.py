@@ -11,6 +11,7 @@ import os
 import numpy as np
 import torch
 
+from oracle import diffusion_oracle as dor
 from oracle import latte_oracle as lo
 from oracle.reference_loader import (load_reference_diffusion, load_reference_latte,
                                      randomize_zero_init)
@@ -135,6 +136,19 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
         torch.manual_seed(seed + 10)
         out["ddim_eta05_final"] = diff.ddim_sample_loop(fn, z.shape, z, clip_denoised=False,
                                                         model_kwargs=mk, device="cpu", eta=0.5).numpy()
+        if name == "tiny_uncond":
+            # denoised_fn / cond_fn hooks (gd:316-321, :345-375; rs:100-104), clip_denoised=True, DDIM with eta > 0:
+            # same seed -> same randn_like draws as the *_noises arrays above
+            hooks = dict(denoised_fn=dor.example_denoised_fn, cond_fn=dor.example_cond_fn)
+            torch.manual_seed(seed + 10)
+            out["ddpm_hooks_final"] = diff.p_sample_loop(fn, z.shape, z, clip_denoised=True, model_kwargs=mk, device="cpu",
+                                                         **hooks).numpy()
+            torch.manual_seed(seed + 10)
+            out["ddim_hooks_final"] = diff.ddim_sample_loop(fn, z.shape, z, clip_denoised=True, model_kwargs=mk,
+                                                            device="cpu", eta=0.3, **hooks).numpy()
+            torch.manual_seed(seed + 10)
+            out["ddim_denoised_only_final"] = diff.ddim_sample_loop(fn, z.shape, z, clip_denoised=False, model_kwargs=mk,
+                                                                    device="cpu", denoised_fn=dor.example_denoised_fn).numpy()
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
 
 

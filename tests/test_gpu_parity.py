@@ -341,3 +341,37 @@ def test_text_conditioned_variant_matches_reference_golden(cd):
     torch.cuda.synchronize()
     for k in range(steps):
         assert rel_l2(ts[k], torch.from_numpy(r["ddpm_samples"][k])) < gtol, k
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+def test_sampling_hooks_match_reference_golden(cd):
+    """denoised_fn / cond_fn of p_sample / ddim_sample (gd:316-321, :345-375; hook timesteps are the ORIGINAL ones,
+    rs:100-104) through latte_sampler_step_ex, against loops run by the reference with the same hooks, clip_denoised=True
+    and (DDIM) eta = 0.3, fed the reference's own noise draws."""
+    from oracle import diffusion_oracle as do
+    kw, sd, r = load_golden_model("tiny_uncond")
+    m = engine_model(kw, sd, cd)
+    steps = int(r["loop_steps"])
+    d = latte_amd.create_diffusion(str(steps))
+    z = torch.from_numpy(r["x"]).cuda()
+    hooks = dict(denoised_fn=do.example_denoised_fn, cond_fn=do.example_cond_fn)
+
+    def chain(method, eta, clip, noises, **hk):
+        x = z.clone()
+        for k, i in enumerate(range(steps - 1, -1, -1)):
+            out = d._call_model(m.forward, x, i, {})
+            x = d._step(method, out, x, i, noises[k], eta, clip, hk.get("denoised_fn"), hk.get("cond_fn"), {})["sample"]
+        return x
+
+    nz = torch.from_numpy(r["ddpm_noises"]).cuda()
+    assert rel_l2(chain("ddpm", 0.0, True, nz, **hooks), torch.from_numpy(r["ddpm_hooks_final"])) < TOL
+    nz = torch.from_numpy(r["ddim_noises"]).cuda()
+    assert rel_l2(chain("ddim", 0.3, True, nz, **hooks), torch.from_numpy(r["ddim_hooks_final"])) < TOL
+    only = chain("ddim", 0.0, False, nz, denoised_fn=do.example_denoised_fn)
+    assert rel_l2(only, torch.from_numpy(r["ddim_denoised_only_final"])) < TOL
+    # the public loops take the hooks too (own noise draws: finite, and different from the unhooked chain)
+    a = d.ddim_sample_loop(m.forward, z.shape, z, clip_denoised=True, device="cuda", **hooks)
+    b = d.ddim_sample_loop(m.forward, z.shape, z, clip_denoised=True, device="cuda")
+    assert torch.isfinite(a).all() and rel_l2(a, b) > 1e-3
+    c = d.p_sample_loop(m.forward, z.shape, z, clip_denoised=True, device="cuda", **hooks)
+    assert torch.isfinite(c).all()
