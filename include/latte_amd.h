@@ -45,6 +45,10 @@ typedef struct latte_schedule latte_schedule_t;
 int latte_schedule_create(int diffusion_steps, const char* timestep_respacing /* "", "250", "ddim50", "10,15,20" */,
                           const char* noise_schedule /* "linear" | "squaredcos_cap_v2" */,
                           latte_schedule_t** out);
+/* What the model predicts, as create_diffusion derives it (diffusion/__init__.py:32-45): predict_xstart -> START_X
+ * instead of EPSILON; learn_sigma -> LEARNED_RANGE (model output 2C channels), else FIXED_LARGE / FIXED_SMALL
+ * (sigma_small) with C output channels (gaussian_diffusion.py:289-313,323-328).  Default: 0, 1, 0. */
+int latte_schedule_set_model_types(latte_schedule_t* s, int predict_xstart, int learn_sigma, int sigma_small);
 void latte_schedule_destroy(latte_schedule_t* s);
 int latte_schedule_num_timesteps(const latte_schedule_t* s);
 /* SpacedDiffusion.timestep_map (respace.py:75,86): respaced index -> original timestep */

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "latte_version": (c_char, []),
     "latte_schedule_create": (c_int, [c_int, c_char, c_char, ctypes.POINTER(c_void)]),
     "latte_schedule_destroy": (None, [c_void]),
+    "latte_schedule_set_model_types": (c_int, [c_void, c_int, c_int, c_int]),
     "latte_schedule_num_timesteps": (c_int, [c_void]),
     "latte_schedule_timestep_map": (c_int, [c_void, c_void, c_int]),
     "latte_schedule_table": (c_int, [c_void, c_char, c_void, c_int]),

@@ -14,6 +14,9 @@ struct latte_schedule {
   std::vector<double> betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
       sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped, posterior_mean_coef1,
       posterior_mean_coef2, log_betas;
+  // what the model predicts (gd ModelMeanType / ModelVarType as create_diffusion sets them, diffusion/__init__.py:32-45)
+  int mean_type = 0;   // 0 EPSILON, 1 START_X (predict_xstart=True)
+  int var_type = 0;    // 0 LEARNED_RANGE (learn_sigma=True), 1 FIXED_LARGE, 2 FIXED_SMALL (learn_sigma=False [, sigma_small])
 };
 
 namespace latte {
@@ -134,6 +137,8 @@ struct SamplerCoefs {  // fp32 values of the fp64 tables at the step (gaussian_d
   float nonzero;                        // 0 when index == 0
   float cfg_scale;                      // > 1: model_out is a raw doubled batch, combine here
   float sqrt_one_minus_ab;              // condition_score: (1 - alpha_bar).sqrt() in fp32 (gd:368)
+  float fixed_log_var;                  // var_type 1 / 2: the step's log variance (gd:298-313)
+  int mean_type, var_type;              // latte_schedule::mean_type / var_type; var_type != 0: model_out has C channels
   int method, clip;
 };
 // x0_in: pred_xstart after the caller's denoised_fn (replaces the computed one BEFORE the clamp); grad: cond_fn(x, t);

@@ -272,6 +272,11 @@ SamplerCoefs make_coefs(const latte_schedule_t* s, int method, int i, float eta,
   c.nonzero = i == 0 ? 0.0f : 1.0f;
   c.cfg_scale = 1.0f;
   c.sqrt_one_minus_ab = std::sqrt(1.0f - ab);   // gd:368 on the fp32 alpha_bar
+  c.mean_type = s->mean_type;
+  c.var_type = s->var_type;
+  // gd:298-313: FIXED_LARGE = log(append(posterior_variance[1], betas[1:])), FIXED_SMALL = posterior_log_variance_clipped
+  if (s->var_type == 1) c.fixed_log_var = (float)std::log(i == 0 ? s->posterior_variance[1] : s->betas[i]);
+  else c.fixed_log_var = (float)s->posterior_log_variance_clipped[i];
   return c;
 }
 
@@ -558,6 +563,9 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   if (start_index >= n || end_index < 0 || start_index < end_index) return fail(LATTE_ERR_INVALID, "sample_loop: bad index range");
   if (n < 2) return fail(LATTE_ERR_INVALID, "sample_loop: learned-range variance needs >= 2 timesteps");
   if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "sample_loop: batch exceeds max_batch");
+  if ((s->var_type == 0) != (e->Cout == 2 * e->Cin))
+    return fail(LATTE_ERR_INVALID, "sample_loop: the model's learn_sigma and the diffusion's learn_sigma disagree "
+                                   "(model output channels vs ModelVarType, gd:290 / :338)");
   const bool use_cfg = cfg_scale > 1.0f;  // sample.py:51
   if (use_cfg && (batch % 2)) return fail(LATTE_ERR_INVALID, "sample_loop: guidance needs the doubled batch");
   hipStream_t st = (hipStream_t)stream;

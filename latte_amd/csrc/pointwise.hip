@@ -342,19 +342,21 @@ __global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t bf = i / chw, r = i % chw;
     const size_t b = bf / frames, f = bf % frames;
-    const size_t o = ((b * frames + f) * 2 * C) * hw + r;
+    const int Cm = c.var_type == 0 ? 2 * C : C;     // channels of the model output: eps | v, or eps / x_start alone
+    const size_t o = ((b * frames + f) * Cm) * hw + r;
     float eps;
     if (raw_cfg && r < (size_t)4 * hw) {
       const size_t bc = b % hb;
-      const float cond = mo[((bc * frames + f) * 2 * C) * hw + r];
-      const float unc = mo[(((bc + hb) * frames + f) * 2 * C) * hw + r];
+      const float cond = mo[((bc * frames + f) * Cm) * hw + r];
+      const float unc = mo[(((bc + hb) * frames + f) * Cm) * hw + r];
       eps = unc + c.cfg_scale * (cond - unc);
     } else {
       eps = mo[o];
     }
-    const float v = mo[o + chw];
+    const float v = c.var_type == 0 ? mo[o + chw] : 0.0f;
     const float xv = x[i];
     float x0 = c.sqrt_recip * xv - c.sqrt_recipm1 * eps;               // gd:338-343
+    if (c.mean_type == 1) x0 = eps;                                    // START_X: the model output is x_start (gd:323-324)
     if (predict_only) {                                                // the caller applies its denoised_fn to this
       x0_out[i] = x0;
       continue;
@@ -364,7 +366,8 @@ __global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ 
     float s;
     if (c.method == LATTE_METHOD_DDPM) {
       const float frac = (v + 1.0f) / 2.0f;                            // gd:295
-      const float log_var = frac * c.max_log + (1.0f - frac) * c.min_log;
+      float log_var = frac * c.max_log + (1.0f - frac) * c.min_log;
+      if (c.var_type != 0) log_var = c.fixed_log_var;                  // gd:298-313
       float mean = c.coef1 * x0 + c.coef2 * xv;                        // gd:232-241
       if (grad != nullptr) mean = mean + expf(log_var) * grad[i];      // condition_mean, gd:354-355 (variance = exp(log_var), gd:297)
       const float nz = noise != nullptr ? noise[i] : 0.0f;

@@ -166,6 +166,13 @@ int latte_schedule_create(int diffusion_steps, const char* timestep_respacing, c
   return LATTE_OK;
 }
 
+int latte_schedule_set_model_types(latte_schedule_t* s, int predict_xstart, int learn_sigma, int sigma_small) {
+  if (!s) return latte::fail(LATTE_ERR_INVALID, "schedule_set_model_types: null schedule");
+  s->mean_type = predict_xstart ? 1 : 0;                     // diffusion/__init__.py:33-35
+  s->var_type = learn_sigma ? 0 : (sigma_small ? 2 : 1);     // :36-44
+  return LATTE_OK;
+}
+
 void latte_schedule_destroy(latte_schedule_t* s) { delete s; }
 
 int latte_schedule_num_timesteps(const latte_schedule_t* s) { return s ? s->num_timesteps : -1; }

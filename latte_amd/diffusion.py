@@ -24,10 +24,11 @@ _METHOD = {"ddpm": 0, "ddim": 1}
 
 
 class SpacedDiffusion:
-    """Stand-in for ``respace.SpacedDiffusion`` as built by ``create_diffusion``: EPSILON mean type,
-    LEARNED_RANGE variance (diffusion/__init__.py:32-46)."""
+    """Stand-in for ``respace.SpacedDiffusion`` as built by ``create_diffusion`` (diffusion/__init__.py:32-46):
+    EPSILON or START_X mean type, LEARNED_RANGE / FIXED_LARGE / FIXED_SMALL variance."""
 
-    def __init__(self, timestep_respacing, noise_schedule="linear", diffusion_steps=1000):
+    def __init__(self, timestep_respacing, noise_schedule="linear", diffusion_steps=1000, predict_xstart=False,
+                 learn_sigma=True, sigma_small=False):
         lib = load_library()
         h = _lib.c_void()
         if isinstance(timestep_respacing, (list, tuple)):
@@ -35,6 +36,8 @@ class SpacedDiffusion:
         spec = "" if timestep_respacing is None else str(timestep_respacing)
         check(lib.latte_schedule_create(int(diffusion_steps), spec.encode(), noise_schedule.encode(), h))
         self._h = h
+        check(lib.latte_schedule_set_model_types(h, int(bool(predict_xstart)), int(bool(learn_sigma)), int(bool(sigma_small))))
+        self.predict_xstart, self.learn_sigma, self.sigma_small = bool(predict_xstart), bool(learn_sigma), bool(sigma_small)
         self.original_num_steps = int(diffusion_steps)
         self.num_timesteps = lib.latte_schedule_num_timesteps(h)
         n = self.num_timesteps
@@ -85,8 +88,9 @@ class SpacedDiffusion:
         with ORIGINAL timesteps (rs:100-104; condition_mean for DDPM, condition_score for DDIM)."""
         _lib.require_gpu()
         B, F, C = x.shape[:3]
-        if model_output.shape != (B, F, C * 2, *x.shape[3:]):                      # gd:290
-            raise AssertionError(f"model output shape {tuple(model_output.shape)} != {(B, F, C * 2, *x.shape[3:])}")
+        want = (B, F, C * 2 if self.learn_sigma else C, *x.shape[3:])              # gd:290 / :338
+        if model_output.shape != want:
+            raise AssertionError(f"model output shape {tuple(model_output.shape)} != {want}")
         x32 = x.float().contiguous()
         mo = model_output.float().contiguous()
         nz = None if noise is None else noise.float().contiguous()
@@ -223,11 +227,9 @@ class SpacedDiffusion:
 
 def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
                      predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000):
-    """``diffusion.create_diffusion`` (diffusion/__init__.py:10-47).  The accelerated path covers the
-    configuration every Latte sampling script uses: epsilon prediction with learned-range variance."""
-    if predict_xstart or not learn_sigma or sigma_small:
-        raise LatteError("latte_amd implements the sampler configuration Latte ships: predict_xstart=False, "
-                         "learn_sigma=True (EPSILON mean, LEARNED_RANGE variance)")
+    """``diffusion.create_diffusion`` (diffusion/__init__.py:10-47).  ``use_kl`` / ``rescale_learned_sigmas`` only select
+    the training loss (gd LossType) and do not touch sampling."""
     if timestep_respacing is None or timestep_respacing == "":
         timestep_respacing = [diffusion_steps]
-    return SpacedDiffusion(timestep_respacing, noise_schedule=noise_schedule, diffusion_steps=diffusion_steps)
+    return SpacedDiffusion(timestep_respacing, noise_schedule=noise_schedule, diffusion_steps=diffusion_steps,
+                           predict_xstart=predict_xstart, learn_sigma=learn_sigma, sigma_small=sigma_small)

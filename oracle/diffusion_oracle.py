@@ -53,7 +53,11 @@ class Schedule:
     """Tables of ``GaussianDiffusion.__init__`` (gd:153-201) for the respaced betas of
     ``SpacedDiffusion.__init__`` (rs:73-87)."""
 
-    def __init__(self, timestep_respacing="", noise_schedule="linear", diffusion_steps=1000):
+    def __init__(self, timestep_respacing="", noise_schedule="linear", diffusion_steps=1000, predict_xstart=False,
+                 learn_sigma=True, sigma_small=False):
+        # init:32-45: what the model predicts
+        self.predict_xstart = bool(predict_xstart)
+        self.var_type = "learned_range" if learn_sigma else ("fixed_small" if sigma_small else "fixed_large")
         base_betas = named_betas(noise_schedule, diffusion_steps)
         if timestep_respacing is None or timestep_respacing == "":
             timestep_respacing = [diffusion_steps]                              # init:29-30
@@ -93,12 +97,22 @@ def p_mean_variance(s: Schedule, model_out: torch.Tensor, x: torch.Tensor, i: in
     ``model_out`` is [B,F,2C,H,W]; ``i`` is the respaced index.  ``denoised_fn`` is applied to the x_start
     prediction BEFORE the clamp (process_xstart, gd:316-321)."""
     C = x.shape[2]
-    eps, v = torch.split(model_out, C, dim=2)                                    # gd:291
-    min_log = _coef(s.posterior_log_variance_clipped, i)
-    max_log = _coef(s.log_betas, i)
-    frac = (v + 1) / 2
-    log_var = frac * max_log + (1 - frac) * min_log                              # gd:296
+    var_type = getattr(s, "var_type", "learned_range")
+    if var_type == "learned_range":
+        eps, v = torch.split(model_out, C, dim=2)                                # gd:291
+        min_log = _coef(s.posterior_log_variance_clipped, i)
+        max_log = _coef(s.log_betas, i)
+        frac = (v + 1) / 2
+        log_var = frac * max_log + (1 - frac) * min_log                          # gd:296
+    else:
+        # gd:298-313: fixed_large = log(append(posterior_variance[1], betas[1:])), fixed_small = clipped posterior
+        eps = model_out
+        table = (np.log(np.append(s.posterior_variance[1], s.betas[1:])) if var_type == "fixed_large"
+                 else s.posterior_log_variance_clipped)
+        log_var = _coef(table, i) + torch.zeros_like(x)                          # _extract_into_tensor broadcast
     x0 = _coef(s.sqrt_recip_alphas_cumprod, i) * x - _coef(s.sqrt_recipm1_alphas_cumprod, i) * eps
+    if getattr(s, "predict_xstart", False):
+        x0 = eps                                                                 # START_X, gd:323-324
     if denoised_fn is not None:
         x0 = denoised_fn(x0)
     if clip_denoised:
@@ -171,3 +185,13 @@ def example_cond_fn(x, t, **kwargs):
     """A deterministic ``cond_fn``: stands in for grad log p(y | x); depends on x AND on the ORIGINAL timestep, so a
     wrong timestep mapping (rs:100-104) shows."""
     return 0.05 * torch.tanh(x) * (t.float().view(-1, 1, 1, 1, 1) / 1000.0 + 0.5)
+
+
+def synthetic_model(x, t, out_channels):
+    """A cheap deterministic stand-in for a denoiser (the sampler arithmetic is under test, not the network):
+    [B,F,C,H,W], int64[B] -> [B,F,out_channels,H,W]."""
+    s = torch.sin(x * 1.7 + 0.3) * 0.8 + 0.1 * x
+    s = s * (0.5 + t.float().view(-1, 1, 1, 1, 1) / 2000.0)
+    if out_channels == x.shape[2]:
+        return s
+    return torch.cat([s, torch.cos(x * 0.9 - 0.2) * 0.7], dim=2)

@@ -152,6 +152,32 @@ def tiny_model(rl, rd, name, kw, use_cfg, seed):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
 
 
+def sampler_types(rd):
+    """create_diffusion's other model types (init:32-45): fixed variances (learn_sigma=False [, sigma_small]) and
+    x_start prediction, DDPM and DDIM, run by the reference on the synthetic model."""
+    g = torch.Generator("cpu").manual_seed(77)
+    z = torch.randn(2, 4, 4, 8, 8, generator=g)
+    out = {"z": z.numpy()}
+    steps = 6
+    for tag, kw in (("fixed_large", dict(learn_sigma=False)), ("fixed_small", dict(learn_sigma=False, sigma_small=True)),
+                    ("xstart_learned", dict(predict_xstart=True)), ("xstart_fixed_small", dict(predict_xstart=True, learn_sigma=False, sigma_small=True))):
+        d = rd.create_diffusion(str(steps), **kw)
+        oc = 8 if kw.get("learn_sigma", True) else 4
+        fn = lambda x, t, **k: dor.synthetic_model(x, t, oc)
+        for method in ("ddpm", "ddim"):
+            torch.manual_seed(5)
+            noises = [torch.randn_like(z) for _ in range(steps)]
+            torch.manual_seed(5)
+            if method == "ddpm":
+                fin = d.p_sample_loop(fn, z.shape, z, clip_denoised=True, device="cpu")
+            else:
+                fin = d.ddim_sample_loop(fn, z.shape, z, clip_denoised=False, device="cpu", eta=0.4)
+            out[f"{tag}::{method}"] = fin.numpy()
+            out["noises"] = np.stack([n_.numpy() for n_ in noises])
+    out["steps"] = np.int64(steps)
+    np.savez_compressed(os.path.join(OUT, "sampler_types.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rl, rd = load_reference_latte(), load_reference_diffusion()
@@ -159,6 +185,7 @@ def main():
     tiny_model(rl, rd, "tiny_classcond", TINY, use_cfg=True, seed=100)
     tiny_model(rl, rd, "tiny_uncond", TINY4, use_cfg=False, seed=200)
     tiny_model(rl, rd, "tiny_textcond", TINY78, use_cfg=True, seed=300)
+    sampler_types(rd)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -375,3 +375,64 @@ def test_sampling_hooks_match_reference_golden(cd):
     assert torch.isfinite(a).all() and rel_l2(a, b) > 1e-3
     c = d.p_sample_loop(m.forward, z.shape, z, clip_denoised=True, device="cuda", **hooks)
     assert torch.isfinite(c).all()
+
+
+SAMPLER_TYPES = {"fixed_large": dict(learn_sigma=False), "fixed_small": dict(learn_sigma=False, sigma_small=True),
+                 "xstart_learned": dict(predict_xstart=True),
+                 "xstart_fixed_small": dict(predict_xstart=True, learn_sigma=False, sigma_small=True)}
+
+
+@pytest.mark.parametrize("tag", sorted(SAMPLER_TYPES))
+def test_other_model_types_match_reference_golden(tag):
+    """create_diffusion(learn_sigma=False[, sigma_small=True]) / predict_xstart=True (init:32-45; gd:289-313,323-328)
+    on the update kernel, against loops the reference ran on a synthetic model callable (same noise draws)."""
+    import os
+    from _util import GOLDEN
+    from oracle import diffusion_oracle as do
+    r = np.load(os.path.join(GOLDEN, "sampler_types.npz"))
+    kw = SAMPLER_TYPES[tag]
+    steps = int(r["steps"])
+    d = latte_amd.create_diffusion(str(steps), **kw)
+    oc = 8 if kw.get("learn_sigma", True) else 4
+    z = torch.from_numpy(r["z"]).cuda()
+    nz = torch.from_numpy(r["noises"]).cuda()
+    fn = lambda xx, tt, **k: do.synthetic_model(xx, tt, oc)
+    for method, eta, clip in (("ddpm", 0.0, True), ("ddim", 0.4, False)):
+        x = z.clone()
+        for k, i in enumerate(range(steps - 1, -1, -1)):
+            x = d._step(method, d._call_model(fn, x, i, {}), x, i, nz[k], eta, clip)["sample"]
+        assert rel_l2(x, torch.from_numpy(r[f"{tag}::{method}"])) < 1e-4, method      # fp32 update kernel, torch-GPU model fn
+    out = d.p_sample_loop(fn, z.shape, z, clip_denoised=True, device="cuda")           # public loop, own noise
+    assert torch.isfinite(out).all()
+    with pytest.raises(AssertionError):                                               # wrong channel count (gd:290 / :338)
+        d._step("ddpm", torch.zeros(2, 4, 12 - oc, 8, 8, device="cuda"), z, 0, None, 0.0, False)
+
+
+def test_fused_loop_with_fixed_variance_model():
+    """A learn_sigma=False Latte (C output channels) with create_diffusion(learn_sigma=False): whole chain inside the
+    engine vs the oracle; mixing a learn_sigma=True model with it fails loudly."""
+    from oracle import diffusion_oracle as do
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=8, num_frames=4, extras=1, learn_sigma=False)
+    cfg = lo.preset_config("Latte-S/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=9)
+    m = latte_amd.Latte_models["Latte-S/2"](compute_dtype="f16", **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    steps = 5
+    d = latte_amd.create_diffusion(str(steps), learn_sigma=False)
+    s = do.Schedule(str(steps), learn_sigma=False)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(2, 4, 4, 8, 8, generator=g)
+    noises = [torch.randn(2, 4, 4, 8, 8, generator=g) for _ in range(steps)]
+    want = do.sample_loop(s, lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt, None), z, method="ddpm", noises=noises)
+    xx = z.clone().cuda().contiguous()
+    nz = torch.stack(noises).cuda().contiguous()
+    check(load_library().latte_sample_loop(m.engine(2), d._h, 0, 0.0, 0, 1.0, ptr(xx), None, 2, steps - 1, 0, ptr(nz), None,
+                                           None, stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(xx, want) < TOL
+    d2 = latte_amd.create_diffusion(str(steps))
+    with pytest.raises(latte_amd.LatteError, match="learn_sigma"):
+        check(load_library().latte_sample_loop(m.engine(2), d2._h, 0, 0.0, 0, 1.0, ptr(xx), None, 2, steps - 1, 0, ptr(nz),
+                                               None, None, stream_ptr()))

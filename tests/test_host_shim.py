@@ -61,8 +61,8 @@ def test_create_diffusion_surface():
     assert abs(d.alphas_cumprod[-1] - 4.0358297653756747e-05) < 1e-19
     d = latte_amd.create_diffusion("")
     assert d.num_timesteps == 1000
-    with pytest.raises(latte_amd.LatteError):
-        latte_amd.create_diffusion("250", learn_sigma=False)
+    d = latte_amd.create_diffusion("250", learn_sigma=False, sigma_small=True, predict_xstart=True)   # init:32-45
+    assert (d.learn_sigma, d.sigma_small, d.predict_xstart) == (False, True, True)
     with pytest.raises(latte_amd.LatteError):
         latte_amd.create_diffusion("ddim600")
 
