@@ -109,6 +109,7 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
 // text_embedding_projection of the extras == 78 variant (latte.py:238-242): out[B,N] = Linear(SiLU(text[B,K]))
 int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K, hipStream_t st);
 int launch_iota(int64_t* p, int n, hipStream_t st);
+int launch_silu_rows(const float* in, float* out, size_t n, hipStream_t st);   // out = SiLU(in), may alias
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
 int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);

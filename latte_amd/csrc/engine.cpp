@@ -154,12 +154,15 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     const float* add_tab = c.extras == 2 ? e->ytab : c.extras == 78 ? e->txt_proj : nullptr;
     const int64_t* add_idx = c.extras == 78 ? e->iota : y;
     if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, add_tab, add_idx, e->cvec, B, D, D, D, st))) return rc;
-    if ((rc = launch_small_linear(IN_SILU, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
+    // adaLN_modulation = Linear(SiLU(c)): SiLU once per row here, not once per output feature inside the linear
+    if ((rc = launch_silu_rows(e->cvec, e->cvec, (size_t)B * D, st))) return rc;
+    if ((rc = launch_small_linear(IN_PLAIN, e->cvec, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->mod, B, e->nmod, D,
                                   e->nmod, st))) return rc;
     if (c.extras == 78) {   // final layer: c = t only (latte.py:372-373) -> redo its 2D columns from the plain t_emb
       const size_t fo = (size_t)c.depth * 6 * D;
       if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, nullptr, nullptr, e->cvec_t, B, D, D, D, st))) return rc;
-      if ((rc = launch_small_linear(IN_SILU, e->cvec_t, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr, nullptr,
+      if ((rc = launch_silu_rows(e->cvec_t, e->cvec_t, (size_t)B * D, st))) return rc;
+      if ((rc = launch_small_linear(IN_PLAIN, e->cvec_t, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr, nullptr,
                                     e->mod + fo, B, 2 * D, D, e->nmod, st))) return rc;
     }
   }
@@ -571,7 +574,7 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   hipStream_t st = (hipStream_t)stream;
   // ---- conditioning of the whole chain, once: it depends on (timestep, label) only, never on x.
   //   temb[i]      = t_embedder(timestep_map[i])           (own, or the table installed after the RCCL broadcast)
-  //   c[i, b]      = temb[i] (+ y_embedder(y[b]))           latte.py:337,348
+  //   c[i, b]      = SiLU(temb[i] (+ y_embedder(y[b])))     latte.py:337,348 (+ the SiLU of :173)
   //   mod[i, b, :] = all 28 adaLN_modulation + the final layer's, = Linear(SiLU(c))   latte.py:172-178,192-198
   // Unconditional models have one row per step shared by every sample (row stride 0).  The adaLN weights (0.9 GB
   // fp32) are then streamed once per 64 rows instead of once per denoising step.
@@ -603,10 +606,10 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   const size_t fo = (size_t)e->cfg.depth * 6 * D;
   for (int64_t r0 = 0; r0 < rows_all; r0 += 64) {
     const int rows = (int)std::min<int64_t>(64, rows_all - r0);
-    if ((rc = launch_small_linear(IN_SILU, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
+    if ((rc = launch_small_linear(IN_PLAIN, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
                                   e->mod_all + (size_t)r0 * e->nmod, rows, e->nmod, D, e->nmod, st))) return rc;
     if (ex == 78 &&
-        (rc = launch_small_linear(IN_SILU, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
+        (rc = launch_small_linear(IN_PLAIN, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
                                   nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return rc;
   }
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;

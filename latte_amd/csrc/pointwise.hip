@@ -261,6 +261,8 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // c[(i, b), :] = temb[i, :] (+ ytab[y[b], :]): the conditioning vector of step i, sample b (latte.py:337,348)
+// (the rows only ever feed adaLN_modulation = Linear(SiLU(c)), latte.py:172-175: SiLU is applied here, once per row,
+//  instead of once per output feature inside the linear)
 __global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __restrict__ ytab, const int64_t* __restrict__ y,
                                  float* __restrict__ out, int n_steps, int bu, int D) {
   const size_t total = (size_t)n_steps * bu * D;
@@ -270,7 +272,7 @@ __global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __
     const int b = (int)(r % bu), step = (int)(r / bu);
     float v = temb[(size_t)step * D + d];
     if (ytab != nullptr) v += ytab[(size_t)y[b] * D + d];
-    out[i] = v;
+    out[i] = silu(v);
   }
 }
 
@@ -307,6 +309,10 @@ __global__ void __launch_bounds__(256) text_proj_kernel(const float* __restrict_
       if (lane == 0 && b0 + u < B) out[(size_t)(b0 + u) * N + n] = r + bias[n];
     }
   }
+}
+
+__global__ void silu_rows_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = silu(in[i]);
 }
 
 __global__ void iota_kernel(int64_t* p, int n) {
@@ -563,6 +569,12 @@ int launch_text_proj(const float* text, const float* W, const float* bias, float
                      hipStream_t st) {
   if (K % 128) return fail(LATTE_ERR_INVALID, "text_proj: K must be a multiple of 128");
   hipLaunchKernelGGL(text_proj_kernel, dim3((N + 3) / 4), dim3(256), 0, st, text, W, bias, out, B, N, K);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_silu_rows(const float* in, float* out, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(silu_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, n);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
