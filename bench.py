@@ -188,6 +188,21 @@ def main():
     finite = bool(torch.isfinite(xx).all())
     note(f'timed region done: {elapsed:.3f}s')
 
+    other = None
+    if world == 1:
+        # BASELINE.json configs[1] words the same FaceForensics job as DDPM-250 (the YAML default `sample_method: 'ddpm'`),
+        # the metric as DDIM-250: same model cost, DDPM adds one engine-side noise fill per step.  Short side measurement.
+        om = "ddpm" if args.method == "ddim" else "ddim"
+        n_other = min(args.steps, 60)
+        xo = x.clone()
+        run_steps(lib, model, diffusion, xo, 2, om, B)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(lib, model, diffusion, xo, n_other, om, B)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        other = {"method": om, "value": round(B * n_other / dt, 3), "unit": "sample-steps/s", "steps": n_other,
+                 "finite": bool(torch.isfinite(xo).all())}
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops = FLOPS_PER_SAMPLE_STEP["Latte-XL/2"]
@@ -212,6 +227,7 @@ def main():
             "config": {"workload": "Latte-XL/2 FaceForensics (uncond) 16x256x256 -> latents 16x4x32x32, "
                                    f"{args.method.upper()} on the '250' respacing, random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} (independent samples)"},
+            "other_sampler": other,
             "latent_frames_per_sec": round(world * B * 16 / (elapsed / args.steps * 250), 3),
             "model_mfma_frac": round(value / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "finite": finite,
