@@ -116,3 +116,19 @@ def randomize_zero_init(model, std=0.02, seed=1234):
             if p.requires_grad and float(p.abs().max()) == 0.0:
                 p.copy_(torch.randn(p.shape, generator=g) * std)
     return model
+
+
+def load_reference_latte_t2v():
+    """Returns the reference ``models/latte_t2v.py`` module object (unmodified source) on top of the diffusers stand-in
+    (oracle/diffusers_standin.py: memory-derived restatement of the diffusers 0.24.0 leaf modules it imports)."""
+    assert reference_available(), "reference checkout not present (expected only in the build container)"
+    from oracle import diffusers_standin
+    diffusers_standin.install()
+    name = "_reference_latte_t2v"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE_ROOT, "models", "latte_t2v.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
