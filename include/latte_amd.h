@@ -185,6 +185,36 @@ int latte_vae_check_weights(latte_vae_t* v);
 int latte_vae_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out,
                      void* stream);
 
+/* ------------------------------------------------------------------ LatteT2V denoiser (Latte-1 text-to-video)
+ * LatteT2V.forward, /root/reference/models/latte_t2v.py:677-941 (constructor :475-672).
+ * PixArt-alpha style blocks with norm_type "ada_norm_single", attention_bias = True, activation_fn "gelu-approximate",
+ * norm_elementwise_affine = False, norm_eps 1e-6 -- the configuration Latte-1 ships; weights by the reference's
+ * state-dict keys (to_q / to_k / to_v are packed into one fused GEMM on load).  The diffusers 0.24.0 leaves the reference
+ * imports are restated, not vendored: parity is pinned against the reference's own file only (oracle/latte_t2v_oracle.py). */
+typedef struct latte_t2v latte_t2v_t;
+typedef struct {
+  int num_attention_heads, attention_head_dim;   /* inner dim = heads * head_dim (16 x 72 = 1152) */
+  int in_channels, out_channels;                 /* 4, 8 (learned sigma) */
+  int num_layers;                                /* 28 spatial + 28 temporal blocks */
+  int sample_size, patch_size;                   /* latent side (64 for 512 px), 2 */
+  int cross_attention_dim, caption_channels;     /* 1152 (= inner dim), 4096 (T5-XXL features) */
+  int video_length;                              /* frames, 16 */
+  int max_text_tokens;                           /* workspace for the text tokens of one sample (120) */
+  int compute_dtype;                             /* LATTE_DTYPE_BF16 | LATTE_DTYPE_F16 */
+} latte_t2v_config_t;
+int latte_t2v_create(const latte_t2v_config_t* cfg, int max_batch, latte_t2v_t** out);
+void latte_t2v_destroy(latte_t2v_t* e);
+int latte_t2v_num_keys(const latte_t2v_t* e);
+const char* latte_t2v_key(const latte_t2v_t* e, int i);
+int latte_t2v_load_tensor(latte_t2v_t* e, const char* key, const float* data, int64_t numel, int on_device, void* stream);
+int latte_t2v_check_weights(latte_t2v_t* e);
+/* x:[B,C,F,H,W] fp32 (channels before frames, latte_t2v.py:729), t: int64[B], encoder_hidden_states:[B,n_text,caption_channels]
+ * fp32, encoder_attention_mask:[B,n_text] fp32 1 = keep / 0 = padded, or NULL; out:[B,out_channels,F,H,W] fp32.  All device
+ * pointers.  enable_temporal_attentions = 0 skips the temporal blocks (latte_t2v.py:867). */
+int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const float* encoder_hidden_states,
+                      const float* encoder_attention_mask, int batch, int n_text, int enable_temporal_attentions, float* out,
+                      void* stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * Runs ONE denoiser forward eagerly with HIP events around every kernel launch on `stream`,
  * synchronises, and reports per-kernel-class totals.  classes (fixed order):

@@ -26,6 +26,12 @@ class ModelConfig(ctypes.Structure):
                                      "compute_dtype")]
 
 
+class T2VConfig(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers",
+                                     "sample_size", "patch_size", "cross_attention_dim", "caption_channels", "video_length",
+                                     "max_text_tokens", "compute_dtype")]
+
+
 DTYPES = {"bf16": 0, "bfloat16": 0, "f16": 1, "fp16": 1, "float16": 1}
 
 # name -> (restype, argtypes); mirrors include/latte_amd.h and include/latte_amd_debug.h
@@ -57,6 +63,13 @@ PROTOTYPES = {
     "latte_sample_loop": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_f32, c_void, c_void, c_int, c_int, c_int,
                                   c_void, c_void, c_void, c_void]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
+    "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
+    "latte_t2v_destroy": (None, [c_void]),
+    "latte_t2v_num_keys": (c_int, [c_void]),
+    "latte_t2v_key": (c_char, [c_void, c_int]),
+    "latte_t2v_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
+    "latte_t2v_check_weights": (c_int, [c_void]),
+    "latte_t2v_forward": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "latte_bench_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_f32), c_void]),
     "latte_vae_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void)]),
     "latte_vae_destroy": (None, [c_void]),

@@ -68,7 +68,9 @@ __device__ __forceinline__ int64_t seq_base_row(const AttnArgs& a, int seq) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int HD, int DT>
+// CROSS = true (LatteT2V attn2): queries from a [rows, q_ld] buffer, Lk keys / values per SAMPLE from a.kv ([K | V], 2D
+// columns), an optional additive score bias per (sample, key); everything else is the same kernel.
+template <int HD, int DT, bool CROSS = false>
 __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;  // k-steps of the QK^T contraction (hd padded to 32)
   constexpr int DF = (HD + 15) / 16;  // 16-wide d fragments of the PV product
@@ -84,8 +86,11 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
   const int head = (blockIdx.x / q_tiles) % a.heads;
   const int seq = blockIdx.x / (q_tiles * a.heads);
   const int64_t base = seq_base_row(a, seq);
-  const size_t ld = (size_t)3 * a.D;
+  const size_t ld = CROSS ? (size_t)a.q_ld : (size_t)3 * a.D;
   const half_t* qkv_h = a.qkv + (size_t)head * HD;
+  const int NK = CROSS ? a.Lk : a.L;                       // keys per sequence
+  const int smp = seq / a.U;                               // CROSS: the sample whose text tokens are the keys
+  const half_t* kv_h = CROSS ? a.kv + ((size_t)smp * a.Lk) * (2 * (size_t)a.D) + (size_t)head * HD : nullptr;
 
   // Q fragments (B operand of S^T = K·Q^T): lane = (query fl, chunk g + 4 ks)
   const int q_idx = qt * 64 + wave * 16 + fl;
@@ -104,15 +109,22 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float c = a.scale * 1.4426950408889634f;  // softmax in the exp2 domain
 
-  const int kv_tiles = (a.L + 63) >> 6;
+  const int kv_tiles = (NK + 63) >> 6;
   for (int kt = 0; kt < kv_tiles; ++kt) {
     __syncthreads();  // previous tile fully consumed
     for (int id = tid; id < 64 * NCH; id += 256) {
       const int key = id / NCH, ch = id % NCH;
-      const int key_ld = min(kt * 64 + key, a.L - 1);
-      const half_t* rowp = qkv_h + (size_t)(base + (int64_t)key_ld * a.row_stride) * ld + ch * 8;
-      const u32x4 kv = *(const u32x4*)(rowp + a.D);
-      const u32x4 vv = *(const u32x4*)(rowp + 2 * a.D);
+      const int key_ld = min(kt * 64 + key, NK - 1);
+      u32x4 kv, vv;
+      if constexpr (CROSS) {
+        const half_t* rowp = kv_h + (size_t)key_ld * (2 * (size_t)a.D) + ch * 8;
+        kv = *(const u32x4*)rowp;
+        vv = *(const u32x4*)(rowp + a.D);
+      } else {
+        const half_t* rowp = qkv_h + (size_t)(base + (int64_t)key_ld * a.row_stride) * ld + ch * 8;
+        kv = *(const u32x4*)(rowp + a.D);
+        vv = *(const u32x4*)(rowp + 2 * a.D);
+      }
       *(u32x4*)(k_lds + key * PITCH + ch * 16) = kv;
       // transposed V image: element (d, key) at vt[d][slot(key)], slot = MFMA k-slot order:
       // within each 32-key group  slot = g*8 + half*4 + r  for  key = half*16 + g*4 + r
@@ -147,7 +159,10 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 64 + 16 * j + 4 * g + r;
-        const float z = key < a.L ? st[j][r] * c : NEG_BIG;
+        float z = key < NK ? st[j][r] * c : NEG_BIG;
+        if constexpr (CROSS) {
+          if (a.kbias != nullptr && key < NK) z += a.kbias[(size_t)smp * a.Lk + key] * 1.4426950408889634f;
+        }
         st[j][r] = z;
         mx = fmaxf(mx, z);
       }
@@ -539,6 +554,23 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
     return fail(LATTE_ERR_INVALID, "attention: unknown dtype");
   }
 #undef ATTN_LAUNCH
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st) {
+  if (a.hd != 64 && a.hd != 72) return fail(LATTE_ERR_INVALID, "cross attention: head_dim must be 64 or 72");
+  if (a.L <= 0 || a.Lk <= 0 || !a.kv || a.q_ld < a.D) return fail(LATTE_ERR_INVALID, "cross attention: bad arguments");
+  dim3 block(256), grid(a.num_seq * a.heads * ((a.L + 63) / 64));
+#define XATTN_LAUNCH(HD, DT) hipLaunchKernelGGL((attn_flash_kernel<HD, DT, true>), grid, block, 0, st, a)
+  if (dtype == LATTE_DTYPE_BF16) {
+    if (a.hd == 64) XATTN_LAUNCH(64, LATTE_DTYPE_BF16); else XATTN_LAUNCH(72, LATTE_DTYPE_BF16);
+  } else if (dtype == LATTE_DTYPE_F16) {
+    if (a.hd == 64) XATTN_LAUNCH(64, LATTE_DTYPE_F16); else XATTN_LAUNCH(72, LATTE_DTYPE_F16);
+  } else {
+    return fail(LATTE_ERR_INVALID, "cross attention: unknown dtype");
+  }
+#undef XATTN_LAUNCH
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -85,8 +85,15 @@ struct AttnArgs {
   int64_t row_stride;     // row offset between consecutive tokens of a sequence (1 spatial, T temporal)
   float scale;            // hd^-0.5
   int variant;            // 0 = pick by L; 1 = force the generic flash kernel for L > 16 (test hook)
+  // cross-attention (LatteT2V attn2, launch_cross_attention): queries from `qkv` viewed as [rows, q_ld] (column head*hd),
+  // keys / values from kv [num_samples * Lk, 2*D] ([K | V], column head*hd), shared by the U sequences of a sample;
+  // kbias: additive score bias [num_samples, Lk] (the -10000 * (1 - mask) of latte_t2v.py:746-749) or NULL
+  const half_t* kv;
+  const float* kbias;
+  int Lk, q_ld;
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t st);
+int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st);
 
 // ---- pointwise / small kernels ------------------------------------------------------------------
 // y(half)[m, :] = LN(x[m, :]) * (1 + scale[s(m), :]) + shift[s(m), :], eps 1e-6, no affine.
@@ -110,6 +117,14 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
 int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K, hipStream_t st);
 int launch_iota(int64_t* p, int n, hipStream_t st);
 int launch_silu_rows(const float* in, float* out, size_t n, hipStream_t st);   // out = SiLU(in), may alias
+// adaLN-single (latte_t2v.py:301-304,913-915): mod[b, j, :] = table[j, :] + t6[b, (j % 6) * D ...] for the 6 * nblk block
+// rows, then the 2 head rows = head_table[r, :] + temb[b, :]; mod is [B, (6 * nblk + 2) * D].
+int launch_adaln_single(const float* tables /* [nblk, 6, D] */, const float* head_table /* [2, D] */, const float* t6 /* [B, 6D] */,
+                        const float* temb /* [B, D] */, float* mod, int B, int nblk, int D, hipStream_t st);
+// out[b, f, c, :] = in[b, c, f, :] (to_bfc = 1) or out[b, c, f, :] = in[b, f, c, :] (to_bfc = 0); hw contiguous floats
+int launch_permute_cf(const float* in, float* out, int B, int C, int F, int hw, int to_bfc, hipStream_t st);
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st);   // bias = (1 - mask) * -10000
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
 int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);

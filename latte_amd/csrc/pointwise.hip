@@ -315,6 +315,40 @@ __global__ void silu_rows_kernel(const float* __restrict__ in, float* __restrict
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = silu(in[i]);
 }
 
+__global__ void adaln_single_kernel(const float* __restrict__ tables, const float* __restrict__ head_table,
+                                    const float* __restrict__ t6, const float* __restrict__ temb, float* __restrict__ mod, int B,
+                                    int nblk, int D) {
+  const size_t per = (size_t)(6 * nblk + 2) * D, total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per, r = i % per;
+    const int row = (int)(r / D), d = (int)(r % D);
+    float v;
+    if (row < 6 * nblk) v = tables[(size_t)row * D + d] + t6[b * 6 * D + (size_t)(row % 6) * D + d];
+    else v = head_table[(size_t)(row - 6 * nblk) * D + d] + temb[b * D + d];
+    mod[i] = v;
+  }
+}
+
+__global__ void permute_cf_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int F, int hw, int to_bfc) {
+  const size_t total = (size_t)B * C * F * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t q = i % hw, r = i / hw;
+    size_t b, c, f;
+    if (to_bfc) { c = r % C; f = (r / C) % F; b = r / ((size_t)C * F); out[i] = in[((b * C + c) * F + f) * hw + q]; }
+    else        { f = r % F; c = (r / F) % C; b = r / ((size_t)C * F); out[i] = in[((b * F + f) * C + c) * hw + q]; }
+  }
+}
+
+__global__ void mask_bias_kernel(const float* __restrict__ mask, float* __restrict__ bias, size_t n) {
+  // latte_t2v.py:746-747: (1 - mask) * -10000.0, added to the cross-attention scores
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    bias[i] = (1.0f - mask[i]) * -10000.0f;
+}
+
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 __global__ void iota_kernel(int64_t* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -575,6 +609,33 @@ int launch_text_proj(const float* text, const float* W, const float* bias, float
 
 int launch_silu_rows(const float* in, float* out, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(silu_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_adaln_single(const float* tables, const float* head_table, const float* t6, const float* temb, float* mod, int B,
+                        int nblk, int D, hipStream_t st) {
+  const size_t n = (size_t)B * (6 * nblk + 2) * D;
+  hipLaunchKernelGGL(adaln_single_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, tables, head_table, t6, temb, mod, B, nblk, D);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_permute_cf(const float* in, float* out, int B, int C, int F, int hw, int to_bfc, hipStream_t st) {
+  const size_t n = (size_t)B * C * F * hw;
+  hipLaunchKernelGGL(permute_cf_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, B, C, F, hw, to_bfc);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(mask_bias_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, mask, bias, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, v, n);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -37,7 +37,7 @@ def main():
     rows = []
     cases = [("tiny (D=128, 2+2 layers, 4 frames, 8x8 latent, 6 text tokens)",
               to.T2VConfig(num_attention_heads=2, attention_head_dim=64, num_layers=2, sample_size=8, cross_attention_dim=128,
-                           caption_channels=32, video_length=4), 2, 6),
+                           caption_channels=64, video_length=4), 2, 6),
              ("hd=72 geometry (D=144, 3+3 layers, 16 frames, 16x16 latent, 20 text tokens)",
               to.T2VConfig(num_attention_heads=2, attention_head_dim=72, num_layers=3, sample_size=16, cross_attention_dim=144,
                            caption_channels=48, video_length=16), 1, 20)]

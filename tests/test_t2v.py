@@ -1,0 +1,95 @@
+"""LatteT2V denoiser on the HIP engine vs the oracle restatement of
+/root/reference/models/latte_t2v.py (pinned against the reference's own file; the diffusers leaves are memory-derived, see
+oracle/latte_t2v_oracle.py).  Tolerance: the sampling path's 1e-3 relative L2."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import latte_amd
+from _util import GOLDEN, rel_l2
+
+TOL = 1e-3
+
+
+def _fixture():
+    from oracle import latte_t2v_oracle as to
+    z = np.load(os.path.join(GOLDEN, "tiny_t2v.npz"))
+    cfg = to.T2VConfig(**json.loads(bytes(z["cfg_json"]).decode()))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    return cfg, sd, z
+
+
+def _model(cfg, sd, cd, **kw):
+    m = latte_amd.LatteT2V(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
+                           in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+                           sample_size=cfg.sample_size, patch_size=cfg.patch_size, cross_attention_dim=cfg.cross_attention_dim,
+                           caption_channels=cfg.caption_channels, video_length=cfg.video_length, compute_dtype=cd, **kw)
+    m.load_state_dict(sd)
+    return m
+
+
+def test_t2v_shim_surface_on_cpu():
+    cfg, sd, z = _fixture()
+    m = _model(cfg, sd, "bf16")
+    assert set(m.state_dict()) == set(sd)
+    with pytest.raises(latte_amd.LatteError):
+        latte_amd.LatteT2V(norm_type="layer_norm")
+    if not torch.cuda.is_available():
+        with pytest.raises(latte_amd.LatteError):
+            m(torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["encoder_hidden_states"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["bf16", "f16"])
+def test_t2v_forward_matches_reference_fixture(cd):
+    cfg, sd, z = _fixture()
+    m = _model(cfg, sd, cd).to("cuda")
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    enc, mask = torch.from_numpy(z["encoder_hidden_states"]), torch.from_numpy(z["encoder_attention_mask"])
+    out = m(x.cuda(), timestep=t.cuda(), encoder_hidden_states=enc.cuda(), encoder_attention_mask=mask.cuda(),
+            added_cond_kwargs={"resolution": None, "aspect_ratio": None}, return_dict=False)[0]
+    assert out.shape == (x.shape[0], cfg.out_channels, *x.shape[2:])
+    assert rel_l2(out, torch.from_numpy(z["forward"])) < TOL
+    out = m(x.cuda(), t.cuda(), enc.cuda(), enable_temporal_attentions=False).sample
+    assert rel_l2(out, torch.from_numpy(z["forward_spatial_only"])) < TOL
+    # a padded caption token is ignored
+    enc2 = enc.clone()
+    enc2[-1, -1] += 3.0
+    a = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+    b = m(x.cuda(), t.cuda(), enc2.cuda(), encoder_attention_mask=mask.cuda()).sample
+    assert rel_l2(b[-1], a[-1]) < 1e-5
+
+
+T2V_CASES = [
+    # (heads, hd, layers, sample_size, frames, text tokens, caption channels, batch): Latte-1 width at reduced depth
+    (16, 72, 1, 16, 16, 20, 128, 1),     # T = 64: flash self-attention, temporal L = 16
+    (16, 72, 1, 32, 4, 120, 256, 2),     # T = 256: the full-sequence self-attention kernel, 120 text tokens (two key tiles)
+    (4, 64, 2, 8, 8, 7, 64, 2),          # hd = 64, ragged text length
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", T2V_CASES, ids=lambda c: "h%dx%d_L%d_s%d_f%d_k%d" % c[:6])
+def test_t2v_forward_matches_oracle(case):
+    from oracle import latte_t2v_oracle as to
+    heads, hd, layers, ss, fr, lk, cc, B = case
+    cfg = to.T2VConfig(num_attention_heads=heads, attention_head_dim=hd, num_layers=layers, sample_size=ss,
+                       cross_attention_dim=heads * hd, caption_channels=cc, video_length=fr)
+    sd = to.init_state_dict(cfg, seed=5)
+    g = torch.Generator("cpu").manual_seed(6)
+    x = torch.randn(B, 4, fr, ss, ss, generator=g)
+    t = torch.tensor([981, 44][:B])
+    enc = torch.randn(B, lk, cc, generator=g)
+    mask = torch.ones(B, lk)
+    mask[0, lk - max(lk // 3, 1):] = 0
+    with torch.no_grad():
+        want = to.latte_t2v_forward(sd, cfg, x, t, enc, mask)
+    m = _model(cfg, sd, "f16", max_batch=B).to("cuda")
+    got = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+    assert rel_l2(got, want) < TOL
+    m16 = _model(cfg, sd, "bf16", max_batch=B).to("cuda")
+    got = m16(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+    assert rel_l2(got, want) < 3e-3      # bf16 operands, random (untrained) weights with O(1) adaLN tables: see DESIGN.md section 2
