@@ -2,8 +2,8 @@
 
 Public surface = the reference entry points for the sampling hot path:
 ``Latte_models`` / ``get_models`` / ``find_model`` (models/latte.py, models/__init__.py, utils.py),
-``create_diffusion`` (diffusion/__init__.py), ``AutoencoderKL`` (diffusers, decode only), ``LattePipeline`` (sample/pipeline_latte.py, name kept;
-the T2V family is a later row), ``load_config`` (OmegaConf.load stand-in for the YAMLs).
+``create_diffusion`` (diffusion/__init__.py), ``AutoencoderKL`` (diffusers, decode only), ``LatteT2V`` / ``LattePipeline`` (models/latte_t2v.py, sample/pipeline_latte.py:
+the Latte-1 text-to-video denoiser and its sampling loop), ``load_config`` (OmegaConf.load stand-in for the YAMLs).
 """
 from ._lib import LatteError, load_library  # noqa: F401
 from .config import Config, load_config  # noqa: F401

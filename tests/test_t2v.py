@@ -93,3 +93,68 @@ def test_t2v_forward_matches_oracle(case):
     m16 = _model(cfg, sd, "bf16", max_batch=B).to("cuda")
     got = m16(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
     assert rel_l2(got, want) < 3e-3      # bf16 operands, random (untrained) weights with O(1) adaLN tables: see DESIGN.md section 2
+
+
+def test_pipeline_surface_on_cpu():
+    """LattePipeline keeps the reference's constructor / call surface (pipeline_latte.py:100-115,516-542)."""
+    from latte_amd.schedulers import DDIMScheduler
+    with pytest.raises(latte_amd.LatteError):
+        latte_amd.LattePipeline()
+    cfg, sd, z = _fixture()
+    pipe = latte_amd.LattePipeline(transformer=_model(cfg, sd, "bf16"), scheduler=DDIMScheduler())
+    assert pipe.vae_scale_factor == 8
+    with pytest.raises(ValueError):
+        pipe()
+    with pytest.raises(latte_amd.LatteError):
+        pipe(prompt="a cat")                                  # no tokenizer / text encoder given
+    with pytest.raises(latte_amd.LatteError):
+        pipe(prompt_embeds=torch.zeros(1, 6, cfg.caption_channels), negative_prompt_embeds=torch.zeros(1, 6, cfg.caption_channels),
+             enable_vae_temporal_decoder=True)
+    emb = torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 1, 5, 3)
+    mask = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 0, 0, 0]], dtype=torch.float32)
+    out, keep = pipe.mask_text_embeddings(emb, mask)          # batch > 1: zeroed, not cut (pipeline_latte.py:122-125)
+    assert keep == 5 and float(out[1, 0, 2:].abs().sum()) == 0.0
+    out, keep = pipe.mask_text_embeddings(emb[:1], mask[:1])  # batch 1: cut to the kept tokens
+    assert keep == 3 and out.shape == (1, 1, 3, 3)
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps[:3].tolist() == [980, 960, 940] and s.timesteps[-1].item() == 0
+
+
+@pytest.mark.gpu
+def test_pipeline_guided_ddim_chain_matches_oracle_loop():
+    """The denoising loop of pipeline_latte.py:700-760 (guidance pair [negative, prompt], learned-sigma drop, scheduler step)
+    around the engine denoiser vs the same loop around the oracle denoiser; then the per-frame VAE decode hand-off."""
+    from oracle import latte_t2v_oracle as to
+    from oracle import vae_oracle as vo
+    from latte_amd.schedulers import DDIMScheduler
+    cfg, sd, z = _fixture()
+    g = torch.Generator("cpu").manual_seed(9)
+    pe, ne = torch.randn(1, 6, cfg.caption_channels, generator=g), torch.randn(1, 6, cfg.caption_channels, generator=g)
+    lat = torch.randn(1, 4, cfg.video_length, cfg.sample_size, cfg.sample_size, generator=g)
+    steps, scale = 4, 4.5
+    sch = DDIMScheduler()
+    sch.set_timesteps(steps)
+    want = lat.clone()
+    with torch.no_grad():
+        for t in sch.timesteps:
+            x2 = torch.cat([want] * 2)
+            out = to.latte_t2v_forward(sd, cfg, x2, t.reshape(1).expand(2), torch.cat([ne, pe]))
+            unc, txt = out.chunk(2)
+            eps = (unc + scale * (txt - unc)).chunk(2, dim=1)[0]
+            want = sch.step(eps, t, want, return_dict=False)[0]
+    pipe = latte_amd.LattePipeline(transformer=_model(cfg, sd, "f16"), scheduler=DDIMScheduler()).to("cuda")
+    got = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps, guidance_scale=scale, latents=lat,
+               output_type="latents").video
+    assert rel_l2(got, want) < 2e-3          # four guided steps at scale 4.5 on an untrained tiny model (f16 operands)
+    # decode hand-off (pipeline_latte.py:773-785) on a 16x16 latent (the VAE engine's smallest): uint8 [b, f, h, w, c]
+    vsd = vo.init_state_dict(seed=2)
+    vae = latte_amd.AutoencoderKL(latent_size=16, max_frames=2, compute_dtype="f16")
+    vae.load_state_dict(vsd)
+    pipe2 = latte_amd.LattePipeline(vae=vae, transformer=_model(cfg, sd, "f16"), scheduler=DDIMScheduler()).to("cuda")
+    zl = torch.randn(1, 4, 2, 16, 16, generator=g)
+    video = pipe2.decode_latents(zl.cuda())
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (1, 2, 128, 128, 3)
+    ref = vo.decode(vsd, (zl / 0.18215).permute(0, 2, 1, 3, 4).reshape(2, 4, 16, 16))
+    ref = ((ref / 2.0 + 0.5).clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert (video[0].int() - ref.int()).abs().float().mean() < 1.0
