@@ -68,6 +68,15 @@ __device__ __forceinline__ int64_t seq_base_row(const AttnArgs& a, int seq) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// hardware transpose read: lane i of a 16-lane group supplies the address of 4 d-values of key (i >> 2) of a ROW-MAJOR image
+// and receives the 4 keys of d-column i (see attn_full_kernel below)
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short i16v4;
+template <int DT>
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {   // 16-bit elements: the bit pattern is dtype-agnostic
+  i16v4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16v4*)p);
+  return __builtin_bit_cast(u32x2, v);
+}
+
 // CROSS = true (LatteT2V attn2): queries from a [rows, q_ld] buffer, Lk keys / values per SAMPLE from a.kv ([K | V], 2D
 // columns), an optional additive score bias per (sample, key); everything else is the same kernel.
 template <int HD, int DT, bool CROSS = false>
@@ -75,9 +84,10 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;  // k-steps of the QK^T contraction (hd padded to 32)
   constexpr int DF = (HD + 15) / 16;  // 16-wide d fragments of the PV product
   constexpr int NCH = HD / 8;         // 16-byte chunks per head row
-  __shared__ __attribute__((aligned(16))) char lds[64 * PITCH + DF * 16 * PITCH];
+  constexpr int VP = 160;             // row pitch of the row-major V image: conflict-free for the transpose reads
+  __shared__ __attribute__((aligned(16))) char lds[64 * PITCH + 64 * VP];
   char* const k_lds = lds;
-  char* const vt_lds = lds + 64 * PITCH;
+  char* const v_lds = lds + 64 * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fl = lane & 15, g = lane >> 4;
@@ -126,16 +136,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
         vv = *(const u32x4*)(rowp + 2 * a.D);
       }
       *(u32x4*)(k_lds + key * PITCH + ch * 16) = kv;
-      // transposed V image: element (d, key) at vt[d][slot(key)], slot = MFMA k-slot order:
-      // within each 32-key group  slot = g*8 + half*4 + r  for  key = half*16 + g*4 + r
-      const int k5 = key & 31;
-      const int slot = (key & 32) + ((k5 >> 2) & 3) * 8 + (k5 >> 4) * 4 + (k5 & 3);
-      half_t* vcol = (half_t*)(vt_lds + (ch * 8) * PITCH) + slot;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vcol[(2 * e) * (PITCH / 2)] = (half_t)(vv[e] & 0xffffu);
-        vcol[(2 * e + 1) * (PITCH / 2)] = (half_t)(vv[e] >> 16);
-      }
+      *(u32x4*)(v_lds + key * VP + ch * 16) = vv;     // row-major: V^T fragments come out of ds_read_b64_tr_b16
     }
     __syncthreads();
 
@@ -193,8 +194,11 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
                         pack2<DT>(st[2 * ks2 + 1][0], st[2 * ks2 + 1][1]), pack2<DT>(st[2 * ks2 + 1][2], st[2 * ks2 + 1][3])};
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const u32x4 vf = *(const u32x4*)(vt_lds + (16 * d + fl) * PITCH + ks2 * 64 + g * 16);
-        o[d] = mfma_k32<DT>(vf, pb, o[d]);
+        // pad d-columns (>= HD) read finite neighbouring data and only produce unused O rows
+        const char* vb = v_lds + (32 * ks2 + 4 * g + (fl >> 2)) * VP + (fl & 3) * 8 + d * 32;
+        const u32x2 lo = lds_tr16<DT>(vb);
+        const u32x2 hi = lds_tr16<DT>(vb + 16 * VP);
+        o[d] = mfma_k32<DT>((u32x4){lo[0], lo[1], hi[0], hi[1]}, pb, o[d]);
       }
     }
   }
@@ -224,12 +228,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
 // 4 keys of d-column i), so V is never transposed in memory.
 // Row pitch 160 B (10 chunks) for both images: conflict-free for the b128 K reads (row 10r + chunk distinct mod 16
 // inside every 16-lane service group) and for the tr reads (8 rows x 32 B tile the 64 banks).
-typedef __attribute__((__vector_size__(4 * sizeof(short)))) short i16v4;
-template <int DT>
-__device__ __forceinline__ u32x2 lds_tr16(const char* p) {   // 16-bit elements: the bit pattern is dtype-agnostic
-  i16v4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16v4*)p);
-  return __builtin_bit_cast(u32x2, v);
-}
+
 
 template <int HD, int DT>
 __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
