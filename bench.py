@@ -109,9 +109,9 @@ def vae_decode_rate(device):
     """VAE decode of one 16-frame video (latents 16x4x32x32 -> 16x256x256x3 uint8), random sd-vae-ft-shaped weights;
     reported beside the headline, outside its timed region (decode is ~1.5 % of a 250-step chain)."""
     import latte_amd
-    from oracle import vae_oracle as vo
+    from latte_amd.random_init import vae_decoder_state_dict
     vae = latte_amd.AutoencoderKL(latent_size=32, max_frames=16, compute_dtype="f16")
-    vae.load_state_dict(vo.init_state_dict(0))
+    vae.load_state_dict(vae_decoder_state_dict(0))
     vae.to(device)
     lat = torch.randn(1, 16, 4, 32, 32, device=device) * 0.18215
     vae.decode_video_uint8(lat)

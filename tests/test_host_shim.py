@@ -119,3 +119,28 @@ def test_avi_round_trip(tmp_path):
         assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and int.from_bytes(raw[4:8], "little") == len(raw) - 8
     with pytest.raises(ValueError):
         write_avi(str(tmp_path / "bad.avi"), np.zeros((2, 4, 4), dtype=np.uint8))
+
+
+def test_oracle_is_only_imported_by_the_checkers():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+    The package, the tools and the rest of bench.py must not (random weights for plumbing runs come from
+    latte_amd.random_init)."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        hits = []
+        tree = ast.parse(open(path).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            for n in ast.iter_child_nodes(fn) if isinstance(fn, ast.Module) else ast.walk(fn):
+                if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle":
+                    hits.append(fn.name if isinstance(fn, ast.FunctionDef) else "<module>")
+                if isinstance(n, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in n.names):
+                    hits.append(fn.name if isinstance(fn, ast.FunctionDef) else "<module>")
+        return hits
+
+    for path in glob.glob(os.path.join(root, "latte_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")):
+        assert oracle_imports(path) == [], path
+    assert set(oracle_imports(os.path.join(root, "bench.py"))) <= {"cpu_baseline"}
+    assert set(oracle_imports(os.path.join(root, "__graft_entry__.py"))) <= {"smoke"}

@@ -179,77 +179,6 @@ def normal_check():
     log(f"fill_normal: mean={out.mean().item():.4f} std={out.std().item():.4f} kurt={(out**4).mean().item():.3f} finite={bool(torch.isfinite(out).all())}")
 
 
-def golden_parity():
-    from _util import engine_model, load_golden_model, rel_l2
-    import latte_amd
-    for name in ("tiny_classcond", "tiny_uncond"):
-        kw, sd, r = load_golden_model(name)
-        for cd in ("bf16", "f16"):
-            m = engine_model(kw, sd, cd, max_batch=2)
-            x = torch.from_numpy(r["x"]).to(dev)
-            t = torch.from_numpy(r["t"]).to(dev)
-            y = torch.from_numpy(r["y"]).to(dev) if "y" in r else None
-            out = m(x, t, y=y)
-            log(f"{name} {cd} forward: rel-L2 {rel_l2(out, torch.from_numpy(r['forward'])):.3e}")
-            if "forward_with_cfg" in r:
-                out = m.forward_with_cfg(torch.from_numpy(r["x_cfg"]).to(dev), t, y=torch.from_numpy(r["y_cfg"]).to(dev), cfg_scale=7.0)
-                log(f"{name} {cd} forward_with_cfg: rel-L2 {rel_l2(out, torch.from_numpy(r['forward_with_cfg'])):.3e}")
-            steps = int(r["loop_steps"])
-            d = latte_amd.create_diffusion(str(steps))
-            if "x_cfg" in r:
-                z = torch.from_numpy(r["x_cfg"]).to(dev)
-                fn, mk = m.forward_with_cfg, dict(y=torch.from_numpy(r["y_cfg"]).to(dev), cfg_scale=7.0)
-            else:
-                z = x
-                fn, mk = m.forward, dict(y=y)
-            # feed the reference's noise draws through the C loop directly
-            for method, mi in (("ddim", 1), ("ddpm", 0)):
-                xx = z.clone().contiguous()
-                nz = torch.from_numpy(r[f"{method}_noises"]).to(dev).contiguous()
-                ts = torch.empty((steps,) + tuple(xx.shape), device=dev)
-                t0s = torch.empty_like(ts)
-                eng = m.engine(xx.shape[0])
-                yy = mk.get("y")
-                check(lib.latte_sample_loop(eng, d._h, mi, 0.0, 0, float(mk.get("cfg_scale", 1.0)), ptr(xx), ptr(yy), xx.shape[0],
-                                            steps - 1, 0, ptr(nz), ptr(ts), ptr(t0s), stream_ptr()))
-                torch.cuda.synchronize()
-                ref_s = torch.from_numpy(r[f"{method}_samples"])
-                ref_0 = torch.from_numpy(r[f"{method}_pred_xstart"])
-                per = [f"{rel_l2(ts[k], ref_s[k]):.1e}" for k in range(steps)]
-                log(f"{name} {cd} {method} loop: final rel-L2 {rel_l2(xx, ref_s[-1]):.3e}; per-step sample {per}; x0 last {rel_l2(t0s[-1], ref_0[-1]):.3e}")
-
-
-def oracle_parity():
-    from _util import rel_l2
-    from oracle import latte_oracle as lo
-    from latte_amd.models import Latte_models
-    cases = [("Latte-S/2", dict(input_size=8, num_frames=4, num_classes=101, extras=2), 2),
-             ("Latte-S/2", dict(input_size=32, num_frames=4, extras=1), 1),
-             ("Latte-B/2", dict(input_size=16, num_frames=16, extras=1), 1),
-             ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 1)]
-    for name, kw, B in cases:
-        cfg = lo.preset_config(name, **kw)
-        sd = lo.init_state_dict(cfg, seed=0)
-        g = torch.Generator("cpu").manual_seed(1)
-        x = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
-        t = torch.tensor([999, 12][:B])
-        y = torch.tensor([7, 101][:B]) if kw["extras"] == 2 else None
-        t0 = time.time()
-        with torch.no_grad():
-            ref = lo.latte_forward(sd, cfg, x, t, y)
-        t_or = time.time() - t0
-        for cd in ("bf16", "f16"):
-            m = Latte_models[name](compute_dtype=cd, max_batch=B, **kw)
-            m.load_state_dict(sd)
-            m = m.to(dev)
-            out = m(x.to(dev), t.to(dev), y=None if y is None else y.to(dev))
-            torch.cuda.synchronize()
-            eps_rel = rel_l2(out[:, :, :4], ref[:, :, :4])
-            log(f"{name} {kw} B={B} {cd}: rel-L2 all {rel_l2(out, ref):.3e} eps-only {eps_rel:.3e} (oracle {t_or:.1f}s)")
-            del m
-            torch.cuda.empty_cache()
-
-
 def gemm_bench():
     ms = _lib.c_f32()
     for M in (4096, 8192, 32768):
@@ -392,7 +321,6 @@ def gemm_stagger():
 
 
 def xl_profile():
-    from oracle import latte_oracle as lo
     from latte_amd.models import Latte_models
     import latte_amd
     kw = dict(input_size=32, num_frames=16, extras=1)
@@ -432,6 +360,6 @@ def xl_profile():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["env", "tr16_probe", "gemm_checks", "attention_checks", "ln_checks", "normal_check",
-                             "golden_parity", "oracle_parity", "gemm_bench", "xl_profile"]
+                             "gemm_bench", "xl_profile"]
     for w in which:
         section(globals()[w])

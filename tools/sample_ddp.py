@@ -67,10 +67,9 @@ def main():
         if a.vae:
             vae = latte_amd.AutoencoderKL.from_pretrained(a.vae, latent_size=args.latent_size, max_frames=args.num_frames)
         else:
-            sys.path.insert(0, ROOT)
-            from oracle import vae_oracle  # random decoder weights only (no checkpoint offline)
+            from latte_amd.random_init import vae_decoder_state_dict   # random decoder weights (no checkpoint offline)
             vae = latte_amd.AutoencoderKL(latent_size=args.latent_size, max_frames=args.num_frames)
-            vae.load_state_dict(vae_oracle.init_state_dict(0))
+            vae.load_state_dict(vae_decoder_state_dict(0))
         vae.to(device)
 
     out_dir = a.out or args.get("save_video_path") or "./sample_videos"

@@ -43,14 +43,11 @@ def main():
     scheduler = DDIMScheduler(beta_start=args.beta_start, beta_end=args.beta_end, beta_schedule=args.beta_schedule, clip_sample=False)
     tokenizer = text_encoder = None
     if a.random:
-        sys.path.insert(0, ROOT)
-        from oracle import latte_t2v_oracle as to          # random-weight generators only
-        from oracle import vae_oracle as vo
-        cfg = to.T2VConfig(num_layers=a.layers, sample_size=latent, video_length=args.video_length)
+        from latte_amd.random_init import t2v_state_dict, vae_decoder_state_dict
         transformer = latte_amd.LatteT2V(num_layers=a.layers, sample_size=latent, video_length=args.video_length,
-                                         compute_dtype=cdt, max_batch=2).load_state_dict(to.init_state_dict(cfg, seed=0))
+                                         compute_dtype=cdt, max_batch=2).load_state_dict(t2v_state_dict(0, num_layers=a.layers))
         vae = latte_amd.AutoencoderKL(latent_size=latent, max_frames=args.video_length, compute_dtype="f16")
-        vae.load_state_dict(vo.init_state_dict(0))
+        vae.load_state_dict(vae_decoder_state_dict(0))
     else:
         from transformers import T5EncoderModel, T5Tokenizer
         p = args.pretrained_model_path

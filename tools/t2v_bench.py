@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import latte_amd  # noqa: E402
-from oracle import latte_t2v_oracle as to  # noqa: E402  (random-weight generator only)
+from latte_amd.random_init import t2v_state_dict  # noqa: E402
 
 
 def main():
@@ -25,8 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
-    cfg = to.T2VConfig(num_layers=a.layers)
-    sd = to.init_state_dict(cfg, seed=0)
+    sd = t2v_state_dict(0, num_layers=a.layers)
     m = latte_amd.LatteT2V(num_layers=a.layers, compute_dtype=a.dtype, max_batch=a.batch).load_state_dict(sd).to("cuda")
     B = a.batch
     x = torch.randn(B, 4, 16, 64, 64, device="cuda")
