@@ -158,3 +158,30 @@ def test_pipeline_guided_ddim_chain_matches_oracle_loop():
     ref = vo.decode(vsd, (zl / 0.18215).permute(0, 2, 1, 3, 4).reshape(2, 4, 16, 16))
     ref = ((ref / 2.0 + 0.5).clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1)
     assert (video[0].int() - ref.int()).abs().float().mean() < 1.0
+
+
+def test_ddim_scheduler_standin_closed_form():
+    """latte_amd.schedulers.DDIMScheduler (memory-derived stand-in, unpinned): a full eta = 0 chain on a model that returns the
+    TRUE noise recovers x0 exactly, the last step lands on alpha_bar_prev = 1, and the update is the DDIM closed form."""
+    from latte_amd.schedulers import DDIMScheduler
+    s = DDIMScheduler()
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(1, 4, 2, 4, 4, generator=g, dtype=torch.float64)
+    eps = torch.randn(1, 4, 2, 4, 4, generator=g, dtype=torch.float64)
+    a = float(s.alphas_cumprod[900])
+    x = a ** 0.5 * x0 + (1 - a) ** 0.5 * eps
+    for t in s.timesteps:
+        at = float(s.alphas_cumprod[int(t)])
+        true_eps = (x - at ** 0.5 * x0) / (1 - at) ** 0.5
+        x = s.step(true_eps, t, x, return_dict=False)[0]
+    assert float((x - x0).abs().max()) < 1e-9
+    # one step against the closed form
+    s.set_timesteps(4)
+    t = s.timesteps[1]                      # 500 -> 250
+    xt = torch.randn(2, 3, generator=g, dtype=torch.float64)
+    e = torch.randn(2, 3, generator=g, dtype=torch.float64)
+    at, ap = float(s.alphas_cumprod[500]), float(s.alphas_cumprod[250])
+    want = ap ** 0.5 * (xt - (1 - at) ** 0.5 * e) / at ** 0.5 + (1 - ap) ** 0.5 * e
+    assert float((s.step(e, t, xt, return_dict=False)[0] - want).abs().max()) < 1e-12
