@@ -13,7 +13,9 @@ extern "C" {
 
 /* C[M,N] = A[M,K] W[N,K]^T with epilogue epi: 0 half=acc+bias | 1 half=gelu_tanh(acc+bias) |
  * 2 out_f32[m,n] += gate[(m / rows_per_sample) * gate_stride + n] * (acc+bias) | 3 out_f32 = acc+bias.
- * A must be allocated with rows padded to a multiple of 256.  (nn.Linear, latte.py:43,45,171) */
+ * A must be allocated with rows padded to a multiple of 256.  (nn.Linear, latte.py:43,45,171)
+ * variant: tile configuration as in csrc/common.h (0 = the engine's choice, 10 = deferred read-modify-write kernel for
+ * epi 2) + 1000 * call-site tag (0 attention out-projection, 1 fc2: separate kernel symbols for the profiler). */
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
                      int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
 /* Attention core of latte.py:50-70 on a [rows, 3*D] qkv buffer (see AttnArgs in csrc/common.h). */
@@ -38,8 +40,15 @@ int latte_debug_conv3x3(const void* in, const float* w, const float* bias, const
 int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
                           int dtype, void* stream);
 
+/* The forms the decoder's fp32 residual stream uses: out32[N,Ho,Wo,Cout] = conv(in half) + bias (+ res32), nothing rounded to
+ * half; GroupNorm [+ SiLU] of an fp32 NHWC input to a half output. */
+int latte_debug_conv3x3_f32(const void* in, const float* w, const float* bias, const float* res32, float* out32, int N, int H,
+                            int W, int Cin, int Cout, int ups, int dtype, void* stream);
+int latte_debug_groupnorm_f32(const float* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
+                              int dtype, void* stream);
+
 /* Runs the VAE decoder (include/latte_amd.h) up to and including stage `stop_after` and returns that stage's NHWC
- * activation widened to fp32 (trace_dims = N, H, W, C).  Stages: 0 conv_in, 1 mid.resnets.0, 2 mid.attentions.0,
+ * activation (the fp32 residual stream) (trace_dims = N, H, W, C).  Stages: 0 conv_in, 1 mid.resnets.0, 2 mid.attentions.0,
  * 3 mid.resnets.1, then for up block i: three resnets and (i < 3) the upsampler -> 4..18.  Localises a divergence. */
 struct latte_vae;
 int latte_debug_vae_trace(struct latte_vae* v, const float* z, int n_frames, float z_scale, int stop_after, float* trace_out,

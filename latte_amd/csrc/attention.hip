@@ -535,12 +535,8 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
     if (small)                                                                                                \
       hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);                                 \
     else if (full) {                                                                                          \
-      static bool attr_done = false;                                                                          \
-      if (!attr_done) {                                                                                       \
-        LATTE_HIP(hipFuncSetAttribute((const void*)attn_full_kernel<HD, DT>,                                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, FULL_LDS));                 \
-        attr_done = true;                                                                                     \
-      }                                                                                                       \
+      static std::atomic<uint64_t> attr_done{0};                                                              \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_full_kernel<HD, DT>, FULL_LDS, attr_done)) return rc_; \
       hipLaunchKernelGGL((attn_full_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                           \
     } else                                                                                                    \
       hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);                                 \

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,19 @@ int fail(int code, const std::string& msg);
     if (e_ != hipSuccess)                                                                    \
       return ::latte::fail(LATTE_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE function attribute: the opt-in is remembered per device
+// id (bit mask, thread-safe), so an engine created on a second GPU of the same process gets its own.
+inline int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  LATTE_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    LATTE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return LATTE_OK;
+}
 
 // 16-bit storage element (bf16 or f16 bit pattern depending on the engine's compute dtype)
 typedef uint16_t half_t;
@@ -63,10 +77,12 @@ struct GemmArgs {
   int gate_stride;
   int rows_per_sample;
   int stagger;        // persistent kernel: number of start cohorts (0/1 = none); cohort c sleeps c/stagger of a tile time
+  int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
-// 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
+// 8 = 256x192, 9 = 256x256   (N % tileN == 0 required); 10 = 256x192 persistent kernel with the deferred
+// read-modify-write epilogue (EPI_GATE_RES_F32 only; falls back to 8 when the problem is not eligible)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);
@@ -133,14 +149,16 @@ int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStr
 int launch_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);
 
 // ---- VAE decoder kernels (vae.hip) -----------------------------------------------------------------
+// out32 != nullptr: fp32 output  out32 = conv + bias (+ res32)  (the decoder's residual stream is fp32); else half `out` (+ res)
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
-                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st);
-int launch_groupnorm(const half_t* x, half_t* y, const float* gamma, const float* beta, float* partial, float* stats, int N,
-                     int HW, int C, int silu, int dtype, hipStream_t st);
+                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
+                   const float* res32 = nullptr, float* out32 = nullptr);
+// x: half [N, HW, C] or (x_is_f32) fp32; y: half
+int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st);
 int groupnorm_max_slabs();
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st);
-int launch_conv_in(const float* x, const float* wt, const float* bias, half_t* out, int N, int H, int W, int Cout, int dtype,
-                   hipStream_t st);
+int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st);
 int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* out, int N, int H, int W, int C, int out_mode,
                     int dtype, hipStream_t st);
 int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st);

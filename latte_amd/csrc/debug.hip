@@ -134,11 +134,8 @@ extern "C" {
 // out: int64 [8 waves][2] = {ticks spent issuing, ticks until landed}, each summed over `reps` bursts of 16 instructions.
 int latte_debug_dma_probe(const void* src_1gib_window, long long* out, int mode, int waves, int reps, void* stream) {
   if (waves < 1 || waves > 8) return fail(LATTE_ERR_INVALID, "dma_probe: waves must be 1..8");
-  static bool attr_done = false;
-  if (!attr_done) {
-    LATTE_HIP(hipFuncSetAttribute((const void*)dma_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc_ = ensure_dynamic_lds((const void*)dma_probe_kernel, 8 * 16384, attr_done)) return rc_;
   hipLaunchKernelGGL(dma_probe_kernel, dim3(256), dim3(64 * waves), 8 * 16384, (hipStream_t)stream, (const char*)src_1gib_window,
                      out, mode, reps);
   LATTE_HIP(hipGetLastError());
@@ -151,6 +148,7 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
   g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = out; g.gate = gate;
   g.M = M; g.N = N; g.K = K; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample;
   if (epi == EPI_BIAS_RES_H16) g.res = (const half_t*)gate;   // epi 5: `gate` carries the half residual [Mpad, N]
+  if (variant >= 1000) { g.tag = variant / 1000; variant %= 1000; }   // + 1000 * call-site tag (GemmArgs::tag)
   return launch_gemm(g, epi, dtype, variant, (hipStream_t)stream);
 }
 
@@ -192,13 +190,42 @@ int latte_debug_conv3x3(const void* in, const float* w, const float* bias, const
   return rc;
 }
 
+/* The decoder's fp32-stream forms: out32 = conv(in) + bias (+ res32), and GroupNorm of an fp32 input. */
+int latte_debug_conv3x3_f32(const void* in, const float* w, const float* bias, const float* res32, float* out32, int N, int H,
+                            int W, int Cin, int Cout, int ups, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  half_t *wp = nullptr, *zeros = nullptr;
+  LATTE_HIP(hipMalloc((void**)&wp, (size_t)Cout * Cin * 9 * 2));
+  LATTE_HIP(hipMalloc((void**)&zeros, 64));
+  LATTE_HIP(hipMemsetAsync(zeros, 0, 64, st));
+  int rc = launch_pack_conv_w(w, wp, Cout, Cin, dtype, st);
+  if (!rc) rc = launch_conv3x3((const half_t*)in, wp, bias, nullptr, nullptr, zeros, N, H, W, Cin, Cout, ups, dtype, st, res32, out32);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(wp);
+  (void)hipFree(zeros);
+  return rc;
+}
+
+int latte_debug_groupnorm_f32(const float* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
+                              int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float *partial = nullptr, *stats = nullptr;
+  LATTE_HIP(hipMalloc((void**)&partial, (size_t)N * groupnorm_max_slabs() * 64 * 4));
+  LATTE_HIP(hipMalloc((void**)&stats, (size_t)N * 64 * 4));
+  int rc = launch_groupnorm(x, 1, (half_t*)y, gamma, beta, partial, stats, N, HW, C, silu, dtype, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(partial);
+  (void)hipFree(stats);
+  return rc;
+}
+
 int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,
                           int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   float *partial = nullptr, *stats = nullptr;
   LATTE_HIP(hipMalloc((void**)&partial, (size_t)N * groupnorm_max_slabs() * 64 * 4));
   LATTE_HIP(hipMalloc((void**)&stats, (size_t)N * 64 * 4));
-  int rc = launch_groupnorm((const half_t*)x, (half_t*)y, gamma, beta, partial, stats, N, HW, C, silu, dtype, st);
+  int rc = launch_groupnorm(x, 0, (half_t*)y, gamma, beta, partial, stats, N, HW, C, silu, dtype, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(partial);
   (void)hipFree(stats);

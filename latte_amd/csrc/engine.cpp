@@ -198,7 +198,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
     if ((rc = launch_attention(a, dt, st))) return rc;
     tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
-    g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D;
+    g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
@@ -206,7 +206,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC1);
-    g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm;
+    g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[3] ? e->gemm_variant_of[3] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC2);
   }
@@ -420,7 +420,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..9");
+    if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..9");   // (10 is per-GEMM only)
     const int bn = value >= 7 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
@@ -430,7 +430,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   for (int gi = 0; gi < 4; ++gi) {
     static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
     if (k == names[gi]) {
-      if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..9");
+      if (value < 0 || value > 10) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..10");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }
@@ -666,7 +666,8 @@ int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, c
 }
 
 int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int iters, float* ms_per_launch, void* stream) {
-  int stagger = 0;
+  int stagger = 0, tag = 0;
+  if (variant >= 1000) { tag = variant / 1000; variant %= 1000; }    // measurement: + 1000 * call-site tag (GemmArgs::tag)
   if (variant >= 100) { stagger = variant / 100; variant %= 100; }   // measurement: variant + 100 * cohorts
   if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(LATTE_ERR_INVALID, "bench_gemm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -693,7 +694,7 @@ int latte_bench_gemm(int M, int N, int K, int epi, int dtype, int variant, int i
   if (!rc) rc = launch_fill_normal(gate, (size_t)N, 8, 0, st);
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.gate = gate; g.M = M; g.N = N; g.K = K;
-  g.gate_stride = 0; g.rows_per_sample = M; g.stagger = stagger;
+  g.gate_stride = 0; g.rows_per_sample = M; g.stagger = stagger; g.tag = tag;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);

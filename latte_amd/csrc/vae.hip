@@ -36,7 +36,9 @@ struct ConvArgs {
   const half_t* w;      // [Cout, 9 * Cin], k = (ky * 3 + kx) * Cin + ci
   const float* bias;    // [Cout]
   const half_t* res;    // nullptr or [N, Hout, Wout, Cout] residual (may alias out)
-  half_t* out;          // [N, Hout, Wout, Cout]
+  half_t* out;          // [N, Hout, Wout, Cout]  (ignored when out32 is set)
+  const float* res32;   // fp32 residual (the decoder's residual stream) or nullptr; may alias out32
+  float* out32;         // fp32 output: out32 = acc + bias (+ res32), nothing is rounded to half
   const half_t* zeros;  // >= 16 bytes of zeros (padded taps)
   int N, Hin, Win, Cin, Cout, ups;   // Hout = Hin << ups
 };
@@ -145,6 +147,14 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
       const float4 b4 = *(const float4*)(g.bias + n);
       float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
       const size_t o = (size_t)m * g.Cout + n;
+      if (g.out32 != nullptr) {   // fp32 stream: the skip path is never rounded (wave-uniform branch)
+        if (g.res32 != nullptr) {
+          const float4 r4 = *(const float4*)(g.res32 + o);
+          v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
+        }
+        *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
+        continue;
+      }
       if (g.res != nullptr) {
         const u32x2 r2 = *(const u32x2*)(g.res + o);
         float r0, r1, r2f, r3;
@@ -161,8 +171,21 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // partial[n][slab][g] = (sum, sumsq) over the slab's pixels and the group's channels.  One thread owns 8 consecutive
 // channels of a pixel (16-byte loads); the per-thread sums are combined in a FIXED order (deterministic).
-template <int DT>
-__global__ void __launch_bounds__(256) gn_partial_kernel(const half_t* __restrict__ x, float* __restrict__ partial, int HW,
+// 8 consecutive channels of a pixel: from the half activation (16-byte load) or from the fp32 residual stream
+template <int DT, bool IN32>
+__device__ __forceinline__ void load_oct(const void* x, size_t oct_index, float (&f)[8]) {
+  if constexpr (IN32) {
+    const float4 a = *(const float4*)((const float*)x + oct_index * 8), b = *(const float4*)((const float*)x + oct_index * 8 + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    const u32x4 v = *(const u32x4*)((const half_t*)x + oct_index * 8);
+    unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
+    unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+  }
+}
+
+template <int DT, bool IN32>
+__global__ void __launch_bounds__(256) gn_partial_kernel(const void* __restrict__ x, float* __restrict__ partial, int HW,
                                                          int C, int slabs) {
   __shared__ float red[256 * 4];
   const int n = blockIdx.y, slab = blockIdx.x;
@@ -173,12 +196,12 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const half_t* __restric
   const int p0 = slab * per, p1 = min(HW, p0 + per);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;   // channels [8 oct, +4) and [8 oct + 4, +4)
   for (int p = p0 + pl; p < p1; p += px_per_it) {
-    const u32x4 v = *(const u32x4*)(x + ((size_t)n * HW + p) * C + oct * 8);
-    float a, b;
-    unpack2<DT>(v[0], a, b); s0 += a + b; q0 += a * a + b * b;
-    unpack2<DT>(v[1], a, b); s0 += a + b; q0 += a * a + b * b;
-    unpack2<DT>(v[2], a, b); s1 += a + b; q1 += a * a + b * b;
-    unpack2<DT>(v[3], a, b); s1 += a + b; q1 += a * a + b * b;
+    float f[8];
+    load_oct<DT, IN32>(x, ((size_t)n * HW + p) * oct_per_px + oct, f);
+    s0 += f[0] + f[1]; q0 += f[0] * f[0] + f[1] * f[1];
+    s0 += f[2] + f[3]; q0 += f[2] * f[2] + f[3] * f[3];
+    s1 += f[4] + f[5]; q1 += f[4] * f[4] + f[5] * f[5];
+    s1 += f[6] + f[7]; q1 += f[6] * f[6] + f[7] * f[7];
   }
   red[threadIdx.x * 4 + 0] = s0; red[threadIdx.x * 4 + 1] = q0;
   red[threadIdx.x * 4 + 2] = s1; red[threadIdx.x * 4 + 3] = q1;
@@ -217,8 +240,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
   stats[(n * 32 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-template <int DT, bool SILU>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
+template <int DT, bool SILU, bool IN32>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const void* __restrict__ x, half_t* __restrict__ y,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int HW, int C, size_t total_oct) {
   const int cpg = C >> 5, oct_per_px = C >> 3;
@@ -227,10 +250,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const half_t* __restrict_
     const size_t px = i / oct_per_px;
     const int n = (int)(px / HW);
     const int c0 = oct * 8;
-    const u32x4 v = *(const u32x4*)(x + i * 8);
     float f[8];
-    unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
-    unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+    load_oct<DT, IN32>(x, i, f);
     const float4 ga = *(const float4*)(gamma + c0), gb = *(const float4*)(gamma + c0 + 4);
     const float4 ba = *(const float4*)(beta + c0), bb = *(const float4*)(beta + c0 + 4);
     const float gam[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
@@ -268,10 +289,9 @@ __global__ void post_quant_kernel(const float* __restrict__ z, const float* __re
   }
 }
 
-// conv_in: [N, h, w, 4] fp32 -> [N, h, w, Cout] half, 3x3 pad 1.  wt = [36][Cout] fp32 (k = (ky*3+kx)*4 + ci).
-template <int DT>
+// conv_in: [N, h, w, 4] fp32 -> [N, h, w, Cout] fp32 (the residual stream), 3x3 pad 1.  wt = [36][Cout] fp32 (k = (ky*3+kx)*4 + ci).
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                      const float* __restrict__ bias, half_t* __restrict__ out, int N, int H,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int N, int H,
                                                       int W, int Cout) {
   __shared__ float patch[36];
   const int p = blockIdx.x;   // output pixel
@@ -290,7 +310,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
       a0 = fmaf(patch[k], w2.x, a0);
       a1 = fmaf(patch[k], w2.y, a1);
     }
-    *(unsigned int*)(out + (size_t)p * Cout + co) = pack2<DT>(a0, a1);
+    *(float2*)(out + (size_t)p * Cout + co) = make_float2(a0, a1);
   }
 }
 
@@ -417,18 +437,17 @@ inline int grid_for(size_t n, int block) {
 }  // namespace
 
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
-                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st) {
+                   const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
+                   const float* res32, float* out32) {
   if (Cin % 64 != 0 || Cout % 128 != 0) return fail(LATTE_ERR_INVALID, "conv3x3: need Cin % 64 == 0 and Cout % 128 == 0");
-  ConvArgs a{in, w, bias, res, out, zeros, N, Hin, Win, Cin, Cout, ups};
+  if (!out && !out32) return fail(LATTE_ERR_INVALID, "conv3x3: no output");
+  ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups};
   const int M = N * (Hin << ups) * (Win << ups);
   const int tiles = ((M + 127) / 128) * (Cout / 128);
   constexpr int LDS = 2 * 256 * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    LATTE_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<LATTE_DTYPE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    LATTE_HIP(hipFuncSetAttribute((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_bf16{0}, attr_f16{0};
+  if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_BF16>, LDS, attr_bf16)) return rc_;
+  if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, LDS, attr_f16)) return rc_;
   if (dtype == LATTE_DTYPE_BF16) {
     hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_BF16>, dim3(tiles), dim3(256), LDS, st, a);
   } else {
@@ -438,21 +457,24 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   return LATTE_OK;
 }
 
-int launch_groupnorm(const half_t* x, half_t* y, const float* gamma, const float* beta, float* partial, float* stats, int N,
-                     int HW, int C, int silu, int dtype, hipStream_t st) {
+int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st) {
   if (C != 128 && C != 256 && C != 512) return fail(LATTE_ERR_INVALID, "groupnorm: C must be 128, 256 or 512");
   int slabs = HW / 1024;
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
   const size_t total_oct = (size_t)N * HW * C / 8;
   const bool bf = dtype == LATTE_DTYPE_BF16;
-  if (bf) hipLaunchKernelGGL(gn_partial_kernel<LATTE_DTYPE_BF16>, dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
-  else hipLaunchKernelGGL(gn_partial_kernel<LATTE_DTYPE_F16>, dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  else if (bf) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_BF16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), 1e-6f);
   const dim3 grid(grid_for(total_oct, 256));
-#define GN_APPLY(DT, S) hipLaunchKernelGGL((gn_apply_kernel<DT, S>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
-  if (bf) { if (silu) GN_APPLY(LATTE_DTYPE_BF16, true); else GN_APPLY(LATTE_DTYPE_BF16, false); }
-  else    { if (silu) GN_APPLY(LATTE_DTYPE_F16, true); else GN_APPLY(LATTE_DTYPE_F16, false); }
+#define GN_APPLY(DT, S, I) hipLaunchKernelGGL((gn_apply_kernel<DT, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
+#define GN_APPLY_I(DT, S) do { if (x_is_f32) GN_APPLY(DT, S, true); else GN_APPLY(DT, S, false); } while (0)
+  if (bf) { if (silu) GN_APPLY_I(LATTE_DTYPE_BF16, true); else GN_APPLY_I(LATTE_DTYPE_BF16, false); }
+  else    { if (silu) GN_APPLY_I(LATTE_DTYPE_F16, true); else GN_APPLY_I(LATTE_DTYPE_F16, false); }
+#undef GN_APPLY_I
 #undef GN_APPLY
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -465,12 +487,8 @@ int launch_post_quant(const float* z, const float* w, const float* b, float* out
   return LATTE_OK;
 }
 
-int launch_conv_in(const float* x, const float* wt, const float* bias, half_t* out, int N, int H, int W, int Cout, int dtype,
-                   hipStream_t st) {
-  if (dtype == LATTE_DTYPE_BF16)
-    hipLaunchKernelGGL(conv_in_kernel<LATTE_DTYPE_BF16>, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
-  else
-    hipLaunchKernelGGL(conv_in_kernel<LATTE_DTYPE_F16>, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
+int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL(conv_in_kernel, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -4,7 +4,11 @@
 //   called by the reference at          /root/reference/sample/sample.py:113-115, sample_ddp.py:165-168
 //   uint8 video conversion              /root/reference/sample/sample.py:122
 //
-// Activation layout: NHWC half.  Four ping-pong buffers sized for the largest map ([N, 8h, 8w, 256]).
+// Activation layout: NHWC.  The decoder's RESIDUAL STREAM (conv_in output, every ResnetBlock2D / attention / upsampler
+// output) is fp32 -- two ping-pong buffers -- so the skip path is never rounded: with a half stream each of the ~20
+// block outputs added one half rounding of the whole activation and the f16 decode ended at 1.35e-3 rel-L2 against the
+// fp32 restatement (round 1).  Only the MFMA operands (GroupNorm+SiLU outputs, conv1 outputs, attention q/k/v/P) are
+// half: three half scratch buffers, all sized for the largest map ([N, 8h, 8w, 256]).
 #include <cmath>
 #include <map>
 #include <string>
@@ -47,7 +51,9 @@ struct latte_vae {
   float *agn_w, *agn_b, *aq_b, *ak_b, *av_b, *ao_b, *ao_b_eff, *zero_bias;
   float* ao_w_f32;     // to_out weight in fp32 (for the folded bias  Wo bv + bo)
   half_t *aq_w, *ak_w, *av_w, *ao_w;
-  half_t* buf[4];
+  half_t* buf[3];      // half scratch (MFMA operands)
+  float* sbuf[2];      // fp32 residual stream, ping-pong
+  float* ones;         // [512] gate vector of ones (attention out-projection through the gated fp32 residual epilogue)
   half_t* zeros;
   float *pq_out, *scores, *gn_partial, *gn_stats, *stage;
   int64_t stage_numel = 0;
@@ -105,19 +111,25 @@ int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, con
   return launch_gemm(g, epi, dtype, 1, st);   // plain 128 x 128 kernel: small, oddly shaped problems
 }
 
-// x (buf a) -> ResnetBlock2D -> buf a (in place);  b, c, d scratch.  [N, H, W, C]
-int run_resnet(latte_vae* v, const Resnet& r, half_t* a, half_t* b, half_t* c, half_t* d, int N, int H, int W, hipStream_t st) {
+// ResnetBlock2D on the fp32 stream: x = *s -> *s (in place when cin == cout, else through *s2 and the two are swapped);
+// b, c, d: half scratch.  [N, H, W, C]
+int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, half_t* c, half_t* d, int N, int H, int W,
+               hipStream_t st) {
   int rc;
   const int HW = H * W, dt = v->dtype;
-  if ((rc = launch_groupnorm(a, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st))) return rc;
+  float* x = *s;
+  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st))) return rc;
   if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, b, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st))) return rc;
-  if ((rc = launch_groupnorm(b, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st))) return rc;
-  const half_t* res = a;
-  if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels
-    if ((rc = gemm_h16(a, r.scw, r.scb, d, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_H16, dt, st))) return rc;
-    res = d;
+  if ((rc = launch_groupnorm(b, 0, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st))) return rc;
+  if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
+    float* y = *s2;
+    if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
+    if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
+    if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
+    std::swap(*s, *s2);
+    return LATTE_OK;
   }
-  return launch_conv3x3(c, r.c2w, r.c2b, res, a, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st);
+  return launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
 }
 
 }  // namespace
@@ -185,7 +197,13 @@ int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_v
 
   // workspace: the largest NHWC map is [N, 8h, 8w, 256] (output of up_blocks.2's upsampler)
   const size_t big = (size_t)max_frames * (8 * latent_size) * (8 * latent_size) * 256;
-  for (int i = 0; i < 4; ++i) TRY(valloc(v, &v->buf[i], big));
+  for (int i = 0; i < 3; ++i) TRY(valloc(v, &v->buf[i], big));
+  for (int i = 0; i < 2; ++i) TRY(valloc(v, &v->sbuf[i], big));
+  TRY(valloc(v, &v->ones, 512));
+  {
+    std::vector<float> one(512, 1.0f);
+    LATTE_HIP(hipMemcpy(v->ones, one.data(), sizeof(float) * 512, hipMemcpyHostToDevice));
+  }
   TRY(valloc(v, &v->zeros, 64));
   TRY(valloc(v, &v->pq_out, (size_t)max_frames * latent_size * latent_size * 4));
   const size_t L = (size_t)latent_size * latent_size;
@@ -279,26 +297,29 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     if ((rc = launch_small_linear(IN_PLAIN, v->av_b, nullptr, v->ao_w_f32, v->ao_b, nullptr, nullptr, v->ao_b_eff, 1, top, top, top, st))) return rc;
     v->bias_folded = true;
   }
-  half_t *a = v->buf[0], *b = v->buf[1], *c = v->buf[2], *d = v->buf[3];
+  half_t *b = v->buf[0], *c = v->buf[1], *d = v->buf[2];
+  float *a = v->sbuf[0], *a2 = v->sbuf[1];   // the fp32 residual stream and its ping-pong partner
   int stage_no = 0, cur_c = top;
   // stage numbering: 0 conv_in | 1 mid.resnet0 | 2 mid.attention | 3 mid.resnet1 | then per up block: 3 resnets (+ upsampler)
   auto traced = [&](int& rc_out) -> bool {
     if (stage_no++ != stop_after) return false;
     const int64_t n = (int64_t)N * H * W * cur_c;
-    rc_out = launch_convert_h16_to_f32(a, trace_out, n, dt, st);
+    rc_out = LATTE_OK;
+    if (hipMemcpyAsync(trace_out, a, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      rc_out = fail(LATTE_ERR_HIP, "vae_trace: copy failed");
     *trace_numel = n;
     trace_dims[0] = N; trace_dims[1] = H; trace_dims[2] = W; trace_dims[3] = cur_c;
     return true;
   };
   if ((rc = launch_post_quant(z, v->pq_w, v->pq_b, v->pq_out, N, H * W, z_scale, st))) return rc;
-  if ((rc = launch_conv_in(v->pq_out, v->ci_wt, v->ci_b, a, N, H, W, top, dt, st))) return rc;
+  if ((rc = launch_conv_in(v->pq_out, v->ci_wt, v->ci_b, a, N, H, W, top, st))) return rc;
   if (traced(rc)) return rc;
-  if ((rc = run_resnet(v, v->mid[0], a, b, c, d, N, H, W, st))) return rc;
+  if ((rc = run_resnet(v, v->mid[0], &a, &a2, b, c, d, N, H, W, st))) return rc;
   if (traced(rc)) return rc;
   {  // mid-block attention: 1 head, dim 512, tokens = H*W per frame
     const int L = H * W;
     if (L % 128 != 0) return fail(LATTE_ERR_INVALID, "vae_decode: H*W must be a multiple of 128 for the attention GEMMs");
-    if ((rc = launch_groupnorm(a, c, v->agn_w, v->agn_b, v->gn_partial, v->gn_stats, N, L, top, 0, dt, st))) return rc;
+    if ((rc = launch_groupnorm(a, 1, c, v->agn_w, v->agn_b, v->gn_partial, v->gn_stats, N, L, top, 0, dt, st))) return rc;
     if ((rc = gemm_h16(c, v->aq_w, v->aq_b, b, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // q  [N L, 512]
     if ((rc = gemm_h16(c, v->ak_w, v->ak_b, d, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // k  [N L, 512]
     half_t* vt = b + (size_t)N * L * top;   // V0^T per frame [512, L], behind q in buffer b
@@ -313,28 +334,34 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
       if ((rc = launch_softmax_rows(v->scores, pm, L, L, scale, dt, st))) return rc;
       if ((rc = gemm_h16(pm, vt, v->zero_bias, o + (size_t)f * L * top, nullptr, L, top, L, EPI_BIAS_H16, dt, st))) return rc;  // P V0
     }
-    if ((rc = gemm_h16(o, v->ao_w, v->ao_b_eff, a, a, N * L, top, top, EPI_BIAS_RES_H16, dt, st))) return rc;   // to_out + residual
+    {  // to_out + residual straight into the fp32 stream: stream += 1 * (o Wo^T + b_eff)
+      GemmArgs g{};
+      g.A = o; g.W = v->ao_w; g.bias = v->ao_b_eff; g.out = a; g.gate = v->ones; g.gate_stride = 0;
+      g.M = N * L; g.N = top; g.K = top; g.rows_per_sample = N * L;
+      if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, 1, st))) return rc;
+    }
   }
   if (traced(rc)) return rc;
-  if ((rc = run_resnet(v, v->mid[1], a, b, c, d, N, H, W, st))) return rc;
+  if ((rc = run_resnet(v, v->mid[1], &a, &a2, b, c, d, N, H, W, st))) return rc;
   if (traced(rc)) return rc;
   for (int i = 0; i < 4; ++i) {
     for (int r = 0; r < 3; ++r) {
-      if ((rc = run_resnet(v, v->up[i][r], a, b, c, d, N, H, W, st))) return rc;
+      if ((rc = run_resnet(v, v->up[i][r], &a, &a2, b, c, d, N, H, W, st))) return rc;
       cur_c = v->up[i][r].cout;
       if (traced(rc)) return rc;
     }
-    if (i < 3) {  // Upsample2D: nearest x2 folded into the conv's gather
+    if (i < 3) {  // Upsample2D: nearest x2 folded into the conv's gather (on a half copy of the stream), fp32 result
       const int cch = v->ch[3 - i];
-      if ((rc = launch_conv3x3(a, v->upc_w[i], v->upc_b[i], nullptr, b, v->zeros, N, H, W, cch, cch, 1, dt, st))) return rc;
-      std::swap(a, b);
+      if ((rc = launch_convert_f32_to_h16(a, d, (int64_t)N * H * W * cch, dt, st))) return rc;
+      if ((rc = launch_conv3x3(d, v->upc_w[i], v->upc_b[i], nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, nullptr, a2))) return rc;
+      std::swap(a, a2);
       H *= 2;
       W *= 2;
       if (traced(rc)) return rc;
     }
   }
   if (stop_after >= 0) return fail(LATTE_ERR_INVALID, "vae_trace: stage index beyond the last traced stage");
-  if ((rc = launch_groupnorm(a, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
+  if ((rc = launch_groupnorm(a, 1, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
   return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
 }
 
