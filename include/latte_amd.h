@@ -104,10 +104,11 @@ const char* latte_engine_key(const latte_engine_t* e, int i);
  * (TimestepEmbedder, latte.py:84-123, through respace.py:125-130) -- [num_timesteps, hidden] fp32, device.  It depends on
  * nothing but the schedule and the weights, so the multi-GPU driver lets rank 0 compute it and broadcasts it over RCCL
  * (250 x 1152 x 4 B = 1.15 MB, the only payload collective of the sampling path); latte_engine_set_temb_table installs
- * a received table (copied), which latte_sample_loop then uses for every schedule with that number of steps.
- * table == NULL uninstalls. */
+ * a received table (copied) together with the schedule's timestep_map; latte_sample_loop uses it only for a schedule with
+ * exactly that map (create_diffusion("250") and ("ddim250") both have 250 steps but different maps) and falls back to
+ * computing its own otherwise.  Loading any t_embedder.* tensor uninstalls it.  table == NULL or s == NULL uninstalls. */
 int latte_engine_temb_table(latte_engine_t* e, const latte_schedule_t* s, float* out, void* stream);
-int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_timesteps, void* stream);
+int latte_engine_set_temb_table(latte_engine_t* e, const latte_schedule_t* s, const float* table, void* stream);
 
 /* Text-conditioned variant (extras == 78; latte.py:238-242,340-363): project a batch of text embeddings once,
  * text_embedding:[batch, 77*768] fp32 (device), Linear(SiLU(.)) -> [batch, D] kept inside the engine.  Every later
@@ -162,6 +163,12 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
                       int clip_denoised, float cfg_scale, float* x, const int64_t* y, int batch,
                       int start_index, int end_index, const float* noise,
                       float* trail_sample, float* trail_x0, void* stream);
+/* The same loop with the model callable named explicitly: guided != 0 drives Latte.forward_with_cfg (doubled batch, first
+ * half duplicated, eps_u + cfg_scale * (eps_c - eps_u)) for ANY cfg_scale -- the reference's method has no threshold
+ * (latte.py:379-398); sample.py:51 only decides which callable it passes.  latte_sample_loop = guided iff cfg_scale > 1. */
+int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised, int guided,
+                         float cfg_scale, float* x, const int64_t* y, int batch, int start_index, int end_index,
+                         const float* noise, float* trail_sample, float* trail_x0, void* stream);
 
 /* ------------------------------------------------------------------ VAE decoder
  * Replaces diffusers.AutoencoderKL (sample/sample.py:69 from_pretrained, :113-115 vae.decode(z / 0.18215).sample;
@@ -169,7 +176,8 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
  * block_out_channels (128, 256, 512, 512), layers_per_block 2, norm_num_groups 32, SiLU.  diffusers is not vendored
  * in the reference: the restated algorithm and its parity status are in oracle/vae_oracle.py. */
 typedef struct latte_vae latte_vae_t;
-/* latent_size: H = W of the latent (multiple of 16); max_frames: largest N of one decode call */
+/* latent_size: H = W of the latent (multiple of 16); max_frames: largest N of one decode call; compute_dtype: LATTE_DTYPE_F16
+ * only (MFMA operands f16 as in the reference's fp16 decode, residual stream fp32) */
 int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out);
 void latte_vae_destroy(latte_vae_t* v);
 /* load_state_dict for ONE tensor named by its diffusers key ("decoder.up_blocks.2.resnets.0.conv1.weight",

@@ -14,8 +14,8 @@ extern "C" {
 /* C[M,N] = A[M,K] W[N,K]^T with epilogue epi: 0 half=acc+bias | 1 half=gelu_tanh(acc+bias) |
  * 2 out_f32[m,n] += gate[(m / rows_per_sample) * gate_stride + n] * (acc+bias) | 3 out_f32 = acc+bias.
  * A must be allocated with rows padded to a multiple of 256.  (nn.Linear, latte.py:43,45,171)
- * variant: tile configuration as in csrc/common.h (0 = the engine's choice, 10 = deferred read-modify-write kernel for
- * epi 2) + 1000 * call-site tag (0 attention out-projection, 1 fc2: separate kernel symbols for the profiler). */
+ * variant: tile configuration as in csrc/common.h (0 = the engine's choice) + 1000 * call-site tag of a gated-residual
+ * GEMM (0 attention out-projection, 1 fc2: separate kernel symbols for the profiler). */
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
                      int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
 /* Attention core of latte.py:50-70 on a [rows, 3*D] qkv buffer (see AttnArgs in csrc/common.h). */

@@ -52,7 +52,7 @@ PROTOTYPES = {
     "latte_engine_num_keys": (c_int, [c_void]),
     "latte_engine_key": (c_char, [c_void, c_int]),
     "latte_engine_temb_table": (c_int, [c_void, c_void, c_void, c_void]),
-    "latte_engine_set_temb_table": (c_int, [c_void, c_void, c_int, c_void]),
+    "latte_engine_set_temb_table": (c_int, [c_void, c_void, c_void, c_void]),
     "latte_engine_set_text_embedding": (c_int, [c_void, c_void, c_int, c_void]),
     "latte_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void]),
     "latte_forward_with_cfg": (c_int, [c_void, c_void, c_void, c_void, c_int, c_f32, c_void, c_void]),
@@ -62,6 +62,8 @@ PROTOTYPES = {
                                    c_int, c_void, c_void, c_void]),
     "latte_sample_loop": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_f32, c_void, c_void, c_int, c_int, c_int,
                                   c_void, c_void, c_void, c_void]),
+    "latte_sample_loop_ex": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_int, c_f32, c_void, c_void, c_int, c_int, c_int,
+                                     c_void, c_void, c_void, c_void]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),

@@ -18,6 +18,8 @@ ARCH = "gfx950"
 
 SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "debug.hip", "vae.hip", "engine.cpp", "vae_engine.cpp", "t2v_engine.cpp", "schedule.cpp"]
 COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("LATTE_DEBUG_BUILD"):   # measurement build: main-loop / epilogue ablation instantiations of the GEMM
+    COMMON.append("-DLATTE_GEMM_ABLATE")
 FLAGS = {
     ".hip": COMMON + ["-O3"],
     # host logic reproduces fp64/fp32 reference arithmetic: no FMA contraction

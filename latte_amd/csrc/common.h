@@ -77,12 +77,12 @@ struct GemmArgs {
   int gate_stride;
   int rows_per_sample;
   int stagger;        // persistent kernel: number of start cohorts (0/1 = none); cohort c sleeps c/stagger of a tile time
+  int rmw_mode;       // measurement build only: look-ahead depth + 16 * non-temporal loads of the read-modify-write epilogue
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
-// 8 = 256x192, 9 = 256x256   (N % tileN == 0 required); 10 = 256x192 persistent kernel with the deferred
-// read-modify-write epilogue (EPI_GATE_RES_F32 only; falls back to 8 when the problem is not eligible)
+// 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);

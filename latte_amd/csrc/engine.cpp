@@ -79,6 +79,9 @@ struct latte_engine {
   // broadcast), per-(step, sample) conditioning rows and all adaLN outputs
   float *temb_table = nullptr, *temb_own = nullptr, *temb_work = nullptr, *cond_rows = nullptr, *mod_all = nullptr;
   int temb_table_n = 0;        // > 0: an installed table of that many respaced steps
+  std::vector<int64_t> temb_table_map;   // the timestep_map the installed table was computed for
+  std::vector<int64_t> temb_own_map;     // the timestep_map temb_own currently holds (empty: none); a chain run in several
+                                         // latte_sample_loop segments computes its table once
   int64_t temb_table_cap = 0, temb_own_cap = 0, temb_cap = 0, cond_cap = 0, mod_all_cap = 0;
   int64_t stage_numel = 0;
   std::vector<TensorSlot> slots;
@@ -420,7 +423,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..9");   // (10 is per-GEMM only)
+    if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..9");
     const int bn = value >= 7 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
@@ -430,7 +433,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   for (int gi = 0; gi < 4; ++gi) {
     static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
     if (k == names[gi]) {
-      if (value < 0 || value > 10) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..10");
+      if (value < 0 || value > 9) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..9");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }
@@ -473,6 +476,11 @@ int latte_engine_load_tensor(latte_engine_t* e, const char* key, const float* da
   if (rc) return rc;
   if (!on_device) LATTE_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next call
   s.loaded = true;
+  if (s.key.compare(0, 11, "t_embedder.") == 0) {   // an installed timestep-embedding table was computed from the old weights
+    e->temb_table_n = 0;
+    e->temb_table_map.clear();
+    e->temb_own_map.clear();
+  }
   return LATTE_OK;
 }
 
@@ -490,17 +498,20 @@ int latte_engine_temb_table(latte_engine_t* e, const latte_schedule_t* s, float*
   return compute_temb_table(e, s, out, (hipStream_t)stream);
 }
 
-int latte_engine_set_temb_table(latte_engine_t* e, const float* table, int num_timesteps, void* stream) {
+int latte_engine_set_temb_table(latte_engine_t* e, const latte_schedule_t* s, const float* table, void* stream) {
   if (!e) return fail(LATTE_ERR_INVALID, "set_temb_table: null engine");
-  if (!table || num_timesteps <= 0) {   // uninstall: the engine computes its own table again
+  if (!table || !s) {   // uninstall: the engine computes its own table again
     e->temb_table_n = 0;
+    e->temb_table_map.clear();
     return LATTE_OK;
   }
+  const int num_timesteps = s->num_timesteps;
   int rc = grow(e, &e->temb_table, &e->temb_table_cap, (int64_t)num_timesteps * e->D);
   if (rc) return rc;
   LATTE_HIP(hipMemcpyAsync(e->temb_table, table, sizeof(float) * (size_t)num_timesteps * e->D, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   e->temb_table_n = num_timesteps;
+  e->temb_table_map = s->timestep_map;   // row i is t_embedder(timestep_map[i]): valid for this map only
   return LATTE_OK;
 }
 
@@ -559,6 +570,13 @@ int latte_sampler_step(const latte_schedule_t* s, int method, int index, float e
 int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised,
                       float cfg_scale, float* x, const int64_t* y, int batch, int start_index, int end_index,
                       const float* noise, float* trail_sample, float* trail_x0, void* stream) {
+  return latte_sample_loop_ex(e, s, method, eta, clip_denoised, cfg_scale > 1.0f ? 1 : 0 /* sample.py:51 */, cfg_scale, x, y,
+                              batch, start_index, end_index, noise, trail_sample, trail_x0, stream);
+}
+
+int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised, int guided,
+                         float cfg_scale, float* x, const int64_t* y, int batch, int start_index, int end_index,
+                         const float* noise, float* trail_sample, float* trail_x0, void* stream) {
   if (!e || !s || !x) return fail(LATTE_ERR_INVALID, "sample_loop: null argument");
   int rc = latte_engine_check_weights(e);
   if (rc) return rc;
@@ -569,7 +587,7 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   if ((s->var_type == 0) != (e->Cout == 2 * e->Cin))
     return fail(LATTE_ERR_INVALID, "sample_loop: the model's learn_sigma and the diffusion's learn_sigma disagree "
                                    "(model output channels vs ModelVarType, gd:290 / :338)");
-  const bool use_cfg = cfg_scale > 1.0f;  // sample.py:51
+  const bool use_cfg = guided != 0;   // forward_with_cfg semantics for ANY scale (latte.py:379-398 has no threshold)
   if (use_cfg && (batch % 2)) return fail(LATTE_ERR_INVALID, "sample_loop: guidance needs the doubled batch");
   hipStream_t st = (hipStream_t)stream;
   // ---- conditioning of the whole chain, once: it depends on (timestep, label) only, never on x.
@@ -586,36 +604,53 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
   if (ex == 78 && e->txt_rows != batch)
     return fail(LATTE_ERR_STATE, "sample_loop: text-conditioned model needs latte_engine_set_text_embedding with one row per sample first");
   const float* temb = nullptr;
-  if (e->temb_table_n == n) {
+  if (e->temb_table_n == n && e->temb_table_map == s->timestep_map) {   // installed for exactly this timestep_map
     temb = e->temb_table;
   } else {
-    if ((rc = grow(e, &e->temb_own, &e->temb_own_cap, (int64_t)n * D))) return rc;
-    if ((rc = compute_temb_table(e, s, e->temb_own, st))) return rc;
+    if (e->temb_own_map != s->timestep_map) {
+      e->temb_own_map.clear();
+      if ((rc = grow(e, &e->temb_own, &e->temb_own_cap, (int64_t)n * D))) return rc;
+      if ((rc = compute_temb_table(e, s, e->temb_own, st))) return rc;
+      e->temb_own_map = s->timestep_map;
+    }
     temb = e->temb_own;
   }
-  const int64_t rows_all = (int64_t)n_run * bu;
-  if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_all * D))) return rc;
-  if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_all * e->nmod))) return rc;
-  // rows are ordered by respaced index ascending: row (i - end_index) * bu + b
-  if ((rc = launch_cond_rows(temb + (size_t)end_index * D, ex == 2 ? e->ytab : ex == 78 ? e->txt_proj : nullptr,
-                             ex == 78 ? e->iota : y, e->cond_rows, n_run, bu, D, st))) return rc;
-  if (ex == 78) {   // t-only rows for the final layer (latte.py:372-373)
-    if ((rc = grow(e, &e->cond_rows_t, &e->cond_t_cap, rows_all * D))) return rc;
-    if ((rc = launch_cond_rows(temb + (size_t)end_index * D, nullptr, nullptr, e->cond_rows_t, n_run, bu, D, st))) return rc;
-  }
+  // The conditioning rows of the chain are produced in chunks of <= 256 rows (= 256 / bu steps), right before the steps
+  // that use them: the adaLN outputs are 783 KB per row at XL/2 (nmod = 195 840 fp32), so the whole chain at once would
+  // be 3.1 GB for 250 guided steps at B = 16.  The adaLN weights are streamed once per 64 rows either way.
+  const int chunk_steps = std::max(1, 256 / bu);
+  const int64_t rows_chunk = (int64_t)std::min(chunk_steps, n_run) * bu;
+  if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_chunk * D))) return rc;
+  if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_chunk * e->nmod))) return rc;
+  if (ex == 78 && (rc = grow(e, &e->cond_rows_t, &e->cond_t_cap, rows_chunk * D))) return rc;
   const size_t fo = (size_t)e->cfg.depth * 6 * D;
-  for (int64_t r0 = 0; r0 < rows_all; r0 += 64) {
-    const int rows = (int)std::min<int64_t>(64, rows_all - r0);
-    if ((rc = launch_small_linear(IN_PLAIN, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
-                                  e->mod_all + (size_t)r0 * e->nmod, rows, e->nmod, D, e->nmod, st))) return rc;
-    if (ex == 78 &&
-        (rc = launch_small_linear(IN_PLAIN, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
-                                  nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return rc;
-  }
+  // conditioning of respaced steps [lo, lo + cnt): rows ordered by index ascending, row (i - lo) * bu + b
+  auto chain_conditioning = [&](int lo, int cnt) -> int {
+    const int64_t rows_all = (int64_t)cnt * bu;
+    int r2;
+    if ((r2 = launch_cond_rows(temb + (size_t)lo * D, ex == 2 ? e->ytab : ex == 78 ? e->txt_proj : nullptr,
+                               ex == 78 ? e->iota : y, e->cond_rows, cnt, bu, D, st))) return r2;
+    if (ex == 78 &&   // t-only rows for the final layer (latte.py:372-373)
+        (r2 = launch_cond_rows(temb + (size_t)lo * D, nullptr, nullptr, e->cond_rows_t, cnt, bu, D, st))) return r2;
+    for (int64_t r0 = 0; r0 < rows_all; r0 += 64) {
+      const int rows = (int)std::min<int64_t>(64, rows_all - r0);
+      if ((r2 = launch_small_linear(IN_PLAIN, e->cond_rows + (size_t)r0 * D, nullptr, e->ada_w, e->ada_b, nullptr, nullptr,
+                                    e->mod_all + (size_t)r0 * e->nmod, rows, e->nmod, D, e->nmod, st))) return r2;
+      if (ex == 78 &&
+          (r2 = launch_small_linear(IN_PLAIN, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
+                                    nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return r2;
+    }
+    return LATTE_OK;
+  };
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
   int k = 0;
+  int chunk_lo = start_index + 1;   // first respaced index covered by the rows currently in mod_all
   for (int i = start_index; i >= end_index; --i, ++k) {
-    const float* mod_i = e->mod_all + (size_t)(i - end_index) * bu * e->nmod;
+    if (i < chunk_lo) {   // next chunk: steps i, i - 1, ..., down to max(end_index, i - chunk_steps + 1)
+      chunk_lo = std::max(end_index, i - chunk_steps + 1);
+      if ((rc = chain_conditioning(chunk_lo, i - chunk_lo + 1))) return rc;
+    }
+    const float* mod_i = e->mod_all + (size_t)(i - chunk_lo) * bu * e->nmod;
     if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod))) return rc;
     SamplerCoefs c = make_coefs(s, method, i, eta, clip_denoised);
     c.cfg_scale = cfg_scale;

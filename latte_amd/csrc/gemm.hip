@@ -15,6 +15,7 @@
 //    and float4 bias / gate loads in the epilogue;
 //  * XCD-aware, grouped block->tile mapping so that co-resident tiles of one XCD share A/W panels in
 //    that XCD's private L2.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -351,7 +352,11 @@ __device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t rs, char* lds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int BN, int EPI, int DT>
+// RMW_AHEAD / RMW_NT: the gated fp32 read-modify-write epilogue keeps RMW_AHEAD residual fragments (1 KB per wave each)
+// in flight ahead of the stores; RMW_NT loads them with the non-temporal policy (they are read exactly once).
+// TAG only separates the instantiations of the two gated-residual call sites (0 = attention out-projection, 1 = fc2), which
+// share every other template argument, so that a kernel trace lists them as two kernels.
+template <int BN, int EPI, int DT, int RMW_AHEAD = 2, int RMW_NT = 0, int TAG = 0>
 __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   constexpr int BM = 256, NW = 8;
   constexpr int WTN = BN / 4, FN = WTN / 16;
@@ -526,28 +531,35 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
             b4[j] = *(const float4*)(g.bias + ncol + j * 16);
             g1[j] = *(const float4*)(gr + j * 16);
           }
-          // fragments in (i, j) order, residual loads running two fragments ahead of the stores
+          // fragments in (i, j) order, residual loads running RMW_AHEAD fragments ahead of the stores
           constexpr int NF = 8 * FN;
           auto frag_ptr = [&](int f) -> float* {
             const int mc = min(mbase + (f / FN) * 16, g.M - 1);      // clamped row: the load is unconditional
             return outp + (size_t)mc * g.N + ncol + (f % FN) * 16;
           };
-          float4 q0 = *(const float4*)frag_ptr(0), q1 = *(const float4*)frag_ptr(1);
+          auto load_res = [&](int f) -> float4 {
+            if constexpr (RMW_NT) {
+              const f32x4 v = __builtin_nontemporal_load((const f32x4*)frag_ptr(f));
+              return make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              return *(const float4*)frag_ptr(f);
+            }
+          };
+          float4 qa[RMW_AHEAD];
+#pragma unroll
+          for (int a = 0; a < RMW_AHEAD; ++a) qa[a] = load_res(a);
 #pragma unroll
           for (int f = 0; f < NF; ++f) {
-            float4 q2 = q1;
-            if (f + 2 < NF) q2 = *(const float4*)frag_ptr(f + 2);
+            float4 r = qa[f % RMW_AHEAD];
+            if (f + RMW_AHEAD < NF) qa[f % RMW_AHEAD] = load_res(f + RMW_AHEAD);
             asm volatile("" ::: "memory");                           // keep the prefetch ahead of this fragment's store
             const int i = f / FN, j = f % FN;
-            float4 r = q0;
             r.x += g1[j].x * (acc[i][j][0] + b4[j].x);
             r.y += g1[j].y * (acc[i][j][1] + b4[j].y);
             r.z += g1[j].z * (acc[i][j][2] + b4[j].z);
             r.w += g1[j].w * (acc[i][j][3] + b4[j].w);
             if (mbase + i * 16 < g.M) *(float4*)(outp + (size_t)(mbase + i * 16) * g.N + ncol + j * 16) = r;
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            q0 = q1;
-            q1 = q2;
           }
           return;
         }
@@ -700,279 +712,6 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Persistent ping-pong kernel with a DEFERRED read-modify-write epilogue, for the two gated-residual GEMMs of the
-// block (attention out-projection and fc2: res[m, n] += gate[sample, n] * (acc + bias), latte.py:179-180).
-//
-// In gemm_pps_kernel the fp32 residual epilogue is a chain of load -> add -> store round trips (24 fragments per wave,
-// two loads in flight): ~14-20 us per tile during which the matrix pipes of the CU idle, and because all 256
-// workgroups run their tiles in lock-step the 100 MB of residual traffic of a tile round hits HBM as one burst
-// (measured round 1: proj 130 us against 71 us with the epilogue ablated, fc2 330 against 288).  Here the epilogue of
-// tile n is spread over the main loop of tile n + 1:
-//   * at the tile boundary a wave only converts gate * (acc + bias) to 24 x 4 f16 values (48 VGPRs -- the 192-wide
-//     tile leaves 60 free) and clears its accumulators: no memory round trip besides the bias / gate vectors;
-//   * in each of the next 12 K iterations it loads TWO residual fragments at the top of its fragment-read segment,
-//     and adds + stores them after the compute segment, behind the vmcnt(0) that the K loop executes there anyway
-//     (operand DMA of the next K tile) -- the loads have had a whole read + compute segment (~1.5 us) to land;
-//   * only the last tile of a workgroup runs the synchronous epilogue.
-// The held delta is f16 whatever the operand type: unit roundoff 2^-11 on the DELTA (the residual itself stays fp32),
-// i.e. a quarter of the bf16 operand rounding that is already in acc, and equal to one more f16 operand rounding.
-// Requirements (launcher; otherwise gemm_pps_kernel<192> runs): M % 256 == 0, N % 192 == 0, K >= 12 * 64,
-// rows_per_sample % 256 == 0, out < 4 GiB.  TAG only separates the instantiations of the two call sites (0 = attention
-// out-projection, 1 = fc2) so that a kernel trace shows them as two kernels.
-typedef __attribute__((ext_vector_type(4))) unsigned int rmw_u4;
-template <int DT, int TAG>
-__global__ void __launch_bounds__(512) gemm_rmw_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 192, NW = 8;
-  constexpr int WTN = BN / 4, FN = WTN / 16;   // 48, 3
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-  constexpr int AH_INSTR = 128 / 8 / 4;
-  constexpr int BG_INSTR = BN / 8 / 4;
-  constexpr int GROUP_M = 8;
-  constexpr int NF = 8 * FN;          // 24 accumulator fragments per wave
-  constexpr int NPAIR = NF / 2;       // deferred epilogue: one fragment pair per K iteration
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2, wn = wave & 3;
-  const int K = g.K, N = g.N;
-  const unsigned row_bytes = (unsigned)K * 2u;
-
-  const int tiles_m = g.M / BM, tiles_n = N / BN, nwg = tiles_m * tiles_n;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int cnt = q + (xcd < r ? 1 : 0);
-  if (slot >= cnt) return;
-  auto decode = [&](int wg, int& tm, int& tn) {
-    const int per_group = GROUP_M * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int in_group = wg - group * per_group;
-    tm = first_m + in_group % gsz;
-    tn = in_group / gsz;
-  };
-
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)g.M * row_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)N * row_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsO =
-      __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (unsigned)g.M * (unsigned)N * 4u, 0x00020000);
-
-  const int lrow = lane >> 3, cpos = lane & 7;
-  auto lane_off = [&](int group_row0) -> unsigned {
-    const int row = group_row0 + lrow;
-    return (unsigned)lrow * row_bytes + (unsigned)((cpos ^ ((row >> 1) & 7)) * 16);
-  };
-  const unsigned off_main = lane_off(wn * 8);
-  unsigned step32 = 32u * row_bytes;
-  asm volatile("" : "+s"(step32));
-  auto dma_a_half = [&](int tm_, int kt, int stg) {
-    char* sA = smem + stg * STAGE + grp * 128 * 128 + wn * 1024;
-    const unsigned so = (unsigned)(tm_ * BM + grp * 128 + wn * 8) * row_bytes + (unsigned)kt * 128u;
-#pragma unroll
-    for (int j = 0; j < AH_INSTR; ++j) bload_lds16(rsA, sA + j * 4 * 1024, off_main, so + (unsigned)j * step32);
-  };
-  auto dma_b_all = [&](int tn_, int kt, int stg) {
-    char* sB = smem + stg * STAGE + A_BYTES + wn * 1024;
-    const unsigned so = (unsigned)(tn_ * BN + wn * 8) * row_bytes + (unsigned)kt * 128u;
-#pragma unroll
-    for (int j = 0; j < BG_INSTR; ++j) bload_lds16(rsB, sB + j * 4 * 1024, off_main, so + (unsigned)j * step32);
-  };
-
-  const int sw = (lane >> 1) & 7;
-  const int chunkb = ((lane >> 4) ^ sw) * 16;
-  const int a_off = (grp * 128 + (lane & 15)) * 128 + chunkb;
-  const int b_off = A_BYTES + (wn * WTN + (lane & 15)) * 128 + chunkb;
-
-  f32x4 acc[8][FN];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  int pos = slot, tm, tn;
-  decode(chunk0 + pos, tm, tn);
-  const int nk = K / 64;   // >= NPAIR (launcher)
-  {  // pipeline fill: K tile 0 of the first tile by all 8 waves (row-groups wave + 8 j)
-    const unsigned off_pro = lane_off(wave * 8);
-    char* sA = smem + wave * 1024;
-    char* sB = sA + A_BYTES;
-    const unsigned soA = (unsigned)(tm * BM + wave * 8) * row_bytes;
-    const unsigned soB = (unsigned)(tn * BN + wave * 8) * row_bytes;
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) bload_lds16(rsA, sA + j * NW * 1024, off_pro, soA + (unsigned)(64 * j) * row_bytes);
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) bload_lds16(rsB, sB + j * NW * 1024, off_pro, soB + (unsigned)(64 * j) * row_bytes);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  dma_a_half(tm, 1, 1);
-  if (grp == 0) dma_b_all(tn, 1, 1);
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
-
-  // ---- deferred epilogue state
-  u32x2 held[NF];            // f16 x 4: gate * (acc + bias) of the previous tile, fragment f = i * FN + j
-#pragma unroll
-  for (int f = 0; f < NF; ++f) held[f] = (u32x2){0u, 0u};
-  int dk = NPAIR;            // K iterations since the last boundary; pair dk is handled while dk < NPAIR
-  unsigned p_voff = 0;       // byte offset of this lane's element (row fr, column 4 * (lane >> 4)) of the pending sub-tile
-  const unsigned n64 = (unsigned)N * 64u;   // 16 rows further in the fp32 output
-  rmw_u4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
-
-  // boundary step of a tile that is followed by another one: pack the gated delta, clear the accumulators
-  auto pack_tile = [&](int tm_, int tn_) {
-    int le = lane;
-    asm volatile("" : "+v"(le));   // opaque: nothing lane-derived of the epilogue stays live in the K loop
-    const int ncol = tn_ * BN + wn * WTN + (le >> 4) * 4;
-    const float* gr = g.gate + (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
-    float4 b4[FN], g1[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      b4[j] = *(const float4*)(g.bias + ncol + j * 16);
-      g1[j] = *(const float4*)(gr + j * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const float v0 = g1[j].x * (acc[i][j][0] + b4[j].x), v1 = g1[j].y * (acc[i][j][1] + b4[j].y);
-        const float v2 = g1[j].z * (acc[i][j][2] + b4[j].z), v3 = g1[j].w * (acc[i][j][3] + b4[j].w);
-        held[i * FN + j] = (u32x2){pack2<LATTE_DTYPE_F16>(v0, v1), pack2<LATTE_DTYPE_F16>(v2, v3)};
-        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    p_voff = ((unsigned)(tm_ * BM + grp * 128 + (le & 15)) * (unsigned)N + (unsigned)ncol) * 4u;
-    dk = 0;
-  };
-  // synchronous epilogue of a workgroup's LAST tile (the fast path of gemm_pps_kernel: loads two fragments ahead)
-  auto final_epilogue = [&](int tm_, int tn_) {
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    const int ncol = tn_ * BN + wn * WTN + (le >> 4) * 4;
-    const int mbase = tm_ * BM + grp * 128 + (le & 15);
-    float* const outp = (float*)g.out;
-    const float* gr = g.gate + (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
-    float4 b4[FN], g1[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      b4[j] = *(const float4*)(g.bias + ncol + j * 16);
-      g1[j] = *(const float4*)(gr + j * 16);
-    }
-    auto frag_ptr = [&](int f) -> float* { return outp + (size_t)(mbase + (f / FN) * 16) * N + ncol + (f % FN) * 16; };
-    float4 r0 = *(const float4*)frag_ptr(0), r1 = *(const float4*)frag_ptr(1);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      float4 r2 = r1;
-      if (f + 2 < NF) r2 = *(const float4*)frag_ptr(f + 2);
-      asm volatile("" ::: "memory");
-      const int i = f / FN, j = f % FN;
-      float4 o = r0;
-      o.x += g1[j].x * (acc[i][j][0] + b4[j].x);
-      o.y += g1[j].y * (acc[i][j][1] + b4[j].y);
-      o.z += g1[j].z * (acc[i][j][2] + b4[j].z);
-      o.w += g1[j].w * (acc[i][j][3] + b4[j].w);
-      *(float4*)frag_ptr(f) = o;
-      r0 = r1;
-      r1 = r2;
-    }
-  };
-  auto frag_soff = [&](int f) -> unsigned { return (unsigned)(f / FN) * n64 + (unsigned)(f % FN) * 64u; };
-  auto add_held = [&](rmw_u4 qv, u32x2 h) -> rmw_u4 {
-    const unsigned int lo = h[0], hi = h[1];   // (scalar copies first: see epilogue_store)
-    float4 o = __builtin_bit_cast(float4, qv);
-    o.x += (float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu));
-    o.y += (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
-    o.z += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu));
-    o.w += (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
-    return __builtin_bit_cast(rmw_u4, o);
-  };
-
-  int it = 0;
-  bool counted = false;
-  for (;;) {
-    const int npos = pos + per;
-    const bool has_next = npos < cnt;
-    int ntm = tm, ntn = tn;
-    if (has_next) decode(chunk0 + npos, ntm, ntn);
-
-    for (int kt = 0; kt < nk; ++kt, ++it) {
-      const bool last = kt + 1 == nk;
-      const bool in_tile = kt + 2 < nk;
-      const bool do_dma = in_tile || has_next;
-      const int stm = in_tile ? tm : ntm, stn = in_tile ? tn : ntn;
-      const int skt = in_tile ? kt + 2 : kt + 2 - nk;
-      const char* sbuf = smem + (it & 1) * STAGE;
-      const bool have = dk < NPAIR;     // a fragment pair of the previous tile is handled in this iteration
-      // ---- deferred epilogue, part 1: residual loads of pair dk (static fragment indices through a uniform dispatch)
-      if (have) {
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p)
-          if (dk == p) {
-            q0 = __builtin_amdgcn_raw_buffer_load_b128(rsO, p_voff, frag_soff(2 * p), 0);
-            q1 = __builtin_amdgcn_raw_buffer_load_b128(rsO, p_voff, frag_soff(2 * p + 1), 0);
-          }
-      }
-      u32x4 bf[2][FN], af[2][8];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      // DMA(u+1) must have landed (see gemm_pps_kernel for the `counted` argument); the same wait covers this
-      // iteration's residual loads, issued a read + compute segment ago.
-      if (!counted || have) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      counted = false;
-      // ---- deferred epilogue, part 2: res += delta for pair dk
-      if (have) {
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p)
-          if (dk == p) {
-            __builtin_amdgcn_raw_buffer_store_b128(add_held(q0, held[2 * p]), rsO, p_voff, frag_soff(2 * p), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(add_held(q1, held[2 * p + 1]), rsO, p_voff, frag_soff(2 * p + 1), 0);
-          }
-      }
-      ++dk;
-      if (grp == 1 && last) {
-        if (do_dma) dma_a_half(stm, skt, it & 1);
-        asm volatile("" ::: "memory");   // the boundary step's loads must stay BEHIND the DMA issue
-        if (has_next) pack_tile(tm, tn); else final_epilogue(tm, tn);
-      }
-      __builtin_amdgcn_s_barrier();
-      if (grp == 1 && !last) {
-        if (do_dma) dma_a_half(stm, skt, it & 1);
-      }
-      if (grp == 0) {
-        if (do_dma) {
-          dma_a_half(stm, skt, it & 1);
-          dma_b_all(stn, skt, it & 1);
-        }
-        asm volatile("" ::: "memory");
-        if (last) {
-          if (has_next) pack_tile(tm, tn); else final_epilogue(tm, tn);
-        }
-      }
-      if (last) counted = do_dma;
-    }
-    if (!has_next) break;
-    pos = npos; tm = ntm; tn = ntn;
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
-}
-
 template <int BN, int DT>
 int launch_pp(const GemmArgs& a, int epi, hipStream_t st);
 
@@ -994,6 +733,36 @@ int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
     if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
     hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
     break;                                                                                           \
+  }
+#ifdef LATTE_GEMM_ABLATE
+  // measurement build: look-ahead depth / cache policy of the read-modify-write epilogue (GemmArgs::rmw_mode = depth + 16 * nt)
+  if constexpr (BN == 192 && DT == LATTE_DTYPE_BF16) {
+    if (epi == EPI_GATE_RES_F32 && a.rmw_mode) {
+#define LATTE_RMW_CASE(AH, NT)                                                                        \
+  case AH + 16 * NT: {                                                                                \
+    auto kern = gemm_pps_kernel<BN, EPI_GATE_RES_F32, DT, AH, NT>;                                    \
+    static std::atomic<uint64_t> attr_done{0};                                                        \
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                  \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                                \
+    LATTE_HIP(hipGetLastError());                                                                     \
+    return LATTE_OK;                                                                                  \
+  }
+      switch (a.rmw_mode) {
+        LATTE_RMW_CASE(3, 0) LATTE_RMW_CASE(4, 0) LATTE_RMW_CASE(6, 0) LATTE_RMW_CASE(8, 0) LATTE_RMW_CASE(12, 0)
+        LATTE_RMW_CASE(2, 1) LATTE_RMW_CASE(4, 1) LATTE_RMW_CASE(6, 1) LATTE_RMW_CASE(8, 1)
+        default: break;
+      }
+#undef LATTE_RMW_CASE
+    }
+  }
+#endif
+  if (epi == EPI_GATE_RES_F32 && a.tag == 1) {   // fc2: its own kernel symbol
+    auto kern = gemm_pps_kernel<BN, EPI_GATE_RES_F32, DT, 2, 0, 1>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
   }
   switch (epi) {
     LATTE_GEMM_CASE(EPI_BIAS_H16)
@@ -1044,34 +813,6 @@ int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
   return LATTE_OK;
 }
 
-// deferred read-modify-write kernel: can it take this problem?  (otherwise gemm_pps_kernel<192> does)
-bool rmw_eligible(const GemmArgs& a, int epi) {
-  return epi == EPI_GATE_RES_F32 && a.M > 0 && a.M % 256 == 0 && a.N % 192 == 0 && a.K % 64 == 0 && a.K >= 12 * 64 &&
-         a.rows_per_sample > 0 && a.rows_per_sample % 256 == 0 && (uint64_t)a.M * a.N * 4 < (1ull << 32) &&
-         (uint64_t)a.M * a.K * 2 < (1ull << 32) && (uint64_t)a.N * a.K * 2 < (1ull << 32);
-}
-
-template <int DT>
-int launch_rmw(const GemmArgs& a, hipStream_t st) {
-  constexpr int LDS = 2 * (256 + 192) * 128;
-  const int tiles = (a.M / 256) * (a.N / 192);
-  const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;
-  dim3 grid(nblk), block(512);
-  if (a.tag == 1) {
-    auto kern = gemm_rmw_kernel<DT, 1>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
-    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
-  } else {
-    auto kern = gemm_rmw_kernel<DT, 0>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
-    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
-  }
-  LATTE_HIP(hipGetLastError());
-  return LATTE_OK;
-}
-
 template <int DT>
 int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
   switch (variant) {
@@ -1084,7 +825,6 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
     case 7: return launch_pps<128, DT>(a, epi, st);
     case 8: return launch_pps<192, DT>(a, epi, st);
     case 9: return launch_pps<256, DT>(a, epi, st);
-    case 10: return rmw_eligible(a, epi) ? launch_rmw<DT>(a, st) : launch_pps<192, DT>(a, epi, st);
     default: return fail(LATTE_ERR_INVALID, "gemm: unknown tile variant");
   }
 }
@@ -1096,7 +836,7 @@ int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: return 256;
-    case 5: case 8: case 10: return 192;
+    case 5: case 8: return 192;
     default: return 128;
   }
 }
@@ -1129,16 +869,17 @@ int gemm_auto_variant(int M, int N, int epi) {
 
 int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
   GemmArgs a = a_in;
+#ifdef LATTE_GEMM_ABLATE
+  if (const char* m = getenv("LATTE_RMW_MODE")) a.rmw_mode = atoi(m);
+  if (const char* m = getenv("LATTE_RMW_VARIANT")) { if (epi == EPI_GATE_RES_F32 && variant == 0) variant = atoi(m); }
+#endif
   if (variant == 0) {
     variant = gemm_auto_variant(a.M, a.N, epi);
-    // gated fp32 residual: the deferred read-modify-write kernel whenever the 192-wide tile was (or ties with) the choice
-    if (epi == EPI_GATE_RES_F32 && rmw_eligible(a, epi) && (variant == 8 || variant == 9) && a.N % 192 == 0) variant = 10;
     // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
     //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
   }
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
-  if (variant == 10 && epi != EPI_GATE_RES_F32) return fail(LATTE_ERR_INVALID, "gemm: variant 10 is the gated-residual kernel");
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)
     return fail(LATTE_ERR_INVALID, "gemm: shape not tileable (need K % 64 == 0, N % tileN == 0)");
   if (dtype == LATTE_DTYPE_BF16) return launch_dt<LATTE_DTYPE_BF16>(a, epi, variant, st);

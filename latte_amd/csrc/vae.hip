@@ -445,14 +445,10 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   const int M = N * (Hin << ups) * (Win << ups);
   const int tiles = ((M + 127) / 128) * (Cout / 128);
   constexpr int LDS = 2 * 256 * 128;
-  static std::atomic<uint64_t> attr_bf16{0}, attr_f16{0};
-  if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_BF16>, LDS, attr_bf16)) return rc_;
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv3x3: the VAE kernels are built for f16 operands only");
+  static std::atomic<uint64_t> attr_f16{0};
   if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, LDS, attr_f16)) return rc_;
-  if (dtype == LATTE_DTYPE_BF16) {
-    hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_BF16>, dim3(tiles), dim3(256), LDS, st, a);
-  } else {
-    hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);
-  }
+  hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -464,17 +460,14 @@ int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma,
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
   const size_t total_oct = (size_t)N * HW * C / 8;
-  const bool bf = dtype == LATTE_DTYPE_BF16;
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "groupnorm: the VAE kernels are built for f16 operands only");
   if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
-  else if (bf) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_BF16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), 1e-6f);
   const dim3 grid(grid_for(total_oct, 256));
-#define GN_APPLY(DT, S, I) hipLaunchKernelGGL((gn_apply_kernel<DT, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
-#define GN_APPLY_I(DT, S) do { if (x_is_f32) GN_APPLY(DT, S, true); else GN_APPLY(DT, S, false); } while (0)
-  if (bf) { if (silu) GN_APPLY_I(LATTE_DTYPE_BF16, true); else GN_APPLY_I(LATTE_DTYPE_BF16, false); }
-  else    { if (silu) GN_APPLY_I(LATTE_DTYPE_F16, true); else GN_APPLY_I(LATTE_DTYPE_F16, false); }
-#undef GN_APPLY_I
+#define GN_APPLY(S, I) hipLaunchKernelGGL((gn_apply_kernel<LATTE_DTYPE_F16, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
+  if (silu) { if (x_is_f32) GN_APPLY(true, true); else GN_APPLY(true, false); }
+  else      { if (x_is_f32) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -497,29 +490,23 @@ int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* o
                     int dtype, hipStream_t st) {
   const int total = N * H * W;
   const size_t lds = (size_t)27 * C * sizeof(float);
-  if (dtype == LATTE_DTYPE_BF16)
-    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_BF16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
-  else
-    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv_out: the VAE kernels are built for f16 operands only");
+  hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
 
 int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st) {
-  if (dtype == LATTE_DTYPE_BF16)
-    hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_BF16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
-  else
-    hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_F16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "softmax_rows: the VAE kernels are built for f16 operands only");
+  hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_F16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
 
 int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st) {
   const size_t n = (size_t)Cout * Cin * 9;
-  if (dtype == LATTE_DTYPE_BF16)
-    hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
-  else
-    hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "pack_conv_w: the VAE kernels are built for f16 operands only");
+  hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -27,6 +27,8 @@ class SpacedDiffusion:
     """Stand-in for ``respace.SpacedDiffusion`` as built by ``create_diffusion`` (diffusion/__init__.py:32-46):
     EPSILON or START_X mean type, LEARNED_RANGE / FIXED_LARGE / FIXED_SMALL variance."""
 
+    SEGMENT_BYTES = 256 << 20   # per-step noise / trail buffers of one fused-loop segment (see _loop)
+
     def __init__(self, timestep_respacing, noise_schedule="linear", diffusion_steps=1000, predict_xstart=False,
                  learn_sigma=True, sigma_small=False):
         lib = load_library()
@@ -161,26 +163,35 @@ class SpacedDiffusion:
             B = img.shape[0]
             y = model_kwargs.get("y")
             x32, _, y64 = owner._prep(img, torch.zeros(B, dtype=torch.int64), y)
-            eng = owner.engine(B)
-            owner._set_text(model_kwargs.get("text_embedding"), B)
             cfg_scale = float(model_kwargs.get("cfg_scale", 7.0)) if uses_cfg else 1.0
-            if uses_cfg and cfg_scale <= 1.0:
-                raise LatteError("forward_with_cfg inside the fused loop needs cfg_scale > 1 (sample.py:51)")
-            nz = None
-            if needs_noise:   # same draws, same order as the reference's per-step randn_like (gd:413,555)
-                nz = torch.stack([torch.randn_like(x32) for _ in range(n)])
-            trail_s = trail_0 = None
-            if progressive:
-                trail_s = torch.empty((n,) + tuple(x32.shape), device=device, dtype=torch.float32)
-                trail_0 = torch.empty_like(trail_s)
-            with torch.cuda.device(device):
-                check(load_library().latte_sample_loop(eng, self._h, _METHOD[method], float(eta),
-                                                       int(bool(clip_denoised)), cfg_scale, ptr(x32), ptr(y64), B,
-                                                       n - 1, 0, ptr(nz), ptr(trail_s), ptr(trail_0), stream_ptr()))
-            if progressive:
-                for k in range(n):
-                    yield {"sample": trail_s[k], "pred_xstart": trail_0[k]}
-            else:
+            eng = owner.engine(B, guided=uses_cfg)
+            owner._set_text(model_kwargs.get("text_embedding"), B, guided=uses_cfg)
+            # The chain runs in segments of consecutive steps so that the per-step noise (and the progressive trails) of
+            # only ONE segment exist at a time: 65 MB per 250-step sample-chain otherwise, 4.2 GB at B = 64.  The draws
+            # are the reference's -- one torch.randn_like per step, in step order (gd:413,555) -- whatever the split.
+            numel_bytes = x32.numel() * 4
+            seg = max(1, min(n, self.SEGMENT_BYTES // max(numel_bytes, 1)))
+            lib = load_library()
+            i = n - 1
+            while i >= 0:
+                lo = max(0, i - seg + 1)
+                cnt = i - lo + 1
+                nz = torch.stack([torch.randn_like(x32) for _ in range(cnt)]) if needs_noise else None
+                trail_s = trail_0 = None
+                if progressive:
+                    trail_s = torch.empty((cnt,) + tuple(x32.shape), device=device, dtype=torch.float32)
+                    trail_0 = torch.empty_like(trail_s)
+                with torch.cuda.device(device):
+                    check(lib.latte_sample_loop_ex(eng, self._h, _METHOD[method], float(eta), int(bool(clip_denoised)),
+                                                   int(uses_cfg), cfg_scale, ptr(x32), ptr(y64), B, i, lo, ptr(nz),
+                                                   ptr(trail_s), ptr(trail_0), stream_ptr()))
+                    if nz is not None or progressive:
+                        torch.cuda.current_stream().synchronize()      # the segment's buffers are released / handed out next
+                if progressive:
+                    for k in range(cnt):
+                        yield {"sample": trail_s[k], "pred_xstart": trail_0[k]}
+                i = lo - 1
+            if not progressive:
                 yield {"sample": x32, "pred_xstart": None}
             return
         # ---- generic model callable, step by step

@@ -54,13 +54,21 @@ def _linear(out_f, in_f):
 class Latte(nn.Module):
     """Drop-in for ``models.latte.Latte`` (latte.py:204-398) backed by the MI355X engine.
 
-    Extra keyword arguments (not in the reference): ``compute_dtype`` ("bf16" | "f16": MFMA operand
+    Extra keyword arguments (not in the reference): ``compute_dtype`` ("bf16" | "f16" | None: MFMA operand
     type; accumulation / residual / statistics are always fp32) and ``max_batch`` (engine workspace).
+
+    Operand-type rule (``compute_dtype=None``, the default): unguided calls use bf16 operands, GUIDED calls
+    (``forward_with_cfg`` and the fused loop driven by it) use f16 operands.  Guidance computes
+    ``eps_u + s (eps_c - eps_u)`` (latte.py:395-397): the operand rounding of the two halves is amplified by
+    ``sqrt((s - 1)^2 + s^2)`` (9.2x at the reference's scale 7) wherever the conditioning is strong enough to decorrelate
+    them, which puts bf16's 2^-9 unit roundoff above the 1e-3 parity bar on the guided output, while f16's 2^-11 stays
+    below it at the same MFMA rate (the reference's own half mode is fp16 too, sample.py:72-75).  Passing
+    ``compute_dtype`` or calling ``.to(dtype=...)`` / ``.half()`` pins one type for every call.
     """
 
     def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
                  mlp_ratio=4.0, num_frames=16, class_dropout_prob=0.1, num_classes=1000, learn_sigma=True,
-                 extras=1, attention_mode="math", compute_dtype="bf16", max_batch=2):
+                 extras=1, attention_mode="math", compute_dtype=None, max_batch=2):
         super().__init__()
         if hidden_size % num_heads != 0:
             raise AssertionError("dim should be divisible by num_heads")          # latte.py:38
@@ -118,9 +126,7 @@ class Latte(nn.Module):
         self.final_layer.linear = _linear(patch_size * patch_size * self.out_channels, D)
         self.final_layer.adaLN_modulation = nn.ModuleList([nn.SiLU(), _linear(2 * D, D)])
         self.initialize_weights()
-        self._engine = None
-        self._engine_key = None
-        self._synced = False
+        self._engines = {}        # operand dtype -> [handle, (device index, max_batch), weights packed?]
 
     # ------------------------------------------------------------------ init (latte.py:257-295)
     def initialize_weights(self):
@@ -149,9 +155,13 @@ class Latte(nn.Module):
             self.final_layer.linear.bias.zero_()
 
     # ------------------------------------------------------------------ nn.Module plumbing
+    def _invalidate(self):
+        for rec in getattr(self, "_engines", {}).values():
+            rec[2] = False
+
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._synced = False
+        self._invalidate()
         return r
 
     def to(self, *args, **kwargs):
@@ -166,7 +176,6 @@ class Latte(nn.Module):
             self.compute_dtype = "f16" if dt == torch.float16 else "bf16"
             kwargs.pop("dtype", None)
             args = tuple(a for a in args if not isinstance(a, torch.dtype))
-            self._synced = False
             if not args and not kwargs:
                 return self
         return super().to(*args, **kwargs)
@@ -176,72 +185,80 @@ class Latte(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._synced = False
+        self._invalidate()
         return r
 
     def mark_weights_dirty(self):
         """Call after mutating parameters in place so the engine re-packs them."""
-        self._synced = False
+        self._invalidate()
 
     def __del__(self):
         try:
-            if getattr(self, "_engine", None):
-                load_library().latte_engine_destroy(self._engine)
+            for rec in getattr(self, "_engines", {}).values():
+                if rec[0]:
+                    load_library().latte_engine_destroy(rec[0])
         except Exception:
             pass
 
+    def operand_dtype(self, guided=False):
+        """MFMA operand type of a call: the pinned one, else bf16 (unguided) / f16 (guided) -- class docstring."""
+        return self.compute_dtype or ("f16" if guided else "bf16")
+
     # ------------------------------------------------------------------ engine management
-    def engine_config(self):
+    def engine_config(self, dtype=None):
         cfg = ModelConfig()
         cfg.input_size, cfg.patch_size, cfg.in_channels = self.input_size, self.patch_size, self.in_channels
         cfg.hidden_size, cfg.depth, cfg.num_heads = self.hidden_size, self.depth, self.num_heads
         cfg.mlp_hidden, cfg.num_frames = self.mlp_hidden, self.num_frames
         cfg.num_classes = (self.y_embedder.embedding_table.weight.shape[0] - 1) if self.extras == 2 else 0
         cfg.learn_sigma, cfg.extras = int(self.learn_sigma), self.extras
-        if self.compute_dtype not in _lib.DTYPES:
+        dtype = dtype or self.operand_dtype()
+        if dtype not in _lib.DTYPES:
             raise LatteError(f"compute_dtype must be one of {sorted(_lib.DTYPES)}")
-        cfg.compute_dtype = _lib.DTYPES[self.compute_dtype]
+        cfg.compute_dtype = _lib.DTYPES[dtype]
         return cfg
 
-    def engine(self, batch):
-        """Engine handle for a batch of ``batch`` samples on the parameters' device (created / re-packed lazily)."""
+    def engine(self, batch, guided=False):
+        """Engine handle for a batch of ``batch`` samples on the parameters' device (created / re-packed lazily); one
+        engine per operand type in use (``operand_dtype``)."""
         _lib.require_gpu()
         lib = load_library()
         dev = self.pos_embed.device
         if dev.type != "cuda":
             raise LatteError("latte_amd.Latte runs on an MI355X only: move the module with .to('cuda') "
                              "(there is no CPU fallback)")
+        dtype = self.operand_dtype(guided)
+        rec = self._engines.get(dtype)
         want = max(batch, self.max_batch)
-        key = (dev.index, want, self.compute_dtype)
-        if self._engine is None or self._engine_key != key:
-            if self._engine is not None:
-                lib.latte_engine_destroy(self._engine)
-                self._engine = None
+        key = (dev.index, want)
+        if rec is None or rec[1] != key:
+            if rec is not None and rec[0]:
+                lib.latte_engine_destroy(rec[0])
             h = _lib.c_void()
-            cfg = self.engine_config()
+            cfg = self.engine_config(dtype)
             with torch.cuda.device(dev):
                 check(lib.latte_engine_create(cfg, want, h))
-            self._engine, self._engine_key, self._synced = h, key, False
+            rec = self._engines[dtype] = [h, key, False]
             self.max_batch = want
-        if not self._synced:
+        if not rec[2]:
             sd = self.state_dict()
             with torch.cuda.device(dev):
-                for i in range(lib.latte_engine_num_keys(self._engine)):
-                    k = lib.latte_engine_key(self._engine, i).decode()
+                for i in range(lib.latte_engine_num_keys(rec[0])):
+                    k = lib.latte_engine_key(rec[0], i).decode()
                     if k not in sd:
                         raise LatteError(f'Missing key(s) in state_dict: "{k}"')
                     t = sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
-                    check(lib.latte_engine_load_tensor(self._engine, k.encode(), ptr(t), t.numel(), 1, stream_ptr()))
-                check(lib.latte_engine_check_weights(self._engine))
+                    check(lib.latte_engine_load_tensor(rec[0], k.encode(), ptr(t), t.numel(), 1, stream_ptr()))
+                check(lib.latte_engine_check_weights(rec[0]))
                 torch.cuda.current_stream().synchronize()
-            self._synced = True
-        return self._engine
+            rec[2] = True
+        return rec[0]
 
-    def set_engine_option(self, name, value, batch=1):
-        check(load_library().latte_engine_set_option(self.engine(batch), name.encode(), int(value)))
+    def set_engine_option(self, name, value, batch=1, guided=False):
+        check(load_library().latte_engine_set_option(self.engine(batch, guided), name.encode(), int(value)))
 
     # ------------------------------------------------------------------ the model-callable protocol
-    def _set_text(self, text_embedding, B):
+    def _set_text(self, text_embedding, B, guided=False):
         """extras == 78: project the [B, 77, 768] text embeddings inside the engine (latte.py:341)."""
         if self.extras != 78:
             return
@@ -252,7 +269,7 @@ class Latte(nn.Module):
         if te.shape != (B, 77 * 768):
             raise LatteError(f"text_embedding must be [B, 77, 768] with B = {B}, got {tuple(text_embedding.shape)}")
         with torch.cuda.device(dev):
-            check(load_library().latte_engine_set_text_embedding(self.engine(B), ptr(te), B, stream_ptr()))
+            check(load_library().latte_engine_set_text_embedding(self.engine(B, guided), ptr(te), B, stream_ptr()))
         self._text_keepalive = te     # the projection kernel is stream-ordered; keep its input alive
 
     def _prep(self, x, t, y):
@@ -274,6 +291,10 @@ class Latte(nn.Module):
             y64 = y.to(device=dev, dtype=torch.int64).contiguous()
             if y64.shape != (B,):
                 raise LatteError("y must have shape [B]")
+            rows = self.y_embedder.embedding_table.weight.shape[0]
+            if B and (int(y64.min()) < 0 or int(y64.max()) >= rows):           # nn.Embedding raises IndexError (latte.py:152)
+                raise IndexError(f"label index out of range: y must be in [0, {rows}) "
+                                 f"(num_classes = {rows - 1}, null class = {rows - 1}), got [{int(y64.min())}, {int(y64.max())}]")
         return x32, t64, y64
 
     def forward(self, x, t, y=None, text_embedding=None, use_fp16=False):
@@ -294,8 +315,8 @@ class Latte(nn.Module):
         B = x32.shape[0]
         if B % 2:
             raise LatteError("forward_with_cfg expects the doubled batch [2b, ...] (sample.py:88-94)")
-        eng = self.engine(B)
-        self._set_text(text_embedding, B)
+        eng = self.engine(B, guided=True)
+        self._set_text(text_embedding, B, guided=True)
         out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
                           device=x32.device, dtype=torch.float32)
         with torch.cuda.device(x32.device):

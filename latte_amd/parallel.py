@@ -90,6 +90,6 @@ def broadcast_temb_table(model, diffusion, batch=1, src=0):
         if rank == src:
             check(lib.latte_engine_temb_table(eng, diffusion._h, ptr(table), stream_ptr()))
         broadcast_tensor(table, src)
-        check(lib.latte_engine_set_temb_table(eng, ptr(table), diffusion.num_timesteps, stream_ptr()))
+        check(lib.latte_engine_set_temb_table(eng, diffusion._h, ptr(table), stream_ptr()))
         torch.cuda.current_stream().synchronize()
     return table

@@ -44,6 +44,23 @@ class LattePipeline:
             return emb[:, :, :keep_index, :], keep_index
         return emb * mask[:, None, :, None], emb.shape[2]
 
+    # ------------------------------------------------------------------ pipeline_latte.py:359-379
+    @staticmethod
+    def _text_preprocessing(text, clean_caption=False):
+        """What the reference does to every prompt AND negative prompt before the tokenizer (T5 is case sensitive, so
+        skipping it changes the token ids): ``text.lower().strip()``, or -- with ``clean_caption`` and both ``bs4`` and
+        ``ftfy`` importable -- diffusers' DeepFloyd-IF ``_clean_caption`` twice.  That cleaner (a battery of url / html /
+        CJK / punctuation regexes, pipeline_latte.py:384-496) is not restated here: ``clean_caption=True`` warns and takes
+        the ``lower().strip()`` path, which is also what the reference itself does whenever one of the two packages is
+        missing (:360-368) -- the case in this image."""
+        if clean_caption:
+            import warnings
+            warnings.warn("latte_amd.LattePipeline: clean_caption=True is not available (diffusers' _clean_caption is not "
+                          "restated); prompts are lower-cased and stripped, as the reference does without bs4 / ftfy")
+        if not isinstance(text, (tuple, list)):
+            text = [text]
+        return [str(t).lower().strip() for t in text]
+
     # ------------------------------------------------------------------ pipeline_latte.py:127-270
     def encode_prompt(self, prompt, do_classifier_free_guidance=True, negative_prompt="", num_images_per_prompt=1, device=None,
                       prompt_embeds=None, negative_prompt_embeds=None, clean_caption=False, mask_feature=True):
@@ -57,6 +74,7 @@ class LattePipeline:
             if self.tokenizer is None or self.text_encoder is None:
                 raise LatteError("pass prompt_embeds / negative_prompt_embeds, or construct the pipeline with a tokenizer and a "
                                  "text encoder (T5 in the reference)")
+            prompt = self._text_preprocessing(prompt, clean_caption=clean_caption)                 # :182
             ti = self.tokenizer(prompt, padding="max_length", max_length=max_length, truncation=True, return_attention_mask=True,
                                 add_special_tokens=True, return_tensors="pt")
             attention_mask = ti.attention_mask.to(device)
@@ -69,7 +87,8 @@ class LattePipeline:
         prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs_embed * num_images_per_prompt, seq_len, -1)
         prompt_embeds_attention_mask = prompt_embeds_attention_mask.view(bs_embed, -1).repeat(num_images_per_prompt, 1)
         if do_classifier_free_guidance and negative_prompt_embeds is None:
-            ui = self.tokenizer([negative_prompt] * batch_size, padding="max_length", max_length=prompt_embeds.shape[1],
+            uncond_tokens = self._text_preprocessing([negative_prompt] * batch_size, clean_caption=clean_caption)   # :230-231
+            ui = self.tokenizer(uncond_tokens, padding="max_length", max_length=prompt_embeds.shape[1],
                                 truncation=True, return_attention_mask=True, add_special_tokens=True, return_tensors="pt")
             negative_prompt_embeds = self.text_encoder(ui.input_ids.to(device), attention_mask=ui.attention_mask.to(device))[0]
         if do_classifier_free_guidance:

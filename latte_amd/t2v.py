@@ -26,7 +26,7 @@ class LatteT2V:
     def __init__(self, num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28,
                  sample_size=64, patch_size=2, cross_attention_dim=1152, attention_bias=True, activation_fn="gelu-approximate",
                  norm_type="ada_norm_single", norm_elementwise_affine=False, norm_eps=1e-6, caption_channels=4096,
-                 video_length=16, compute_dtype="bf16", max_batch=2, max_text_tokens=120, **unused):
+                 video_length=16, compute_dtype="f16", max_batch=2, max_text_tokens=120, **unused):
         if norm_type != "ada_norm_single" or not attention_bias or activation_fn != "gelu-approximate" \
                 or norm_elementwise_affine or abs(norm_eps - 1e-6) > 1e-12:
             raise LatteError("latte_amd.LatteT2V implements the Latte-1 configuration only (ada_norm_single, attention_bias, "

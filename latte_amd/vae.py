@@ -26,7 +26,13 @@ class DecoderOutput:
 
 
 class AutoencoderKL:
-    """SD-VAE (``stabilityai/sd-vae-ft-*`` architecture) decoder on the HIP engine."""
+    """SD-VAE (``stabilityai/sd-vae-ft-*`` architecture) decoder on the HIP engine.
+
+    The MFMA operands (GroupNorm+SiLU outputs, conv weights, attention q/k/v/P) are f16 -- the type the reference decodes
+    in (``vae.to(dtype=torch.float16)``, sample.py:74; ``torch_dtype=torch.float16``, sample_t2x.py:32-34) -- and the
+    residual stream is fp32: 1e-3 relative L2 against the fp32 restatement at the full 32x32 -> 256x256 size.  bf16
+    operands (same MFMA rate, 2^-9 instead of 2^-11 unit roundoff in every conv operand) measured 7.3e-3 on the same
+    decode and are not offered: ``compute_dtype`` other than f16 and ``.to(torch.bfloat16)`` raise."""
 
     def __init__(self, latent_size=32, max_frames=16, compute_dtype="f16", scaling_factor=0.18215,
                  block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, norm_num_groups=32):
@@ -37,7 +43,10 @@ class AutoencoderKL:
         self.config = SimpleNamespace(scaling_factor=scaling_factor, block_out_channels=list(block_out_channels),
                                       layers_per_block=layers_per_block, latent_channels=latent_channels,
                                       norm_num_groups=norm_num_groups, in_channels=3, out_channels=3)
-        self.latent_size, self.max_frames, self.compute_dtype = latent_size, max_frames, compute_dtype
+        if compute_dtype not in ("f16", "fp16", "float16"):
+            raise LatteError("latte_amd.AutoencoderKL decodes with f16 MFMA operands only (class docstring): "
+                             f"compute_dtype={compute_dtype!r} is not available")
+        self.latent_size, self.max_frames, self.compute_dtype = latent_size, max_frames, "f16"
         self._sd = {}
         self._device = torch.device("cpu")
         self._h = None
@@ -94,8 +103,10 @@ class AutoencoderKL:
                 self._device = torch.device(a)
                 if self._device.type == "cuda" and self._device.index is None:
                     self._device = torch.device("cuda", torch.cuda.current_device())
-            elif a in (torch.float16, torch.bfloat16):               # sample.py:74 vae.to(dtype=torch.float16)
-                self.compute_dtype = "f16" if a == torch.float16 else "bf16"
+            elif a == torch.bfloat16:
+                raise LatteError("latte_amd.AutoencoderKL decodes with f16 MFMA operands only (class docstring)")
+            elif a in (torch.float16, torch.float32):                # sample.py:74 vae.to(dtype=torch.float16); fp32 = the default
+                pass
         self._synced = False
         return self
 

@@ -61,39 +61,26 @@ def test_gemm_epilogues(lib, dev, dt, variant, shape):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("shape", [(1024, 1152, 1152, 256), (2048, 768, 3072, 512), (16384, 1152, 1152, 4096),
-                                   (4096, 1152, 4608, 4096), (768, 384, 768, 256), (1024, 1152, 704, 256)])
-def test_gemm_deferred_rmw(lib, dev, dt, shape):
-    """Variant 10: the persistent 256x192 kernel whose gated fp32 read-modify-write epilogue is spread over the next tile's
-    K loop (csrc/gemm.hip gemm_rmw_kernel).  The gated delta is held as f16 between the tile boundary and the add
-    (unit roundoff 2^-11 on the delta, the residual itself stays fp32): bound 2^-11 on the delta's share of the result.
-    Shapes: one and several tiles per workgroup, > 256 tiles (uneven tile counts), fc2's long K, the last one falls back to
-    the synchronous kernel (K = 11 K tiles < 12)."""
-    M, N, K, rps = shape
-    g = torch.Generator("cpu").manual_seed(M + N + K)
+def test_gemm_gated_residual_call_site_tags(lib, dev, dt):
+    """The two gated-residual call sites (attention out-projection, fc2) run separate instantiations of the same kernel
+    (distinct symbols in a kernel trace): bit-identical results, exact fp32 read-modify-write."""
+    M, N, K, rps = 4096, 1152, 1152, 4096
+    g = torch.Generator("cpu").manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
     bias = torch.randn(N, generator=g).to(dev)
     gate = torch.randn(M // rps, 2 * N, generator=g).to(dev)
     out0 = torch.randn(M, N, generator=g).to(dev)
-    ref = A.float() @ W.float().t() + bias
-    gi = torch.arange(M, device=dev) // rps
-    delta = gate[gi, :N] * ref
-    want = out0 + delta
+    want = out0 + gate[torch.arange(M, device=dev) // rps, :N] * (A.float() @ W.float().t() + bias)
+    outs = []
     for tag in (0, 1):
         out = out0.clone()
         check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 2 * N, rps, 2, dt,
-                                   10 + 1000 * tag, stream_ptr()))
+                                   1000 * tag, stream_ptr()))
         torch.cuda.synchronize()
-        err = float((out - want).norm() / delta.norm())
-        assert err < 2.0 ** -11, (tag, err)
-        assert float((out - want).abs().max()) < 2.0 ** -10 * float(delta.abs().max()) + 1e-5
-    # twice in a row on the same buffer: deterministic, and no tile is updated twice or skipped
-    o1, o2 = out0.clone(), out0.clone()
-    for o in (o1, o2):
-        check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(o), ptr(gate), M, N, K, 2 * N, rps, 2, dt, 10, stream_ptr()))
-    torch.cuda.synchronize()
-    assert torch.equal(o1, o2)
+        assert float((out - want).norm() / want.norm()) < 2e-5
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
 
 
 CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),

@@ -97,11 +97,13 @@ def test_half_dtype_selects_engine_operand_type():
     import torch
     from latte_amd.models import Latte_models
     m = Latte_models["Latte-S/2"](input_size=8, num_frames=4, extras=1)
-    assert m.compute_dtype == "bf16"
+    # nothing pinned: bf16 operands for the plain forward, f16 for the guided callable (latte_amd.Latte docstring)
+    assert m.compute_dtype is None and m.operand_dtype() == "bf16" and m.operand_dtype(guided=True) == "f16"
     m.to(dtype=torch.float16)
+    assert m.operand_dtype() == m.operand_dtype(guided=True) == "f16"
     assert m.compute_dtype == "f16" and m.pos_embed.dtype == torch.float32
     m.to(torch.bfloat16)
-    assert m.compute_dtype == "bf16"
+    assert m.compute_dtype == "bf16" and m.operand_dtype(guided=True) == "bf16"      # pinned for every call
 
 
 def test_avi_round_trip(tmp_path):

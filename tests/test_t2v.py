@@ -26,7 +26,8 @@ def _model(cfg, sd, cd, **kw):
     m = latte_amd.LatteT2V(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
                            in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
                            sample_size=cfg.sample_size, patch_size=cfg.patch_size, cross_attention_dim=cfg.cross_attention_dim,
-                           caption_channels=cfg.caption_channels, video_length=cfg.video_length, compute_dtype=cd, **kw)
+                           caption_channels=cfg.caption_channels, video_length=cfg.video_length,
+                           **({} if cd is None else {"compute_dtype": cd}), **kw)
     m.load_state_dict(sd)
     return m
 
@@ -90,9 +91,10 @@ def test_t2v_forward_matches_oracle(case):
     m = _model(cfg, sd, "f16", max_batch=B).to("cuda")
     got = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
     assert rel_l2(got, want) < TOL
-    m16 = _model(cfg, sd, "bf16", max_batch=B).to("cuda")
-    got = m16(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
-    assert rel_l2(got, want) < 3e-3      # bf16 operands, random (untrained) weights with O(1) adaLN tables: see DESIGN.md section 2
+    # default operand type of LatteT2V = f16, the type the reference runs this transformer in (sample_t2x.py:29)
+    md = _model(cfg, sd, None, max_batch=B).to("cuda")
+    assert md.compute_dtype == "f16"
+    assert torch.equal(md(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample, got)
 
 
 def test_pipeline_surface_on_cpu():
@@ -146,7 +148,8 @@ def test_pipeline_guided_ddim_chain_matches_oracle_loop():
     pipe = latte_amd.LattePipeline(transformer=_model(cfg, sd, "f16"), scheduler=DDIMScheduler()).to("cuda")
     got = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps, guidance_scale=scale, latents=lat,
                output_type="latents").video
-    assert rel_l2(got, want) < 2e-3          # four guided steps at scale 4.5 on an untrained tiny model (f16 operands)
+    print(f"t2v guided chain rel-L2 vs oracle loop: {rel_l2(got, want):.3e}")
+    assert rel_l2(got, want) < TOL
     # decode hand-off (pipeline_latte.py:773-785) on a 16x16 latent (the VAE engine's smallest): uint8 [b, f, h, w, c]
     vsd = vo.init_state_dict(seed=2)
     vae = latte_amd.AutoencoderKL(latent_size=16, max_frames=2, compute_dtype="f16")

@@ -8,11 +8,10 @@ from _util import rel_l2
 from oracle import vae_oracle as vo
 
 TD = {0: torch.bfloat16, 1: torch.float16}
-# north_star tolerance on the decoded frames: 1e-3 relative L2 against the fp32 restatement, for the decoder's default
-# operand type (f16: the reference's own half mode is fp16, sample.py:72-75,110-111).  bf16 operands (selectable) carry a
-# 4x coarser mantissa into every conv / attention operand: bound stated separately.
+# north_star tolerance on the decoded frames: 1e-3 relative L2 against the fp32 restatement.  The decoder runs f16 MFMA
+# operands (the reference decodes in fp16: sample.py:74, sample_t2x.py:32-34) on an fp32 residual stream; bf16 operands are
+# not offered (7.3e-3 on the same decode: latte_amd/vae.py).
 TOL = 1e-3
-BF16_TOL = 4e-3
 
 
 # ------------------------------------------------------------------------------------------------ CPU
@@ -53,11 +52,16 @@ def test_engine_key_set_equals_oracle_key_set(lib):
         vae.decode(torch.zeros(1, 4, 16, 16))            # no GPU / not moved to cuda: must raise, never fall back
     with pytest.raises(Exception):
         vae.encode(torch.zeros(1, 3, 128, 128))
+    with pytest.raises(Exception):
+        AutoencoderKL(compute_dtype="bf16")              # f16 operands only (latte_amd/vae.py)
+    with pytest.raises(Exception):
+        vae.to(torch.bfloat16)
+    assert vae.to(dtype=torch.float16).compute_dtype == "f16"     # the reference's own call (sample.py:74)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("dt", [1])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0, False), (1, 16, 16, 128, 256, 1, False), (1, 8, 24, 256, 128, 0, True),
                                   (3, 5, 7, 64, 128, 1, True)])
 def test_conv3x3_kernel(lib, dt, case):
@@ -98,7 +102,7 @@ def test_conv3x3_kernel(lib, dt, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("dt", [1])
 @pytest.mark.parametrize("case", [(2, 256, 128, 1), (1, 1024, 512, 1), (1, 4096, 256, 0), (3, 100, 128, 1)])
 def test_groupnorm_kernel(lib, dt, case):
     from latte_amd._lib import check, ptr, stream_ptr
@@ -127,7 +131,7 @@ def test_groupnorm_kernel(lib, dt, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cd,tol", [("bf16", BF16_TOL), ("f16", TOL)])
+@pytest.mark.parametrize("cd,tol", [("f16", TOL)])
 def test_vae_decode_vs_oracle(lib, cd, tol):
     """Whole decoder on random weights, latent 16x16 -> 128x128, 2 frames (oracle: seconds on CPU)."""
     from latte_amd.vae import AutoencoderKL
@@ -152,11 +156,11 @@ def test_vae_decode_vs_oracle(lib, cd, tol):
     # and against the oracle's own uint8 video: half-precision noise moves a few pixels by a few levels
     d = (u8.view(2, 128, 128, 3).cpu().int() - vo.to_uint8_video(want.clone()).int()).abs()
     print(f"uint8 video vs oracle: max level diff {int(d.max())}, mean {float(d.float().mean()):.3f}")
-    assert float(d.float().mean()) < (1.5 if cd == "bf16" else 0.3)
+    assert float(d.float().mean()) < 0.3
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cd,tol", [("bf16", BF16_TOL), ("f16", TOL)])
+@pytest.mark.parametrize("cd,tol", [("f16", TOL)])
 def test_vae_stagewise_vs_oracle(lib, cd, tol):
     """Every traced decoder stage (conv_in, mid block, each up-block resnet / upsampler) against the oracle."""
     import ctypes

@@ -309,63 +309,41 @@ def gemm_in_model():
         torch.cuda.empty_cache()
 
 
-def rmw_bench():
-    """Gated fp32 residual GEMMs: synchronous epilogue (variant 8) against the deferred one (variant 10), stand-alone."""
+def rmw_ahead():
+    """Measurement build (LATTE_DEBUG_BUILD=1): look-ahead depth / non-temporal loads of the synchronous read-modify-write
+    epilogue (LATTE_RMW_MODE = depth + 16 * nt), stand-alone with an output larger than the Infinity Cache (M = 65536:
+    the residual is HBM-cold, as inside the model) and inside the XL/2 forward at B = 8."""
     ms = _lib.c_f32()
-    for M in (8192, 32768, 65536):
-        for (N, K, nm, tag) in [(1152, 1152, "proj", 0), (1152, 4608, "fc2", 1)]:
+    modes = [0, 3, 4, 6, 8, 12, 18, 20, 22, 24]
+    for (N, K, nm, tag) in [(1152, 1152, "proj", 0), (1152, 4608, "fc2", 1)]:
+        for M in (65536, 32768):
             row = []
-            for rep in range(2):
-                for variant in (8, 10):
-                    check(lib.latte_bench_gemm(M, N, K, 2, 0, variant + 1000 * tag, 20, ctypes.byref(ms), stream_ptr()))
-                    tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
-                    row.append(f"v{variant}: {ms.value*1e3:6.1f}us {tf:5.0f}TF")
-            log(f"rmw_bench M={M:5d} {nm:4s} N={N} K={K}: " + " | ".join(row))
-
-
-def rmw_in_model():
-    """proj / fc2 inside the XL/2 forward: variant 8 against 10 (HIP events per launch), B = 8, 2, 1; then steps/s."""
+            for mode in modes + [0]:
+                os.environ["LATTE_RMW_MODE"] = str(mode)
+                check(lib.latte_bench_gemm(M, N, K, 2, 0, 8 + 1000 * tag, 20, ctypes.byref(ms), stream_ptr()))
+                row.append(f"m{mode}: {ms.value*1e3:6.1f}")
+            log(f"rmw_ahead {nm} M={M} (us): " + " | ".join(row))
     from latte_amd.models import Latte_models
-    import latte_amd
-    for B in (8, 2):
-        m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
-        with torch.no_grad():
-            for n_, p_ in m.named_parameters():
-                if float(p_.abs().max()) == 0.0:
-                    p_.normal_(0, 0.02)
-        m = m.to(dev)
-        x = torch.randn(B, 16, 4, 32, 32, device=dev)
-        t = torch.full((B,), 500, device=dev, dtype=torch.int64)
-        outs = {}
-        for v in (8, 10, 8, 10):
-            m.set_engine_option("gemm_variant_proj", v, B)
-            m.set_engine_option("gemm_variant_fc2", v, B)
-            outs[v] = m(x, t).float().clone()
-            m.profile_forward(x, t)
-            pr = [m.profile_forward(x, t) for _ in range(3)]
-            row = " ".join(f"{k}: {min(p[k][0] for p in pr) / max(pr[0][k][1], 1) * 1e3:6.1f}us" for k in
-                           ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial", "attn_temporal", "ln_modulate"))
-            tot = min(sum(v_[0] for v_ in p.values()) for p in pr)
-            log(f"in-model B={B} proj/fc2 variant {v}: {row} | forward {tot:.3f} ms")
-        d = ((outs[8] - outs[10]).norm() / outs[8].norm()).item()
-        log(f"in-model B={B}: forward output rel-L2 (variant 10 vs 8) = {d:.3e}")
-        dd = latte_amd.create_diffusion("250")
-        for v in (8, 10, 0):
-            m.set_engine_option("gemm_variant_proj", v, B)
-            m.set_engine_option("gemm_variant_fc2", v, B)
-            eng = m.engine(B)
-            xx = x.clone()
-            check(lib.latte_sample_loop(eng, dd._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 249, 247, None, None, None, stream_ptr()))
-            torch.cuda.synchronize()
-            t0 = time.time()
-            steps = 20
-            check(lib.latte_sample_loop(eng, dd._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 246, 246 - steps + 1, None, None, None, stream_ptr()))
-            torch.cuda.synchronize()
-            dtm = time.time() - t0
-            log(f"in-model B={B} proj/fc2 variant {v}: {steps} DDIM steps -> {B*steps/dtm:.2f} sample-steps/s "
-                f"({dtm/steps*1e3:.2f} ms/step), finite={bool(torch.isfinite(xx).all())}")
-        del m
-        torch.cuda.empty_cache()
+    B = 8
+    m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.normal_(0, 0.02)
+    m = m.to(dev)
+    x = torch.randn(B, 16, 4, 32, 32, device=dev)
+    t = torch.full((B,), 500, device=dev, dtype=torch.int64)
+    os.environ["LATTE_RMW_VARIANT"] = "8"
+    for mode in modes + [0]:
+        os.environ["LATTE_RMW_MODE"] = str(mode)
+        m.profile_forward(x, t)
+        pr = [m.profile_forward(x, t) for _ in range(3)]
+        row = " ".join(f"{k}: {min(p[k][0] for p in pr) / max(pr[0][k][1], 1) * 1e3:6.1f}us" for k in
+                       ("gemm_proj", "gemm_fc2", "gemm_qkv", "gemm_fc1", "ln_modulate"))
+        tot = min(sum(v_[0] for v_ in p.values()) for p in pr)
+        log(f"rmw_ahead in-model B={B} mode {mode}: {row} | forward {tot:.3f} ms")
+    os.environ["LATTE_RMW_MODE"] = "0"
+    del os.environ["LATTE_RMW_VARIANT"]
 
 
 def gemm_stagger():
