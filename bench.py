@@ -3,7 +3,7 @@
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 One "step" = one pass of the hot path (denoiser forward + sampler update) over the rank's batch of
-latents, inputs resident in HBM.  Workload = BASELINE.json configs[1]: Latte-XL/2, FaceForensics
+latents, inputs resident in HBM.  Workload (every N) = BASELINE.json configs[1]: Latte-XL/2, FaceForensics
 (unconditional) config, 16 frames of 32x32 latents, per-GPU batch 8 (= BASELINE config 3's per-GPU share
 of its batch 64; `--batch 2` is the reference YAML's per_proc_batch_size), DDIM eta=0 over the "250"
 respacing, random-init weights (adaLN/final layers re-drawn N(0, 0.02) so the network is not the
@@ -11,6 +11,17 @@ identity), synthetic N(0,1) latents.  Weak scaling: every rank runs its own samp
 collective (the reference's sample_ddp.py has none either); the only payload collective is the one-off
 RCCL broadcast of the timestep-embedding table before the timed region.
 `value` = aggregate denoising sample-steps/s = n_gpus * batch * K / max-over-ranks time.
+
+Beside the headline, in the same JSON line:
+  * `roofline`: the DOMINANT kernel of the step (largest share of the forward by HIP events on the launch
+    stream) and `roofline_table`: every kernel class with its bound, algorithmic work per launch, average
+    launch time and fraction of the MI355X peak (MFMA 2.5 PFLOP/s dense bf16/f16, HBM 8 TB/s);
+  * `f16`: the same timed loop with f16 MFMA operands (the type guided runs use: latte_amd.Latte docstring);
+  * `config3`: BASELINE config 3's per-GPU share -- UCF101 class-conditional Latte-XL/2, CFG 7.0, 8 samples =
+    16 sequences per GPU through forward_with_cfg (aggregate guided sample-steps/s over all ranks);
+  * `cpu_baseline` (N = 1): the oracle's forward on the host cores, a forward-only proxy of the reference's
+    p_sample_loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
+    than it because it skips the reference's repeated adaLN rows: oracle/VALIDATION.md).
 """
 import argparse
 import ctypes
@@ -26,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_SAMPLE_STEP = {"Latte-XL/2": 3.726e12}  # SURVEY.md §8(d), algorithmic, 16x32x32 latents
 MFMA_PEAK_TFLOPS = 2500.0                           # MI355X_MICROARCH.md: bf16/f16 dense
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def parse():
@@ -39,15 +51,16 @@ def parse():
     p.add_argument("--gemm-variant", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode rate report")
+    p.add_argument("--no-side", action="store_true", help="skip the f16 / config-3 side measurements")
     p.add_argument("--cpu-forwards", type=int, default=2)
     return p.parse_args()
 
 
-def build_model(args, device):
+def build_model(device, dtype, batch, extras=1, num_classes=1000):
     import latte_amd
     torch.manual_seed(0)
-    m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=1, learn_sigma=True,
-                                             compute_dtype=args.dtype, max_batch=args.batch)
+    m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=extras, num_classes=num_classes,
+                                             learn_sigma=True, compute_dtype=dtype, max_batch=batch)
     g = torch.Generator("cpu").manual_seed(1)
     with torch.no_grad():
         for _, prm in m.named_parameters():
@@ -56,18 +69,28 @@ def build_model(args, device):
     return m.to(device).eval()
 
 
-def run_steps(lib, model, diffusion, x, n_steps, method, batch):
+def run_steps(lib, model, diffusion, x, n_steps, method, batch, y=None, cfg_scale=1.0, guided=False):
     """Exactly n_steps denoising steps: chains of up to num_timesteps steps through the fused loop."""
     from latte_amd._lib import check, ptr, stream_ptr
-    eng = model.engine(batch)
+    eng = model.engine(batch, guided=guided)
     T = diffusion.num_timesteps
     left = n_steps
     mi = 1 if method == "ddim" else 0
     while left > 0:
         seg = min(left, T)
-        check(lib.latte_sample_loop(eng, diffusion._h, mi, 0.0, 0, 1.0, ptr(x), None, batch, T - 1, T - seg, None,
-                                    None, None, stream_ptr()))
+        check(lib.latte_sample_loop_ex(eng, diffusion._h, mi, 0.0, 0, int(guided), cfg_scale, ptr(x), ptr(y), batch, T - 1,
+                                       T - seg, None, None, None, stream_ptr()))
         left -= seg
+
+
+def timed_steps(lib, model, diffusion, x, steps, method, batch, **kw):
+    """Side measurement (not the headline): 2 warm-up steps, then `steps` timed ones; seconds per step."""
+    run_steps(lib, model, diffusion, x, 2, method, batch, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(lib, model, diffusion, x, steps, method, batch, **kw)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def cpu_baseline(n_forwards):
@@ -88,21 +111,88 @@ def cpu_baseline(n_forwards):
             lo.latte_forward(sd, cfg, x, t)
         dt = (time.time() - t0) / n_forwards
     return {"value": round(1.0 / dt, 4), "unit": "denoising sample-steps/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{n_forwards} timed fp32 forwards of Latte-XL/2 (B=1, 16x32x32 latents) after 1 warm-up; "
-                      "the sampler update is negligible on CPU (<0.1%)"}
+            "host_cores_visible": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"forward-only proxy of the reference's p_sample_loop: {n_forwards} timed fp32 forwards of the oracle's "
+                      "Latte-XL/2 (B=1, 16x32x32 latents) after 1 warm-up; the sampler update is negligible on CPU "
+                      "(<0.1%); the oracle is bit-identical to the reference forward and ~6 % faster than it "
+                      "(oracle/VALIDATION.md: 6.61 s vs 7.06 s)"}
 
 
-def pmc_traffic(kernel_class, M):
-    """HBM bytes per launch of the dominant GEMM from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE); None when that shape was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        tab = json.load(f)
-    rec = tab.get(f"{kernel_class}:M={M}")
-    return rec["hbm_bytes_per_launch"] if rec else None
+def pmc_table():
+    """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_collect.py:
+    FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE); {} when nothing was profiled."""
+    tab = {}
+    for name in ("r1_gemm_pmc.json", "r2_pmc.json"):      # later files override earlier ones
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                tab.update(json.load(f))
+    return tab
+
+
+def roofline_table(prof, B, dtype):
+    """Per kernel class: algorithmic work per launch (2 M N K for the linears, 4 S L^2 D for the
+    attention products; bytes = the operands a launch must read / write once), average launch time by HIP events, and
+    the fraction of the roofline that bounds it."""
+    D, Hm, F, T = 1152, 4608, 16, 256
+    M = B * F * T
+    mfma = {"gemm_qkv": (2.0 * M * 3 * D * D, "gemm_pps_kernel<256, EPI_BIAS_H16>: qkv projection M=%d N=3456 K=1152" % M),
+            "gemm_proj": (2.0 * M * D * D, "gemm_pps_kernel<192, EPI_GATE_RES_F32, tag 0>: attention out-projection M=%d N=1152 K=1152, gated fp32 residual RMW" % M),
+            "gemm_fc1": (2.0 * M * Hm * D, "gemm_pps_kernel<256, EPI_BIAS_GELU_H16>: fc1 M=%d N=4608 K=1152, bias+GELU" % M),
+            "gemm_fc2": (2.0 * M * D * Hm, "gemm_pps_kernel<192, EPI_GATE_RES_F32, tag 1>: fc2 M=%d N=1152 K=4608, gated fp32 residual RMW" % M)}
+    qkv_bytes = M * 3 * D * 2 + M * D * 2      # reads q, k, v once, writes the head outputs
+    hbm = {"attn_spatial": (qkv_bytes, 4.0 * B * F * T * T * D, "attn_full_kernel<72>: spatial attention, %d sequences x 16 heads x 256 tokens" % (B * F)),
+           "attn_temporal": (qkv_bytes, 4.0 * B * T * F * F * D, "attn_small_kernel<72>: temporal attention, %d sequences x 16 heads x 16 frames" % (B * T)),
+           "ln_modulate": (M * D * (4 + 2), 0.0, "ln_modulate_kernel: LayerNorm + adaLN modulate, fp32 in, half out")}
+    pmc = pmc_table()
+    total_ms = sum(v[0] for v in prof.values())
+    rows = []
+    for k, (ms, n) in prof.items():
+        if n == 0 or (k not in mfma and k not in hbm):
+            continue
+        avg = ms / n
+        row = {"class": k, "launches_per_forward": n, "avg_launch_ms": round(avg, 4), "share_of_forward": round(ms / total_ms, 4)}
+        if k in mfma:
+            fl, name = mfma[k]
+            ach = fl / (avg * 1e-3) / 1e12
+            row.update({"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": fl})
+        else:
+            by, fl, name = hbm[k]
+            ach = by / (avg * 1e-3) / 1e9
+            row.update({"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": by})
+            if fl:
+                row["mfma_frac_of_peak"] = round(fl / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        rec = pmc.get(f"{k}:M={M}")
+        row["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
+        rows.append(row)
+    rows.sort(key=lambda r: -r["share_of_forward"])
+    return rows, total_ms
+
+
+def vae_decoder_flops(h):
+    """Algorithmic FLOPs of one frame of AutoencoderKL.decode at an h x h latent, from the layer shapes (2 * pixels * Cin *
+    Cout * taps per convolution; the one attention as four 512 x 512 linears + the two L x L products): 0.622 TFLOP at
+    h = 32."""
+    def conv(H, cin, cout, k=3):
+        return 2 * H * H * cin * cout * k * k
+
+    def resnet(H, cin, cout):
+        return conv(H, cin, cout) + conv(H, cout, cout) + (conv(H, cin, cout, 1) if cin != cout else 0)
+
+    f = conv(h, 4, 4, 1) + conv(h, 4, 512) + 2 * resnet(h, 512, 512)
+    L = h * h
+    f += 4 * 2 * L * 512 * 512 + 2 * 2 * L * L * 512
+    H, prev = h, 512
+    for i, c in enumerate((512, 512, 256, 128)):
+        for r in range(3):
+            f += resnet(H, prev if r == 0 else c, c)
+        prev = c
+        if i < 3:
+            H *= 2
+            f += conv(H, c, c)
+    return f + conv(H, 128, 3)
 
 
 def vae_decode_rate(device):
@@ -123,7 +213,9 @@ def vae_decode_rate(device):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     return {"ms_per_video": round(dt * 1e3, 2), "frames_per_sec": round(16 / dt, 1), "dtype": "f16",
-            "algorithmic_tflops_per_s": round(16 * 0.62 / dt, 1), "finite_and_nonconstant": bool(out.float().std() > 0)}
+            "algorithmic_tflops_per_s": round(16 * vae_decoder_flops(32) / 1e12 / dt, 1),
+            "algorithmic_tflop_per_frame": round(vae_decoder_flops(32) / 1e12, 4),
+            "finite_and_nonconstant": bool(out.float().std() > 0)}
 
 
 def note(msg):
@@ -155,7 +247,7 @@ def main():
     from latte_amd._lib import load_library
     lib = load_library()
     note('building model')
-    model = build_model(args, device)
+    model = build_model(device, args.dtype, args.batch)
     note('model on device')
     if args.gemm_variant:
         model.set_engine_option("gemm_variant", args.gemm_variant, args.batch)
@@ -203,22 +295,41 @@ def main():
         dt = time.perf_counter() - t1
         other = {"method": om, "value": round(B * n_other / dt, 3), "unit": "sample-steps/s", "steps": n_other,
                  "finite": bool(torch.isfinite(xo).all())}
+    side = {}
+    if not args.no_side:
+        # f16 operands: same model, same loop, short run (the operand type guided runs take)
+        n_side = min(args.steps, 20)
+        other_dt = "f16" if args.dtype == "bf16" else "bf16"
+        model.to(dtype=torch.float16 if other_dt == "f16" else torch.bfloat16)
+        dt16 = timed_steps(lib, model, diffusion, x.clone(), n_side, args.method, B)
+        model.to(dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16)
+        side[other_dt] = {"ms_per_step": dt16 * 1e3, "steps": n_side}
+        # BASELINE config 3's per-GPU share: class-conditional (UCF101: 101 classes), CFG 7.0, 8 samples = 16 sequences
+        m3 = build_model(device, None, 16, extras=2, num_classes=101)     # operand rule: guided -> f16
+        gq = torch.Generator("cpu").manual_seed(2000 + rank)
+        z3 = torch.randn(8, 16, 4, 32, 32, generator=gq)
+        y3 = torch.cat([torch.randint(0, 101, (8,), generator=gq), torch.full((8,), 101)]).to(device)
+        x3 = torch.cat([z3, z3]).to(device).contiguous()
+        n3 = min(args.steps, 10)
+        dt3 = timed_steps(lib, m3, diffusion, x3, n3, args.method, 16, y=y3, cfg_scale=7.0, guided=True)
+        side["config3"] = {"ms_per_step": dt3 * 1e3, "steps": n3}
+        del m3
+        torch.cuda.empty_cache()
+        if dist is not None:   # max over ranks of every side timing
+            keys = sorted(side)
+            tt = torch.tensor([side[k]["ms_per_step"] for k in keys], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            for k, v in zip(keys, tt.tolist()):
+                side[k]["ms_per_step"] = v
     if rank == 0:
         value = world * B * args.steps / elapsed
         flops = FLOPS_PER_SAMPLE_STEP["Latte-XL/2"]
-        # roofline of the dominant kernel, timed live with HIP events on the launch stream
+        # rooflines, timed live with HIP events on the launch stream
         t = torch.full((B,), 500, device=device, dtype=torch.int64)
         model.profile_forward(x, t)
         prof = model.profile_forward(x, t)
-        total_ms = sum(v[0] for v in prof.values())
-        D, Hm, M = 1152, 4608, B * 16 * 256
-        gemm_flops = {"gemm_qkv": 2.0 * M * 3 * D * D, "gemm_proj": 2.0 * M * D * D, "gemm_fc1": 2.0 * M * Hm * D,
-                      "gemm_fc2": 2.0 * M * D * Hm}
-        # dominant kernel for the roofline object: the fc1 GEMM (largest single-shape kernel; fc2 and proj share one
-        # template instantiation, so their rocprof averages are mixed -- DESIGN.md section 5)
-        dom = "gemm_fc1"
-        avg_ms = prof[dom][0] / max(prof[dom][1], 1)
-        achieved = gemm_flops[dom] / (avg_ms * 1e-3) / 1e12
+        table, total_ms = roofline_table(prof, B, args.dtype)
+        dom = table[0]                                   # the dominant kernel = largest share of the forward
         res = {
             "metric": "denoising steps/sec", "value": round(value, 3), "unit": "sample-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,12 +342,24 @@ def main():
             "latent_frames_per_sec": round(world * B * 16 / (elapsed / args.steps * 250), 3),
             "model_mfma_frac": round(value / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "finite": finite,
-            "roofline": {"bound": "mfma", "kernel": f"gemm_pps_kernel ({dom}: M={M} N={Hm} K={D}, bias+GELU epilogue)", "achieved": round(achieved, 1),
-                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic(dom, M), "avg_launch_ms": round(avg_ms, 4)},
+            "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+                         "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"],
+                         "avg_launch_ms": dom["avg_launch_ms"], "share_of_forward": dom["share_of_forward"]},
+            "roofline_table": table,
             "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
             "forward_ms_eager_events": round(total_ms, 4),
         }
+        for k, v in side.items():
+            if k == "config3":
+                sps = world * 8 / (v["ms_per_step"] * 1e-3)
+                res["config3"] = {"workload": "Latte-XL/2 UCF101 class-conditional (101 classes + null), CFG 7.0 through "
+                                              "forward_with_cfg, 8 samples = 16 sequences per GPU, f16 operands (guided rule)",
+                                  "value": round(sps, 3), "unit": "guided sample-steps/s", "ms_per_step": round(v["ms_per_step"], 3),
+                                  "steps": v["steps"], "global_batch": 8 * world,
+                                  "model_mfma_frac": round(2 * sps / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+            else:
+                res[k] = {"value": round(world * B / (v["ms_per_step"] * 1e-3), 3), "unit": "sample-steps/s",
+                          "ms_per_step": round(v["ms_per_step"], 4), "steps": v["steps"]}
         if world == 1 and not args.no_vae:
             res["vae_decode"] = vae_decode_rate(device)
         if world == 1 and not args.no_cpu_baseline:

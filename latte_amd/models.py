@@ -7,6 +7,7 @@ PyTorch op on the data path: ``forward`` / ``forward_with_cfg`` hand device poin
 engine through the C-ABI (``include/latte_amd.h``).  No GPU / no library -> it raises.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -355,17 +356,24 @@ for _fam, (_d, _h, _nh) in {"XL": (28, 1152, 16), "L": (24, 1024, 16), "B": (12,
 
 
 def get_models(args):
-    """``models.get_models`` (models/__init__.py:31-51) for the accelerated family."""
+    """``models.get_models`` (models/__init__.py:31-51): ``Latte-*`` presets and ``LatteT2V`` (the Latte-1 text-to-video
+    transformer, loaded from ``<pretrained_model_path>/transformer`` exactly as the reference does, :41).  ``LatteIMG-*`` is
+    the joint image-video TRAINING variant (models/latte_img.py) and is not part of the sampling engine."""
     name = args.model
-    if "LatteIMG" in name or "LatteT2V" in name:
-        raise LatteError(f"{name}: only the class-conditional / unconditional Latte family runs on the "
-                         "MI355X engine in this build (SURVEY.md §8(f) lists LatteT2V as the next row)")
+
+    def opt(k):
+        return args.get(k) if hasattr(args, "get") else getattr(args, k, None)
+
+    if "LatteIMG" in name:
+        raise LatteError(f"{name}: the joint image-video training variant (models/latte_img.py) is outside the MI355X "
+                         "sampling engine")
+    if "LatteT2V" in name:
+        from .t2v import LatteT2V
+        extra = {k: opt(k) for k in ("compute_dtype", "max_batch") if opt(k) is not None}
+        return LatteT2V.from_pretrained(args.pretrained_model_path, subfolder="transformer", video_length=args.video_length,
+                                        **extra)
     if name in Latte_models:
-        extra = {}
-        for k in ("compute_dtype", "max_batch"):
-            v = args.get(k) if hasattr(args, "get") else getattr(args, k, None)
-            if v is not None:
-                extra[k] = v
+        extra = {k: opt(k) for k in ("compute_dtype", "max_batch") if opt(k) is not None}
         return Latte_models[name](input_size=args.latent_size, num_classes=args.num_classes,
                                   num_frames=args.num_frames, learn_sigma=args.learn_sigma, extras=args.extras,
                                   **extra)
@@ -374,6 +382,8 @@ def get_models(args):
 
 def find_model(model_name):
     """``utils.find_model`` (utils.py:274-287): checkpoint dict -> 'ema' weights if present."""
+    if not os.path.isfile(model_name):
+        raise AssertionError(f"Could not find Latte checkpoint at {model_name}")        # utils.py:278
     checkpoint = torch.load(model_name, map_location=lambda storage, loc: storage)
     if "ema" in checkpoint:
         print("Using Ema!")

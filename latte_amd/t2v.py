@@ -55,6 +55,9 @@ class LatteT2V:
         model.load_state_dict(sd)
         return model
 
+    # models/__init__.py:41 calls the diffusers ModelMixin spelling: same directory layout (config.json + weights)
+    from_pretrained = from_pretrained_2d
+
     def load_state_dict(self, state_dict, strict=True):
         self._sd = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
         self._synced = False

@@ -123,6 +123,35 @@ def test_pipeline_surface_on_cpu():
     assert s.timesteps[:3].tolist() == [980, 960, 940] and s.timesteps[-1].item() == 0
 
 
+def test_pipeline_text_preprocessing_on_cpu():
+    """pipeline_latte.py:182,230-231,359-379: prompt and negative prompt are lower-cased and stripped before the tokenizer
+    (T5 is case sensitive); clean_caption=True without bs4 / ftfy warns and does the same, as the reference."""
+    import warnings
+    from types import SimpleNamespace
+    from latte_amd.schedulers import DDIMScheduler
+    cfg, sd, z = _fixture()
+    seen = []
+
+    def tokenizer(texts, **kw):
+        seen.append(list(texts))
+        n = kw["max_length"]
+        return SimpleNamespace(input_ids=torch.zeros(len(texts), n, dtype=torch.int64),
+                               attention_mask=torch.ones(len(texts), n, dtype=torch.int64))
+
+    def text_encoder(ids, attention_mask=None):
+        return (torch.zeros(ids.shape[0], ids.shape[1], cfg.caption_channels),)
+
+    pipe = latte_amd.LattePipeline(tokenizer=tokenizer, text_encoder=text_encoder, transformer=_model(cfg, sd, "f16"),
+                                   scheduler=DDIMScheduler())
+    pe, ne = pipe.encode_prompt(["  A Dog Running On The BEACH \n"], negative_prompt=" Blurry ", device="cpu")
+    assert seen == [["a dog running on the beach"], ["blurry"]]
+    assert pe.shape[0] == 1 and ne.shape[:2] == pe.shape[:2]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert pipe._text_preprocessing("  MiXed ", clean_caption=True) == ["mixed"]
+        assert any("clean_caption" in str(x.message) for x in w)
+
+
 @pytest.mark.gpu
 def test_pipeline_guided_ddim_chain_matches_oracle_loop():
     """The denoising loop of pipeline_latte.py:700-760 (guidance pair [negative, prompt], learned-sigma drop, scheduler step)
