@@ -55,12 +55,18 @@ def main():
     n = int(args.per_proc_batch_size)
     using_cfg = float(args.cfg_scale) > 1.0
     args.max_batch = 2 * n if using_cfg else n
+    # The reference seeds torch with seed * world + rank before building anything (sample_ddp.py:63-65), which ties the
+    # draws to the world size; here every rank seeds identically (random-weight plumbing runs then hold the SAME replica on
+    # every GPU) and the per-sample noise / labels come from the global sample index (parallel.sample_noise).
+    torch.manual_seed(seed)
     model = latte_amd.get_models(args)
-    if a.ckpt:
-        model.load_state_dict(latte_amd.find_model(a.ckpt))
+    if a.ckpt or args.get("ckpt"):
+        model.load_state_dict(latte_amd.find_model(a.ckpt or args.ckpt))
     else:
         randomise_zero_init(model)
     model = model.to(device).eval()
+    if args.get("use_fp16"):
+        model.to(dtype=torch.float16)                              # sample.py:72-75 / sample_ddp.py use_fp16
     diffusion = latte_amd.create_diffusion(str(a.steps or args.num_sampling_steps))
     vae = None
     if not a.no_decode:
