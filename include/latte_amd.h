@@ -55,7 +55,7 @@ int latte_schedule_num_timesteps(const latte_schedule_t* s);
 int latte_schedule_timestep_map(const latte_schedule_t* s, int64_t* out, int n);
 /* name in {betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
  * sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped,
- * posterior_mean_coef1, posterior_mean_coef2, log_betas} */
+ * posterior_mean_coef1, posterior_mean_coef2, log_betas, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod} */
 int latte_schedule_table(const latte_schedule_t* s, const char* name, double* out, int n);
 
 /* ------------------------------------------------------------------ engine
@@ -169,6 +169,25 @@ int latte_sample_loop(latte_engine_t* e, const latte_schedule_t* s, int method, 
 int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int method, float eta, int clip_denoised, int guided,
                          float cfg_scale, float* x, const int64_t* y, int batch, int start_index, int end_index,
                          const float* noise, float* trail_sample, float* trail_x0, void* stream);
+
+/* ------------------------------------------------------------------ training path, forward evaluation
+ * SURVEY.md section 8(f) rank 3, first slice: the loss VALUES of GaussianDiffusion.training_losses
+ * (gaussian_diffusion.py:719-795, through SpacedDiffusion.training_losses respace.py:95-98; called by train.py:224-226)
+ * on device tensors, one timestep per sample -- no gradients yet (the backward kernels are the next slice).
+ *   latte_q_sample          gaussian_diffusion.py:216-229   x_t = sqrt(ab[t]) x_0 + sqrt(1 - ab[t]) noise
+ *   latte_training_losses   given x_0, x_t, noise and the model's output on (x_t, timestep_map[t]):
+ *                           mse = mean_flat((target - prediction)^2) (target = noise | x_0, :776-785),
+ *                           vb  = _vb_terms_bpd with the frozen mean (:686-717,:760-774; KL in bits, decoder NLL at t == 0),
+ *                           loss by loss_type: 0 MSE (mse [+ vb when the variance is learned]), 1 RESCALED_MSE (vb *
+ *                           num_timesteps / 1000), 2 KL (vb), 3 RESCALED_KL (vb * num_timesteps)  (diffusion/__init__.py:22-27)
+ * t: int64[batch] RESPACED indices (device); tensors [batch, frames, channels, hw] fp32 (model_out with 2 * channels when the
+ * schedule's variance is learned); mse_out / vb_out may be NULL; workspace: latte_training_workspace_floats() floats. */
+int latte_q_sample(const latte_schedule_t* s, const float* x_start, const float* noise, const int64_t* t, int batch,
+                   int64_t numel_per_sample, float* x_t, void* stream);
+int64_t latte_training_workspace_floats(int batch, int64_t numel_per_sample);
+int latte_training_losses(const latte_schedule_t* s, int loss_type, const float* x_start, const float* x_t, const float* noise,
+                          const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw, float* workspace,
+                          int64_t workspace_floats, float* mse_out, float* vb_out, float* loss_out, void* stream);
 
 /* ------------------------------------------------------------------ VAE decoder
  * Replaces diffusers.AutoencoderKL (sample/sample.py:69 from_pretrained, :113-115 vae.decode(z / 0.18215).sample;

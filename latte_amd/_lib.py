@@ -64,6 +64,10 @@ PROTOTYPES = {
                                   c_void, c_void, c_void, c_void]),
     "latte_sample_loop_ex": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_int, c_f32, c_void, c_void, c_int, c_int, c_int,
                                      c_void, c_void, c_void, c_void]),
+    "latte_q_sample": (c_int, [c_void, c_void, c_void, c_void, c_int, c_i64, c_void, c_void]),
+    "latte_training_workspace_floats": (c_i64, [c_int, c_i64]),
+    "latte_training_losses": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void,
+                                      c_i64, c_void, c_void, c_void, c_void]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),

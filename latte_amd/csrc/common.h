@@ -14,11 +14,17 @@ struct latte_schedule {
   std::vector<int64_t> timestep_map;
   std::vector<double> betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
       sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped, posterior_mean_coef1,
-      posterior_mean_coef2, log_betas;
+      posterior_mean_coef2, log_betas, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod;
   // what the model predicts (gd ModelMeanType / ModelVarType as create_diffusion sets them, diffusion/__init__.py:32-45)
   int mean_type = 0;   // 0 EPSILON, 1 START_X (predict_xstart=True)
   int var_type = 0;    // 0 LEARNED_RANGE (learn_sigma=True), 1 FIXED_LARGE, 2 FIXED_SMALL (learn_sigma=False [, sigma_small])
+  // fp32 copies of the tables on ONE device for the batched-timestep kernels (q_sample / training losses), built lazily:
+  // [LATTE_NUM_DEV_TABLES][num_timesteps] = from_numpy(arr).float() of gaussian_diffusion.py:869-881
+  mutable float* dev_tables = nullptr;
+  mutable int dev_tables_device = -1;
 };
+enum DevTable : int { DT_SQRT_AC = 0, DT_SQRT_1MAC, DT_COEF1, DT_COEF2, DT_POST_LOGVAR, DT_LOG_BETAS, DT_SQRT_RECIP, DT_SQRT_RECIPM1,
+                      DT_FIXED_LOGVAR, LATTE_NUM_DEV_TABLES };
 
 namespace latte {
 
@@ -181,5 +187,17 @@ int launch_sampler_update(const SamplerCoefs& c, const float* x, const float* mo
                           int batch, int frames, int channels, int hw, int raw_cfg, float* sample_out,
                           float* x0_out, hipStream_t st, const float* x0_in = nullptr, const float* grad = nullptr,
                           int predict_only = 0);
+
+// ---- batched-timestep kernels of the training path (gaussian_diffusion.py:216-229 q_sample, :686-795 training_losses)
+int launch_q_sample(const float* tables, int n_steps, const float* x_start, const float* noise, const int64_t* t, int batch,
+                    size_t per_sample, float* x_t, hipStream_t st);
+// per-sample mse = mean((target - pred)^2), vb = (t == 0 ? decoder NLL : KL) in bits; partial: [batch][blocks][2] scratch
+int launch_training_terms(const float* tables, int n_steps, int mean_type, int var_type, const float* x_start, const float* x_t,
+                          const float* noise, const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw,
+                          float* partial, int blocks_per_sample, float* mse, float* vb, hipStream_t st);
+int training_terms_blocks(size_t per_sample);
+// loss = kl_only ? scale * vb : mse (+ scale * vb when has_vb); mse_out / vb_out may be nullptr
+int launch_training_combine(const float* mse, const float* vb, int has_vb, int kl_only, float vb_scale, int batch, float* mse_out,
+                            float* vb_out, float* loss_out, hipStream_t st);
 
 }  // namespace latte

@@ -673,6 +673,89 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
   return LATTE_OK;
 }
 
+// fp32 device copies of the schedule tables for the batched-timestep kernels (one device per schedule object)
+static int schedule_device_tables(const latte_schedule_t* s, const float** out, hipStream_t st) {
+  int dev = 0;
+  LATTE_HIP(hipGetDevice(&dev));
+  const int n = s->num_timesteps;
+  if (s->dev_tables && s->dev_tables_device == dev) {
+    *out = s->dev_tables;
+    return LATTE_OK;
+  }
+  if (n < 2) return fail(LATTE_ERR_INVALID, "training: needs >= 2 timesteps (posterior_log_variance_clipped)");
+  if (s->dev_tables) {
+    (void)hipFree(s->dev_tables);
+    s->dev_tables = nullptr;
+  }
+  std::vector<float> h((size_t)LATTE_NUM_DEV_TABLES * n);
+  auto put = [&](int which, const std::vector<double>& v) {
+    for (int i = 0; i < n; ++i) h[(size_t)which * n + i] = (float)v[i];
+  };
+  put(DT_SQRT_AC, s->sqrt_alphas_cumprod);
+  put(DT_SQRT_1MAC, s->sqrt_one_minus_alphas_cumprod);
+  put(DT_COEF1, s->posterior_mean_coef1);
+  put(DT_COEF2, s->posterior_mean_coef2);
+  put(DT_POST_LOGVAR, s->posterior_log_variance_clipped);
+  put(DT_LOG_BETAS, s->log_betas);
+  put(DT_SQRT_RECIP, s->sqrt_recip_alphas_cumprod);
+  put(DT_SQRT_RECIPM1, s->sqrt_recipm1_alphas_cumprod);
+  for (int i = 0; i < n; ++i)   // gd:298-313: FIXED_LARGE = log(append(posterior_variance[1], betas[1:])), else the clipped posterior
+    h[(size_t)DT_FIXED_LOGVAR * n + i] = s->var_type == 1 ? (float)std::log(i == 0 ? s->posterior_variance[1] : s->betas[i])
+                                                          : (float)s->posterior_log_variance_clipped[i];
+  float* d = nullptr;
+  LATTE_HIP(hipMalloc((void**)&d, h.size() * sizeof(float)));
+  LATTE_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  (void)st;
+  s->dev_tables = d;
+  s->dev_tables_device = dev;
+  *out = d;
+  return LATTE_OK;
+}
+
+int latte_q_sample(const latte_schedule_t* s, const float* x_start, const float* noise, const int64_t* t, int batch,
+                   int64_t numel_per_sample, float* x_t, void* stream) {
+  if (!s || !x_start || !noise || !t || !x_t || batch <= 0 || numel_per_sample <= 0)
+    return fail(LATTE_ERR_INVALID, "q_sample: bad arguments");
+  const float* tab = nullptr;
+  int rc = schedule_device_tables(s, &tab, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_q_sample(tab, s->num_timesteps, x_start, noise, t, batch, (size_t)numel_per_sample, x_t, (hipStream_t)stream);
+}
+
+int latte_training_losses(const latte_schedule_t* s, int loss_type, const float* x_start, const float* x_t, const float* noise,
+                          const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw, float* workspace,
+                          int64_t workspace_floats, float* mse_out, float* vb_out, float* loss_out, void* stream) {
+  if (!s || !x_start || !x_t || !noise || !model_out || !t || !workspace || !loss_out || batch <= 0)
+    return fail(LATTE_ERR_INVALID, "training_losses: bad arguments");
+  if (loss_type < 0 || loss_type > 3) return fail(LATTE_ERR_INVALID, "training_losses: loss_type must be 0 MSE, 1 RESCALED_MSE, 2 KL, 3 RESCALED_KL");
+  const size_t per = (size_t)frames * channels * hw;
+  const int blocks = training_terms_blocks(per);
+  const int64_t need = (int64_t)batch * blocks * 2 + 2 * (int64_t)batch;
+  if (workspace_floats < need)
+    return fail(LATTE_ERR_INVALID, "training_losses: workspace too small (latte_training_workspace_floats)");
+  const float* tab = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = schedule_device_tables(s, &tab, st);
+  if (rc) return rc;
+  float* partial = workspace;
+  float* mse = workspace + (size_t)batch * blocks * 2;
+  float* vb = mse + batch;
+  if ((rc = launch_training_terms(tab, s->num_timesteps, s->mean_type, s->var_type, x_start, x_t, noise, model_out, t, batch, frames,
+                                  channels, hw, partial, blocks, mse, vb, st))) return rc;
+  // gd:741-793: which terms exist and how they are scaled
+  const bool kl = loss_type >= 2;
+  const bool has_vb = kl || s->var_type == 0;
+  float vb_scale = 1.0f;
+  if (loss_type == 3) vb_scale = (float)s->num_timesteps;                       // RESCALED_KL, gd:751-752
+  if (loss_type == 1) vb_scale = (float)(s->num_timesteps / 1000.0);            // RESCALED_MSE, gd:771-774
+  return launch_training_combine(mse, vb, has_vb ? 1 : 0, kl ? 1 : 0, vb_scale, batch, mse_out, vb_out, loss_out, st);
+}
+
+int64_t latte_training_workspace_floats(int batch, int64_t numel_per_sample) {
+  if (batch <= 0 || numel_per_sample <= 0) return 0;
+  return (int64_t)batch * training_terms_blocks((size_t)numel_per_sample) * 2 + 2 * (int64_t)batch;
+}
+
 int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
                           float* ms_out, int* launches_out, int n, void* stream) {
   if (!e || !ms_out || !launches_out || n < LATTE_NUM_KERNEL_CLASSES) return fail(LATTE_ERR_INVALID, "profile_forward: bad arguments");

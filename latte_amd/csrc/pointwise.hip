@@ -33,7 +33,9 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
-// One wave per token row; lane owns float2 chunks {lane + 64 c}.  Two-pass statistics in registers.
+// One wave per token row; lane owns the 16-byte chunks {lane + 64 c} of the row (float4 loads, 8-byte half stores: the
+// widest accesses the row length allows -- D / 4 chunks, the last group of 64 only half populated when D / 128 is odd).
+// Two-pass statistics in registers.
 template <int NCH, int DT, bool ADD_TE>
 __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restrict__ x_in, float* x_rw,
                                                           half_t* __restrict__ y, const float* __restrict__ shift,
@@ -41,46 +43,57 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
                                                           int rows_per_sample, const float* __restrict__ te, int T,
                                                           int F) {
   constexpr int D = NCH * 128;
+  constexpr int NT = NCH * 32;            // float4 chunks per row
+  constexpr int NQ = (NT + 63) / 64;      // chunk groups per lane
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float2* xr = (const float2*)(x_in + (size_t)row * D);
-  float2 v[NCH];
+  const float4* xr = (const float4*)(x_in + (size_t)row * D);
+  auto has = [&](int c) -> bool { return (c + 1) * 64 <= NT || c * 64 + lane < NT; };
+  float4 v[NQ];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) v[c] = xr[c * 64 + lane];
+  for (int c = 0; c < NQ; ++c) v[c] = has(c) ? xr[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (ADD_TE) {
     const int f = (row / T) % F;
-    const float2* tr = (const float2*)(te + (size_t)f * D);
-    float2* xw = (float2*)(x_rw + (size_t)row * D);
+    const float4* tr = (const float4*)(te + (size_t)f * D);
+    float4* xw = (float4*)(x_rw + (size_t)row * D);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const float2 e = tr[c * 64 + lane];
-      v[c].x += e.x;
-      v[c].y += e.y;
-      xw[c * 64 + lane] = v[c];
+    for (int c = 0; c < NQ; ++c) {
+      if (has(c)) {
+        const float4 e = tr[c * 64 + lane];
+        v[c].x += e.x; v[c].y += e.y; v[c].z += e.z; v[c].w += e.w;
+        xw[c * 64 + lane] = v[c];
+      }
     }
   }
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) s += v[c].x + v[c].y;
+  for (int c = 0; c < NQ; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);     // absent chunks hold zeros
   const float mean = wave_sum(s) * (1.0f / D);
   float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float a = v[c].x - mean, b = v[c].y - mean;
-    q += a * a + b * b;
+  for (int c = 0; c < NQ; ++c) {
+    if (has(c)) {
+      const float a = v[c].x - mean, b = v[c].y - mean, d = v[c].z - mean, e = v[c].w - mean;
+      q += (a * a + b * b) + (d * d + e * e);
+    }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
   const int smp = row / rows_per_sample;
-  const float2* sh = (const float2*)(shift + (size_t)smp * mod_stride);
-  const float2* sc = (const float2*)(scale + (size_t)smp * mod_stride);
-  unsigned int* yr = (unsigned int*)(y + (size_t)row * D);
+  const float4* sh = (const float4*)(shift + (size_t)smp * mod_stride);
+  const float4* sc = (const float4*)(scale + (size_t)smp * mod_stride);
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  u32x2_t* yr = (u32x2_t*)(y + (size_t)row * D);
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const float2 a = sh[c * 64 + lane], b = sc[c * 64 + lane];
-    const float o0 = (v[c].x - mean) * rstd * (1.0f + b.x) + a.x;
-    const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
-    yr[c * 64 + lane] = pack2<DT>(o0, o1);
+  for (int c = 0; c < NQ; ++c) {
+    if (has(c)) {
+      const float4 a = sh[c * 64 + lane], b = sc[c * 64 + lane];
+      const float o0 = (v[c].x - mean) * rstd * (1.0f + b.x) + a.x;
+      const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
+      const float o2 = (v[c].z - mean) * rstd * (1.0f + b.z) + a.z;
+      const float o3 = (v[c].w - mean) * rstd * (1.0f + b.w) + a.w;
+      yr[c * 64 + lane] = (u32x2_t){pack2<DT>(o0, o1), pack2<DT>(o2, o3)};
+    }
   }
 }
 
@@ -428,6 +441,129 @@ __global__ void sampler_update_kernel(SamplerCoefs c, const float* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Training path, forward evaluation (gaussian_diffusion.py:216-229 q_sample; :686-717 _vb_terms_bpd; :719-795
+// training_losses; diffusion_utils.py:10-88).  One timestep PER SAMPLE: coefficients are gathered from the fp32 device
+// copies of the fp64 tables (= _extract_into_tensor's from_numpy(arr)[t].float()), the arithmetic is the reference's fp32
+// tensor arithmetic op for op (no FMA contraction).
+__global__ void q_sample_kernel(const float* __restrict__ tab, int n_steps, const float* __restrict__ x0,
+                                const float* __restrict__ noise, const int64_t* __restrict__ t, size_t per_sample,
+                                size_t total, float* __restrict__ xt) {
+#pragma clang fp contract(off)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ti = (int)t[i / per_sample];
+    const float a = tab[DT_SQRT_AC * n_steps + ti], b = tab[DT_SQRT_1MAC * n_steps + ti];
+    xt[i] = a * x0[i] + b * noise[i];                                  // gd:226-229
+  }
+}
+
+__device__ __forceinline__ float approx_std_normal_cdf(float x) {      // diffusion_utils.py:39-44
+#pragma clang fp contract(off)
+  const float c = 0.7978845608028654f;                                 // np.sqrt(2.0 / np.pi) as fp32
+  return 0.5f * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
+}
+
+constexpr int TT_THREADS = 256;
+__global__ void __launch_bounds__(TT_THREADS) training_terms_kernel(const float* __restrict__ tab, int n_steps, int mean_type,
+                                                                    int var_type, const float* __restrict__ x0,
+                                                                    const float* __restrict__ xt, const float* __restrict__ noise,
+                                                                    const float* __restrict__ mo, const int64_t* __restrict__ t,
+                                                                    int frames, int C, int hw, float* __restrict__ partial) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y;
+  const int ti = (int)t[b];
+  const float coef1 = tab[DT_COEF1 * n_steps + ti], coef2 = tab[DT_COEF2 * n_steps + ti];
+  const float plv = tab[DT_POST_LOGVAR * n_steps + ti], lb = tab[DT_LOG_BETAS * n_steps + ti];
+  const float srec = tab[DT_SQRT_RECIP * n_steps + ti], srecm1 = tab[DT_SQRT_RECIPM1 * n_steps + ti];
+  const float flv = tab[DT_FIXED_LOGVAR * n_steps + ti];
+  const size_t chw = (size_t)C * hw, per = (size_t)frames * chw;
+  const int Cm = var_type == 0 ? 2 * C : C;
+  float s_mse = 0.f, s_vb = 0.f;
+  for (size_t e = (size_t)blockIdx.x * TT_THREADS + threadIdx.x; e < per; e += (size_t)gridDim.x * TT_THREADS) {
+    const size_t f = e / chw, r = e % chw;
+    const size_t i = (size_t)b * per + e;
+    const size_t o = (((size_t)b * frames + f) * Cm) * hw + r;
+    const float pred = mo[o];
+    const float xs = x0[i], xv = xt[i];
+    const float target = mean_type == 1 ? xs : noise[i];               // gd:776-782
+    const float d = target - pred;
+    s_mse += d * d;
+    // q(x_{t-1} | x_t, x_0), gd:232-241
+    const float true_mean = coef1 * xs + coef2 * xv;
+    // p_mean_variance with clip_denoised = False, gd:289-336
+    float lv;
+    if (var_type == 0) {
+      const float v = mo[o + chw];
+      const float frac = (v + 1.0f) / 2.0f;
+      lv = frac * lb + (1.0f - frac) * plv;
+    } else {
+      lv = flv;
+    }
+    const float x0p = mean_type == 1 ? pred : srec * xv - srecm1 * pred;
+    const float mean = coef1 * x0p + coef2 * xv;
+    float term;
+    if (ti != 0) {                                                     // KL(q || p), diffusion_utils.py:29-36
+      const float dm = true_mean - mean;
+      term = 0.5f * (-1.0f + lv - plv + expf(plv - lv) + (dm * dm) * expf(-lv));
+    } else {                                                           // decoder NLL, diffusion_utils.py:62-88
+      const float centered = xs - mean;
+      const float inv_stdv = expf(-(0.5f * lv));
+      const float cdf_plus = approx_std_normal_cdf(inv_stdv * (centered + 0.00392156862745098f));
+      const float cdf_min = approx_std_normal_cdf(inv_stdv * (centered - 0.00392156862745098f));
+      const float log_cdf_plus = logf(fmaxf(cdf_plus, 1e-12f));
+      const float log_one_minus = logf(fmaxf(1.0f - cdf_min, 1e-12f));
+      const float log_delta = logf(fmaxf(cdf_plus - cdf_min, 1e-12f));
+      const float lp = xs < -0.999f ? log_cdf_plus : (xs > 0.999f ? log_one_minus : log_delta);
+      term = -lp;
+    }
+    s_vb += term;
+  }
+  // deterministic block reduction (fixed tree), then one slot per (sample, block)
+  __shared__ float red[2][TT_THREADS];
+  red[0][threadIdx.x] = s_mse;
+  red[1][threadIdx.x] = s_vb;
+  __syncthreads();
+  for (int w = TT_THREADS / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2] = red[0][0];
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = red[1][0];
+  }
+}
+
+__global__ void training_finalize_kernel(const float* __restrict__ partial, int blocks, double per_sample, float* __restrict__ mse,
+                                         float* __restrict__ vb) {
+  const int b = blockIdx.x;
+  double a = 0.0, c = 0.0;
+  for (int k = 0; k < blocks; ++k) {
+    a += (double)partial[((size_t)b * blocks + k) * 2];
+    c += (double)partial[((size_t)b * blocks + k) * 2 + 1];
+  }
+  mse[b] = (float)(a / per_sample);                                    // mean_flat
+  vb[b] = (float)(c / per_sample) / 0.6931471805599453f;               // mean_flat(.) / np.log(2.0), fp32 division
+}
+
+__global__ void training_combine_kernel(const float* __restrict__ mse, const float* __restrict__ vb, int has_vb, int kl_only,
+                                        float vb_scale, int batch, float* mse_out, float* vb_out, float* loss_out) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const float v = has_vb ? vb[b] * vb_scale : 0.0f;                    // gd:751-752 / :771-774 (no scaling = * 1)
+  if (kl_only) {
+    loss_out[b] = v;
+    return;
+  }
+  if (mse_out) mse_out[b] = mse[b];
+  if (vb_out && has_vb) vb_out[b] = v;
+  loss_out[b] = has_vb ? mse[b] + v : mse[b];                          // gd:788-791
+}
+
 template <int DT>
 __global__ void convert_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -516,6 +652,39 @@ inline int grid_for(size_t n, int block) {
     case 9: MACRO(9); break;                                                            \
     default: return fail(LATTE_ERR_INVALID, "hidden_size must be 128*{1,2,3,4,6,8,9}"); \
   }
+
+int launch_q_sample(const float* tables, int n_steps, const float* x_start, const float* noise, const int64_t* t, int batch,
+                    size_t per_sample, float* x_t, hipStream_t st) {
+  const size_t total = (size_t)batch * per_sample;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, tables, n_steps, x_start, noise, t, per_sample,
+                     total, x_t);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_training_combine(const float* mse, const float* vb, int has_vb, int kl_only, float vb_scale, int batch, float* mse_out,
+                            float* vb_out, float* loss_out, hipStream_t st) {
+  hipLaunchKernelGGL(training_combine_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, mse, vb, has_vb, kl_only, vb_scale, batch,
+                     mse_out, vb_out, loss_out);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int training_terms_blocks(size_t per_sample) {
+  size_t b = (per_sample + (size_t)TT_THREADS * 8 - 1) / ((size_t)TT_THREADS * 8);
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+int launch_training_terms(const float* tables, int n_steps, int mean_type, int var_type, const float* x_start, const float* x_t,
+                          const float* noise, const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw,
+                          float* partial, int blocks_per_sample, float* mse, float* vb, hipStream_t st) {
+  hipLaunchKernelGGL(training_terms_kernel, dim3(blocks_per_sample, batch), dim3(TT_THREADS), 0, st, tables, n_steps, mean_type,
+                     var_type, x_start, x_t, noise, model_out, t, frames, channels, hw, partial);
+  hipLaunchKernelGGL(training_finalize_kernel, dim3(batch), dim3(1), 0, st, partial, blocks_per_sample,
+                     (double)frames * channels * hw, mse, vb);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
 
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T, int F,

@@ -148,6 +148,8 @@ int latte_schedule_create(int diffusion_steps, const char* timestep_respacing, c
   s->posterior_mean_coef1.resize(n);
   s->posterior_mean_coef2.resize(n);
   s->log_betas.resize(n);
+  s->sqrt_alphas_cumprod.resize(n);
+  s->sqrt_one_minus_alphas_cumprod.resize(n);
   for (int i = 0; i < n; ++i) {
     const double a = s->alphas_cumprod[i], ap = s->alphas_cumprod_prev[i];
     s->sqrt_recip_alphas_cumprod[i] = std::sqrt(1.0 / a);
@@ -156,6 +158,8 @@ int latte_schedule_create(int diffusion_steps, const char* timestep_respacing, c
     s->posterior_mean_coef1[i] = B[i] * std::sqrt(ap) / (1.0 - a);
     s->posterior_mean_coef2[i] = (1.0 - ap) * std::sqrt(1.0 - B[i]) / (1.0 - a);
     s->log_betas[i] = std::log(B[i]);
+    s->sqrt_alphas_cumprod[i] = std::sqrt(a);                // gd:176
+    s->sqrt_one_minus_alphas_cumprod[i] = std::sqrt(1.0 - a);  // gd:177
   }
   if (n > 1) {  // gd:191-193: log of [pv[1], pv[1:]]
     s->posterior_log_variance_clipped.resize(n);
@@ -173,7 +177,10 @@ int latte_schedule_set_model_types(latte_schedule_t* s, int predict_xstart, int 
   return LATTE_OK;
 }
 
-void latte_schedule_destroy(latte_schedule_t* s) { delete s; }
+void latte_schedule_destroy(latte_schedule_t* s) {
+  if (s && s->dev_tables) (void)hipFree(s->dev_tables);
+  delete s;
+}
 
 int latte_schedule_num_timesteps(const latte_schedule_t* s) { return s ? s->num_timesteps : -1; }
 
@@ -197,6 +204,8 @@ int latte_schedule_table(const latte_schedule_t* s, const char* name, double* ou
   else if (k == "posterior_mean_coef1") v = &s->posterior_mean_coef1;
   else if (k == "posterior_mean_coef2") v = &s->posterior_mean_coef2;
   else if (k == "log_betas") v = &s->log_betas;
+  else if (k == "sqrt_alphas_cumprod") v = &s->sqrt_alphas_cumprod;
+  else if (k == "sqrt_one_minus_alphas_cumprod") v = &s->sqrt_one_minus_alphas_cumprod;
   else return latte::fail(LATTE_ERR_INVALID, "schedule_table: unknown table '" + k + "'");
   if ((int)v->size() != n) return latte::fail(LATTE_ERR_INVALID, "schedule_table: size mismatch for '" + k + "'");
   std::memcpy(out, v->data(), sizeof(double) * n);

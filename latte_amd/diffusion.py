@@ -19,7 +19,9 @@ from .models import Latte
 
 _TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
            "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
-           "posterior_mean_coef1", "posterior_mean_coef2", "log_betas"]
+           "posterior_mean_coef1", "posterior_mean_coef2", "log_betas", "sqrt_alphas_cumprod",
+           "sqrt_one_minus_alphas_cumprod"]
+_LOSS = {"mse": 0, "rescaled_mse": 1, "kl": 2, "rescaled_kl": 3}
 _METHOD = {"ddpm": 0, "ddim": 1}
 
 
@@ -30,7 +32,10 @@ class SpacedDiffusion:
     SEGMENT_BYTES = 256 << 20   # per-step noise / trail buffers of one fused-loop segment (see _loop)
 
     def __init__(self, timestep_respacing, noise_schedule="linear", diffusion_steps=1000, predict_xstart=False,
-                 learn_sigma=True, sigma_small=False):
+                 learn_sigma=True, sigma_small=False, loss_type="mse"):
+        if loss_type not in _LOSS:
+            raise LatteError(f"loss_type must be one of {sorted(_LOSS)}")
+        self.loss_type = loss_type
         lib = load_library()
         h = _lib.c_void()
         if isinstance(timestep_respacing, (list, tuple)):
@@ -232,15 +237,71 @@ class SpacedDiffusion:
             pass
         return final["sample"]
 
-    def training_losses(self, *a, **k):
-        raise LatteError("training_losses is outside the accelerated sampling path (SURVEY.md §8(f) rank 3)")
+    # ------------------------------------------------------------------ training path, forward evaluation
+    def q_sample(self, x_start, t, noise=None):
+        """``GaussianDiffusion.q_sample`` (gd:216-229) with one respaced timestep per sample, on the engine."""
+        _lib.require_gpu()
+        x0 = x_start.float().contiguous()
+        if noise is None:
+            noise = torch.randn_like(x0)
+        if noise.shape != x0.shape:
+            raise AssertionError("noise.shape == x_start.shape")                      # gd:225
+        nz = noise.to(device=x0.device, dtype=torch.float32).contiguous()
+        t64 = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        if t64.shape != (x0.shape[0],) or int(t64.min()) < 0 or int(t64.max()) >= self.num_timesteps:
+            raise IndexError("t must hold one timestep index in [0, num_timesteps) per sample")
+        out = torch.empty_like(x0)
+        with torch.cuda.device(x0.device):
+            check(load_library().latte_q_sample(self._h, ptr(x0), ptr(nz), ptr(t64), x0.shape[0], x0[0].numel(), ptr(out),
+                                                stream_ptr()))
+        return out
+
+    def training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
+        """``SpacedDiffusion.training_losses`` (rs:95-98 -> gd:719-795) as called by train.py:224-226: the VALUES of the
+        loss terms -- {"loss", "mse", "vb"} of shape [N] for the MSE loss types, {"loss"} for the KL ones -- computed by the
+        engine from ``model(x_t, timestep_map[t], **model_kwargs)``.  Forward evaluation only: nothing here builds an
+        autograd graph, the backward kernels are the next slice of SURVEY.md section 8(f) rank 3."""
+        _lib.require_gpu()
+        model_kwargs = model_kwargs or {}
+        x0 = x_start.float().contiguous()
+        if x0.dim() != 5:
+            raise LatteError("x_start must be [N, F, C, H, W]")
+        if noise is None:
+            noise = torch.randn_like(x0)                                              # gd:732-733
+        nz = noise.to(device=x0.device, dtype=torch.float32).contiguous()
+        t64 = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        x_t = self.q_sample(x0, t64, nz)
+        tmap = torch.tensor(self.timestep_map, device=x0.device, dtype=torch.int64)
+        out = model(x_t, tmap[t64], **model_kwargs)                                  # rs:125-130: ORIGINAL timesteps
+        if isinstance(out, tuple):
+            out = out[0]
+        B, F, C = x0.shape[:3]
+        want = (B, F, C * 2 if self.learn_sigma else C, *x0.shape[3:])               # gd:762 / :784
+        if tuple(out.shape) != want:
+            raise AssertionError(f"model output shape {tuple(out.shape)} != {want}")
+        mo = out.detach().float().contiguous()
+        hw = int(np.prod(x0.shape[3:]))
+        lib = load_library()
+        nws = int(lib.latte_training_workspace_floats(B, x0[0].numel()))
+        ws = torch.empty(nws, device=x0.device, dtype=torch.float32)
+        mse, vb, loss = (torch.empty(B, device=x0.device, dtype=torch.float32) for _ in range(3))
+        with torch.cuda.device(x0.device):
+            check(lib.latte_training_losses(self._h, _LOSS[self.loss_type], ptr(x0), ptr(x_t), ptr(nz), ptr(mo), ptr(t64), B, F, C,
+                                            hw, ptr(ws), nws, ptr(mse), ptr(vb), ptr(loss), stream_ptr()))
+        if self.loss_type in ("kl", "rescaled_kl"):
+            return {"loss": loss}
+        terms = {"mse": mse, "loss": loss}
+        if self.learn_sigma:
+            terms["vb"] = vb
+        return terms
 
 
 def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
                      predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000):
-    """``diffusion.create_diffusion`` (diffusion/__init__.py:10-47).  ``use_kl`` / ``rescale_learned_sigmas`` only select
-    the training loss (gd LossType) and do not touch sampling."""
+    """``diffusion.create_diffusion`` (diffusion/__init__.py:10-47).  ``use_kl`` / ``rescale_learned_sigmas`` select the
+    training loss (LossType RESCALED_KL / RESCALED_MSE / MSE, :22-27) and do not touch sampling."""
     if timestep_respacing is None or timestep_respacing == "":
         timestep_respacing = [diffusion_steps]
+    loss_type = "rescaled_kl" if use_kl else ("rescaled_mse" if rescale_learned_sigmas else "mse")
     return SpacedDiffusion(timestep_respacing, noise_schedule=noise_schedule, diffusion_steps=diffusion_steps,
-                           predict_xstart=predict_xstart, learn_sigma=learn_sigma, sigma_small=sigma_small)
+                           predict_xstart=predict_xstart, learn_sigma=learn_sigma, sigma_small=sigma_small, loss_type=loss_type)

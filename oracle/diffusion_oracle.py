@@ -84,6 +84,8 @@ class Schedule:
         self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
         self.log_betas = np.log(betas)                                           # gd:293
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)                  # gd:176 (q_sample, training)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)  # gd:177
 
 
 def _coef(arr: np.ndarray, i: int) -> torch.Tensor:
@@ -173,6 +175,99 @@ def sample_loop(s: Schedule, model_fn, x: torch.Tensor, method="ddim", eta=0.0, 
         if progressive:
             trail.append(r)
     return (x, trail) if progressive else x
+
+
+# ----------------------------------------------------------------------------- training losses
+def _coef_t(arr: np.ndarray, t: torch.Tensor, ndim: int) -> torch.Tensor:
+    """gd:869-881 for a BATCH of timesteps: ``from_numpy(arr)[t].float()`` broadcast over the trailing dims."""
+    res = torch.from_numpy(np.asarray(arr))[t].float()
+    while res.dim() < ndim:
+        res = res[..., None]
+    return res
+
+
+def _mean_flat(x):
+    return x.mean(dim=list(range(1, x.dim())))                                   # gd:20-24
+
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """diffusion_utils.py:10-36."""
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def _approx_cdf(x):
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))   # diffusion_utils.py:39-44
+
+
+def discretized_gaussian_log_likelihood(x, means, log_scales):
+    """diffusion_utils.py:62-88."""
+    centered = x - means
+    inv_stdv = torch.exp(-log_scales)
+    cdf_plus = _approx_cdf(inv_stdv * (centered + 1.0 / 255.0))
+    cdf_min = _approx_cdf(inv_stdv * (centered - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    return torch.where(x < -0.999, log_cdf_plus,
+                       torch.where(x > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
+
+
+def q_sample(s: Schedule, x_start, t, noise):
+    """gd:216-229."""
+    return (_coef_t(s.sqrt_alphas_cumprod, t, x_start.dim()) * x_start
+            + _coef_t(s.sqrt_one_minus_alphas_cumprod, t, x_start.dim()) * noise)
+
+
+def _vb_terms_bpd(s: Schedule, model_out, x_start, x_t, t):
+    """gd:686-717 with clip_denoised=False (the only way training_losses calls it): per-sample KL / decoder NLL in bits."""
+    nd = x_start.dim()
+    true_mean = _coef_t(s.posterior_mean_coef1, t, nd) * x_start + _coef_t(s.posterior_mean_coef2, t, nd) * x_t   # gd:232-241
+    true_logvar = _coef_t(s.posterior_log_variance_clipped, t, nd)
+    C = x_t.shape[2]
+    if s.var_type == "learned_range":
+        eps, v = torch.split(model_out, C, dim=2)
+        min_log, max_log = _coef_t(s.posterior_log_variance_clipped, t, nd), _coef_t(s.log_betas, t, nd)
+        frac = (v + 1) / 2
+        log_var = frac * max_log + (1 - frac) * min_log
+    else:
+        eps = model_out
+        table = (np.log(np.append(s.posterior_variance[1], s.betas[1:])) if s.var_type == "fixed_large"
+                 else s.posterior_log_variance_clipped)
+        log_var = _coef_t(table, t, nd) + torch.zeros_like(x_t)
+    if s.predict_xstart:
+        x0 = eps
+    else:
+        x0 = _coef_t(s.sqrt_recip_alphas_cumprod, t, nd) * x_t - _coef_t(s.sqrt_recipm1_alphas_cumprod, t, nd) * eps
+    mean = _coef_t(s.posterior_mean_coef1, t, nd) * x0 + _coef_t(s.posterior_mean_coef2, t, nd) * x_t
+    kl = _mean_flat(normal_kl(true_mean, true_logvar, mean, log_var)) / np.log(2.0)
+    nll = _mean_flat(-discretized_gaussian_log_likelihood(x_start, mean, 0.5 * log_var)) / np.log(2.0)
+    return torch.where(t == 0, nll, kl)
+
+
+def training_losses(s: Schedule, model_fn, x_start, t, noise, loss_type="mse"):
+    """gd:719-795 through rs:95-98 (the model sees ORIGINAL timesteps).  ``t`` = respaced indices int64[N];
+    ``loss_type`` in {"mse", "rescaled_mse", "kl", "rescaled_kl"} (init:22-27: use_kl -> rescaled_kl,
+    rescale_learned_sigmas -> rescaled_mse, else mse).  -> dict of [N] tensors."""
+    x_t = q_sample(s, x_start, t, noise)
+    t_orig = torch.tensor(s.timestep_map, dtype=torch.int64)[t]
+    model_out = model_fn(x_t, t_orig)
+    terms = {}
+    if loss_type in ("kl", "rescaled_kl"):
+        terms["loss"] = _vb_terms_bpd(s, model_out, x_start, x_t, t)
+        if loss_type == "rescaled_kl":
+            terms["loss"] = terms["loss"] * s.num_timesteps
+        return terms
+    C = x_t.shape[2]
+    pred = model_out
+    if s.var_type == "learned_range":
+        pred = model_out[:, :, :C]
+        terms["vb"] = _vb_terms_bpd(s, model_out, x_start, x_t, t)           # mean prediction detached: forward value equal
+        if loss_type == "rescaled_mse":
+            terms["vb"] = terms["vb"] * (s.num_timesteps / 1000.0)
+    target = x_start if s.predict_xstart else noise
+    terms["mse"] = _mean_flat((target - pred) ** 2)
+    terms["loss"] = terms["mse"] + terms["vb"] if "vb" in terms else terms["mse"]
+    return terms
 
 
 # ----------------------------------------------------------------------------- hook fixtures

@@ -178,6 +178,39 @@ def sampler_types(rd):
     np.savez_compressed(os.path.join(OUT, "sampler_types.npz"), **out)
 
 
+TRAINING_CASES = [   # (tag, create_diffusion kwargs, respacing): the loss types / model types of init:10-46
+    ("mse_learned", dict(), ""),                                           # train.py:100: create_diffusion(timestep_respacing="")
+    ("rescaled_mse_learned_100", dict(rescale_learned_sigmas=True), "100"),
+    ("rescaled_kl_learned", dict(use_kl=True), ""),
+    ("mse_fixed_large", dict(learn_sigma=False), ""),
+    ("mse_xstart_learned", dict(predict_xstart=True), "250"),
+]
+
+
+def training_inputs(n_steps):
+    """Inputs of the training-loss fixtures: data partly outside +-0.999 (both tail branches of the discretized likelihood),
+    t with the decoder-NLL case t == 0, the last step and interior steps."""
+    g = torch.Generator("cpu").manual_seed(4242)
+    x0 = (torch.randn(5, 4, 4, 8, 8, generator=g) * 0.6).clamp(-1.0, 1.0)
+    noise = torch.randn(5, 4, 4, 8, 8, generator=g)
+    t = torch.tensor([0, n_steps - 1, n_steps // 2, 1, (2 * n_steps) // 3], dtype=torch.int64)
+    return x0, noise, t
+
+
+def training(rd):
+    """GaussianDiffusion.training_losses (gd:719-795) run by the reference on the synthetic model."""
+    out = {}
+    for tag, kw, spec in TRAINING_CASES:
+        d = rd.create_diffusion(spec, **kw)
+        x0, noise, t = training_inputs(d.num_timesteps)
+        oc = 8 if kw.get("learn_sigma", True) else 4
+        terms = d.training_losses(lambda x, tt, **k: dor.synthetic_model(x, tt, oc), x0, t, model_kwargs={}, noise=noise)
+        for k, v in terms.items():
+            out[f"{tag}::{k}"] = v.numpy()
+        out[f"{tag}::x_t"] = d.q_sample(x0, t, noise=noise).numpy()
+    np.savez_compressed(os.path.join(OUT, "training_losses.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rl, rd = load_reference_latte(), load_reference_diffusion()
@@ -186,6 +219,7 @@ def main():
     tiny_model(rl, rd, "tiny_uncond", TINY4, use_cfg=False, seed=200)
     tiny_model(rl, rd, "tiny_textcond", TINY78, use_cfg=True, seed=300)
     sampler_types(rd)
+    training(rd)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

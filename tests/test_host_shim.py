@@ -49,9 +49,12 @@ def test_get_models_reads_reference_config_keys(tmp_path):
     assert cfg.ckpt == "x.pt" and cfg.cfg_scale == 7.0 and cfg.sample_method == "ddpm"
     m = latte_amd.get_models(cfg)
     assert m.input_size == 8 and m.extras == 2 and m.num_frames == 4
-    cfg.model = "LatteT2V"
+    cfg.model = "LatteIMG-XL/2"                                         # joint image-video training variant: not in the engine
     with pytest.raises(latte_amd.LatteError):
         latte_amd.get_models(cfg)
+    cfg.model = "LatteT2V"                                              # dispatches to from_pretrained (tests/test_checkpoints.py)
+    with pytest.raises(AttributeError):
+        latte_amd.get_models(cfg)                                       # the reference's config needs pretrained_model_path too
 
 
 def test_create_diffusion_surface():

@@ -284,7 +284,7 @@ def dma_probe():
 def gemm_in_model():
     """Per-GEMM tile variants measured INSIDE the XL/2 forward (cache state of the real pipeline), B = 8 and 2."""
     from latte_amd.models import Latte_models
-    for B in (8, 2):
+    for B in [int(v) for v in os.environ.get("LATTE_FL_B", "8,2").split(",")]:
         m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
         with torch.no_grad():
             for n_, p_ in m.named_parameters():
