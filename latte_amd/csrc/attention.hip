@@ -439,7 +439,8 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
   constexpr int DF = (HD + 15) / 16;
   constexpr int NCH = HD / 8;
-  __shared__ __attribute__((aligned(16))) char lds[4 * 17 * PITCH];  // per wave: 16 V rows (+1 row of slack)
+  constexpr int VP = 160;   // row pitch of the V patch: conflict-free for the transpose reads (as in attn_full_kernel)
+  __shared__ __attribute__((aligned(16))) char lds[4 * 17 * VP];  // per wave: 16 V rows (+1 row of slack)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fl = lane & 15, g = lane >> 4;
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   const size_t ld = (size_t)3 * a.D;
   const int tok = min(fl, a.L - 1);
   const half_t* rowp = a.qkv + (size_t)(base + (int64_t)tok * a.row_stride) * ld + (size_t)head * HD;
-  char* v_lds = lds + wave * 17 * PITCH;
+  char* v_lds = lds + wave * 17 * VP;
 
   u32x4 qf[KS], kf[KS];
 #pragma unroll
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
     if (ch < NCH) {
       qf[ks] = *(const u32x4*)(rowp + ch * 8);
       kf[ks] = *(const u32x4*)(rowp + a.D + ch * 8);
-      *(u32x4*)(v_lds + fl * PITCH + ch * 16) = *(const u32x4*)(rowp + 2 * a.D + ch * 8);
+      *(u32x4*)(v_lds + fl * VP + ch * 16) = *(const u32x4*)(rowp + 2 * a.D + ch * 8);
     }
   }
   f32x4 st = {0.f, 0.f, 0.f, 0.f};
@@ -502,10 +503,11 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   half_t* orow = a.out + (size_t)(base + (int64_t)tok * a.row_stride) * a.D + head * HD;
 #pragma unroll
   for (int d = 0; d < DF; ++d) {
-    // V^T fragment: lane = (d index 16 d + fl, keys 4g .. 4g+3): column gather from the row-major patch
-    const half_t* vp = (const half_t*)(v_lds + (4 * g) * PITCH) + 16 * d + fl;
-    const unsigned int e0 = vp[0], e1 = vp[PITCH / 2], e2 = vp[2 * (PITCH / 2)], e3 = vp[3 * (PITCH / 2)];
-    const u32x2 vf = {e0 | (e1 << 16), e2 | (e3 << 16)};
+    // V^T fragment: lane = (d index 16 d + fl, keys 4g .. 4g+3) out of the row-major patch through the hardware transpose
+    // read: lane i of a 16-lane group supplies the address of 4 d-values of key (i >> 2) and receives the 4 keys of
+    // d-column i (one ds_read_b64_tr_b16 instead of four 2-byte reads + packing).  Pad columns (>= HD) of the last
+    // fragment read the next row's first bytes / the slack row: finite, and only feed unused O rows.
+    const u32x2 vf = lds_tr16<DT>(v_lds + (4 * g + (fl >> 2)) * VP + (fl & 3) * 8 + d * 32);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = mfma_k16<DT>(vf, pb, acc);  // O^T[d = 16 d + 4g + r][q = fl]
     const int dd = 16 * d + 4 * g;

@@ -73,8 +73,12 @@ for c, ctrs in acc.items():
         rec["hbm_bytes_per_launch"] = int(2 * ca["FETCH_SIZE"] * 1024 + ca["WRITE_SIZE"] * 1024)
         rec["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / ALG[c], 3)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in ca and "GRBM_GUI_ACTIVE" in ca and ca["GRBM_GUI_ACTIVE"] > 0:
-        # busy cycles summed over the chip's 256 CUs x 4 SIMDs, GRBM_GUI_ACTIVE = elapsed shader-engine clocks
-        rec["mfma_busy_frac_of_simd_cycles"] = round(ca["SQ_VALU_MFMA_BUSY_CYCLES"] / (ca["GRBM_GUI_ACTIVE"] * 256 * 4), 4)
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (16 cycles per v_mfma_f32_16x16x32: it equals
+        # 16 x the launch's MFMA count, checked against 2 M N K / 16384); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        # (value / launch time = 8 x the shader clock), so elapsed cycles per SIMD = GRBM_GUI_ACTIVE / 8
+        rec["mfma_busy_frac_of_simd_cycles"] = round(ca["SQ_VALU_MFMA_BUSY_CYCLES"] / (ca["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+        if rec.get("avg_ns_in_pmc_pass"):
+            rec["shader_clock_ghz_in_pmc_pass"] = round(ca["GRBM_GUI_ACTIVE"] / 8 / rec["avg_ns_in_pmc_pass"], 3)
     if "SQ_WAVE_CYCLES" in ca and ca["SQ_WAVE_CYCLES"] > 0:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in ca:
