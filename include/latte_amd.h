@@ -242,6 +242,23 @@ int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const fl
                       const float* encoder_attention_mask, int batch, int n_text, int enable_temporal_attentions, float* out,
                       void* stream);
 
+/* Chain-level text context: the caption projection, the cross-attention K|V of every spatial block and the mask bias depend on
+ * the text only; latte_t2v_set_text computes them once ([batch, n_text, caption_channels] fp32, mask [batch, n_text] or NULL)
+ * and latte_t2v_forward with encoder_hidden_states == NULL / latte_t2v_guided_ddim_loop reuse them for every step.  Loading
+ * a tensor uninstalls the context; encoder_hidden_states == NULL here uninstalls it too. */
+int latte_t2v_set_text(latte_t2v_t* e, const float* encoder_hidden_states, const float* encoder_attention_mask, int batch,
+                       int n_text, void* stream);
+/* The denoising loop of LattePipeline.__call__ (sample/pipeline_latte.py:700-760) for the classifier-free-guidance case with
+ * a DDIM scheduler at eta = 0, entirely inside the engine: per step the transformer on the guidance pair (the latents are
+ * duplicated inside, :725), noise_pred = uncond + s (text - uncond) (:748-749), the learned-sigma half dropped (:752-753),
+ * and DDIMScheduler.step (x0 = (x - sqrt(1 - a_t) eps) / sqrt(a_t); x' = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps).
+ * x: [samples, C, F, H, W] fp32, updated in place; the installed text context must hold 2 * samples rows ordered
+ * [negative prompts | prompts] (:647).  timesteps / alpha_t / alpha_prev: HOST arrays of n_steps entries (the scheduler's
+ * timesteps and alphas_cumprod at t and at the previous timestep, final_alpha_cumprod for the last step). */
+int latte_t2v_guided_ddim_loop(latte_t2v_t* e, float* x, int samples, int n_steps, const int64_t* timesteps,
+                               const double* alpha_t, const double* alpha_prev, float guidance_scale,
+                               int enable_temporal_attentions, void* stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * Runs ONE denoiser forward eagerly with HIP events around every kernel launch on `stream`,
  * synchronises, and reports per-kernel-class totals.  classes (fixed order):

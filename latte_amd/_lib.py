@@ -76,6 +76,8 @@ PROTOTYPES = {
     "latte_t2v_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
     "latte_t2v_check_weights": (c_int, [c_void]),
     "latte_t2v_forward": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "latte_t2v_set_text": (c_int, [c_void, c_void, c_void, c_int, c_int, c_void]),
+    "latte_t2v_guided_ddim_loop": (c_int, [c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_f32, c_int, c_void]),
     "latte_bench_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_f32), c_void]),
     "latte_vae_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void)]),
     "latte_vae_destroy": (None, [c_void]),

@@ -434,6 +434,200 @@ __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_blocks : L > 256 (the 1024-token spatial attention of Latte-1 / the 512-pixel class-conditional models,
+// latte_t2v.py:804-907).  The attn_full machinery -- LDS-DMA staging of row-major K / V images, pipelined fragment reads,
+// V^T through ds_read_b64_tr_b16, swapped QK^T with the softmax statistics in two cross-lane steps -- applied to 256-key
+// BLOCKS with an online softmax across blocks.  One workgroup = (sequence, head, 128 consecutive queries): a wave owns 32
+// queries (two 16-query MFMA column groups) for the whole key loop, so its output
+// accumulators and running (max, sum) stay in registers; per key block all four waves stage the block (2 x 40 KB, two
+// workgroups per CU: one stages while the other computes), compute S^T for it, rescale and accumulate.
+// The running maximum is kept on the RAW scores (the scale is positive), rescale factor alpha = exp2((m_old - m_new) c);
+// every block rescales unconditionally (no deferred-max threshold), so a late dominant key is exact by construction.
+template <int HD, int DT>
+__global__ void __launch_bounds__(256, 2) attn_blocks_kernel(AttnArgs a) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int DF = (HD + 15) / 16;
+  constexpr int NCH = HD / 8;
+  constexpr int RP = 160;
+  constexpr int NKT = 16;            // 16-key tiles per 256-key block
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  char* const k_lds = smem_attn;
+  char* const v_lds = smem_attn + 256 * RP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fl = lane & 15, g = lane >> 4;
+  const int qblocks = (a.L + 127) >> 7;
+  // block -> (sequence, head, query block): the query blocks and heads of one sequence stay on ONE XCD (K / V of a head
+  // are re-read by its L / 128 query blocks out of that XCD's L2; head slices of a token row share 128-byte lines)
+  int seq, head, qb;
+  {
+    int b = blockIdx.x;
+    const int per_seq = a.heads * qblocks;
+    if ((a.num_seq & 7) == 0) {
+      const int xcd = b & 7, slot = b >> 3;
+      seq = (slot / per_seq) * 8 + xcd;
+      b = slot % per_seq;
+    } else {
+      seq = b / per_seq;
+      b = b % per_seq;
+    }
+    head = b / qblocks;
+    qb = b % qblocks;
+  }
+  const int64_t base = seq_base_row(a, seq);
+  const size_t ld = (size_t)3 * a.D;
+  const half_t* qkv_h = a.qkv + (size_t)head * HD;
+  const int q0 = qb * 128 + wave * 32;            // first query of this wave
+  const int nkb = (a.L + 255) >> 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  auto stage = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int inst = wave_u * 10 + j;
+      const int idx = inst * 64 + lane;
+      const int key = idx / 10, ch = idx - key * 10;
+      const int key_ld = min(kb * 256 + key, a.L - 1), ch_ld = min(ch, NCH - 1);
+      const half_t* rowp = qkv_h + (size_t)(base + (int64_t)key_ld * a.row_stride) * ld + ch_ld * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + a.D),
+                                       (__attribute__((address_space(3))) void*)(k_lds + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + 2 * a.D),
+                                       (__attribute__((address_space(3))) void*)(v_lds + inst * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  // Q fragments of the two 16-query groups (B operand of S^T = K Q^T), fetched under the first staging DMA
+  u32x4 qf[2][KS];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_ld = min(q0 + gq * 16 + fl, a.L - 1);
+    const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = g + 4 * ks;
+      qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
+      if (ch < NCH) qf[gq][ks] = *(const u32x4*)(qrow + ch * 8);
+    }
+  }
+  const float c = a.scale * 1.4426950408889634f;
+  const char* kbase = k_lds + fl * RP + g * 16;
+  const char* vbase = v_lds + (4 * g + (fl >> 2)) * RP + (fl & 3) * 8;
+  f32x4 o[2][DF];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+  const bool wave_active = q0 < a.L;     // waves without queries still stage and keep the barriers
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // block kb has landed for everybody
+    if (wave_active) {
+      const int kleft = a.L - kb * 256;   // keys of this block that exist (ragged last block)
+      // The two 16-query groups of the wave go through the block one after the other (QK^T -> softmax -> PV each): the 64
+      // scores of ONE group are live at a time next to both groups' output accumulators, which keeps the wave inside the
+      // 256-register budget of two waves per SIMD (both groups at once, as attn_full_kernel does, spills 31 registers here).
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        f32x4 st[NKT];
+        u32x4 kf[4][KS];
+        auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+        };
+        load_k(0, kf[0]);
+        load_k(1, kf[1]);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) st[kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[gq][ks], st[kt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kleft < 256) {
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * kt + 4 * g + r >= kleft) st[kt][r] = NEG_BIG;
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[gq], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[gq] - m_new) * c);   // first block: exp2(-huge) = 0 on o = l = 0
+        const float nm = -m_new * c;
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c, nm));
+            st[kt][r] = p;
+            ls += p;
+          }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run[gq] = l_run[gq] * alpha + ls;
+        m_run[gq] = m_new;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) o[gq][d] *= alpha;
+        // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
+        u32x4 vfr[2][DF];
+        auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+#pragma unroll
+          for (int d = 0; d < DF; ++d) {
+            const u32x2 lo = lds_tr16<DT>(vbase + (32 * ks2) * RP + d * 32);
+            const u32x2 hi = lds_tr16<DT>(vbase + (32 * ks2 + 16) * RP + d * 32);
+            dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+        };
+        load_v(0, vfr[0]);
+#pragma unroll
+        for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+          if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
+          const u32x4 pb = {pack2<DT>(st[2 * ks2][0], st[2 * ks2][1]), pack2<DT>(st[2 * ks2][2], st[2 * ks2][3]),
+                            pack2<DT>(st[2 * ks2 + 1][0], st[2 * ks2 + 1][1]), pack2<DT>(st[2 * ks2 + 1][2], st[2 * ks2 + 1][3])};
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int d = 0; d < DF; ++d) o[gq][d] = mfma_k32<DT>(vfr[ks2 & 1][d], pb, o[gq][d]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (kb + 1 < nkb) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                    // everybody is done reading block kb: its LDS image may be overwritten
+      stage(kb + 1);
+    }
+  }
+  if (!wave_active) return;
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_idx = q0 + gq * 16 + fl;
+    if (q_idx < a.L) {
+      const float inv = 1.0f / l_run[gq];
+      half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int dd = 16 * d + 4 * g;
+        if (dd < HD) {
+          u32x2 pk = {pack2<DT>(o[gq][d][0] * inv, o[gq][d][1] * inv), pack2<DT>(o[gq][d][2] * inv, o[gq][d][3] * inv)};
+          *(u32x2*)(orow + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int HD, int DT>
 __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
@@ -528,10 +722,12 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
   AttnArgs a = a_in;
   if (const char* ab = getenv("LATTE_ATTN_ABLATE")) a.variant = atoi(ab);   // measurement only (tools/attn_pmc.py)
   const bool full = a.L > 128 && a.L <= 256 && a.variant != 1;   // variant 1 forces the generic flash kernel (tests)
+  const bool blocks = a.L > 256 && a.variant != 1;               // 256-key blocks + online softmax (Latte-1: L = 1024)
   constexpr int FULL_LDS = 2 * 256 * 160;
   dim3 block(256);
   dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4)
-                    : (full ? dim3(a.num_seq * a.heads) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64)));
+                    : (full ? dim3(a.num_seq * a.heads)
+                            : (blocks ? dim3(a.num_seq * a.heads * ((a.L + 127) / 128)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64))));
 #define ATTN_LAUNCH(HD, DT)                                                                                   \
   do {                                                                                                        \
     if (small)                                                                                                \
@@ -540,6 +736,10 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
       static std::atomic<uint64_t> attr_done{0};                                                              \
       if (int rc_ = ensure_dynamic_lds((const void*)attn_full_kernel<HD, DT>, FULL_LDS, attr_done)) return rc_; \
       hipLaunchKernelGGL((attn_full_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                           \
+    } else if (blocks) {                                                                                      \
+      static std::atomic<uint64_t> attr_done_b{0};                                                            \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_blocks_kernel<HD, DT>, FULL_LDS, attr_done_b)) return rc_; \
+      hipLaunchKernelGGL((attn_blocks_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                         \
     } else                                                                                                    \
       hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);                                 \
   } while (0)

@@ -146,6 +146,11 @@ int launch_adaln_single(const float* tables /* [nblk, 6, D] */, const float* hea
 // out[b, f, c, :] = in[b, c, f, :] (to_bfc = 1) or out[b, c, f, :] = in[b, f, c, :] (to_bfc = 0); hw contiguous floats
 int launch_permute_cf(const float* in, float* out, int B, int C, int F, int hw, int to_bfc, hipStream_t st);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+// One guided DDIM step of the text-to-video loop (pipeline_latte.py:747-758 + DDIMScheduler.step, eta = 0) on x [b, C, F, HW]
+// in place: model_out is the denoiser output of the guidance pair in FRAME layout [(2b) F, Cout, HW] ([negative | prompt]):
+// eps = u + s (c - u) on the first C channels (learned sigma dropped), x0 = (x - c1 eps) / c2, x' = c3 x0 + c4 eps.
+int launch_t2v_guided_ddim(float* x, const float* model_out, int b, int C, int Cout, int F, int hw, float scale, float c1, float c2,
+                           float c3, float c4, hipStream_t st);
 int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st);   // bias = (1 - mask) * -10000
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);

@@ -549,6 +549,21 @@ __global__ void training_finalize_kernel(const float* __restrict__ partial, int 
   vb[b] = (float)(c / per_sample) / 0.6931471805599453f;               // mean_flat(.) / np.log(2.0), fp32 division
 }
 
+__global__ void t2v_guided_ddim_kernel(float* __restrict__ x, const float* __restrict__ mo, int b, int C, int Cout, int F, int hw,
+                                       float scale, float c1, float c2, float c3, float c4) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)b * C * F * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i % hw, f = (i / hw) % F, c = (i / ((size_t)hw * F)) % C, bb = i / ((size_t)hw * F * C);
+    const float un = mo[(((bb * F + f) * Cout) + c) * hw + r];                 // negative-prompt half
+    const float tx = mo[((((bb + b) * F + f) * Cout) + c) * hw + r];           // prompt half
+    const float eps = un + scale * (tx - un);                                  // pipeline_latte.py:748-749
+    const float xv = x[i];
+    const float x0 = (xv - c1 * eps) / c2;
+    x[i] = c3 * x0 + c4 * eps;
+  }
+}
+
 __global__ void training_combine_kernel(const float* __restrict__ mse, const float* __restrict__ vb, int has_vb, int kl_only,
                                         float vb_scale, int batch, float* mse_out, float* vb_out, float* loss_out) {
 #pragma clang fp contract(off)
@@ -658,6 +673,15 @@ int launch_q_sample(const float* tables, int n_steps, const float* x_start, cons
   const size_t total = (size_t)batch * per_sample;
   hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, tables, n_steps, x_start, noise, t, per_sample,
                      total, x_t);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_t2v_guided_ddim(float* x, const float* model_out, int b, int C, int Cout, int F, int hw, float scale, float c1, float c2,
+                           float c3, float c4, hipStream_t st) {
+  const size_t total = (size_t)b * C * F * hw;
+  hipLaunchKernelGGL(t2v_guided_ddim_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, x, model_out, b, C, Cout, F, hw, scale, c1,
+                     c2, c3, c4);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

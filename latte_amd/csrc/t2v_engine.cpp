@@ -71,6 +71,13 @@ struct latte_t2v {
   float *xin = nullptr, *xres = nullptr, *temb0 = nullptr, *temb = nullptr, *t6 = nullptr, *mod = nullptr, *out_bf = nullptr,
         *kbias = nullptr, *stage = nullptr;
   half_t *xn = nullptr, *qkv = nullptr, *hbuf = nullptr, *ctx_in = nullptr, *ctx1 = nullptr, *ctx = nullptr, *kv = nullptr;
+  // text context of a chain (latte_t2v_set_text): cross-attention K|V of EVERY spatial block + the additive mask bias,
+  // functions of the text alone, computed once instead of once per denoising step
+  half_t* kv_all = nullptr;         // [num_layers][trows_pad][2D]
+  int txt_batch = 0, txt_nk = 0;    // > 0: a text context for that many samples / tokens is installed
+  bool txt_has_mask = false;
+  int64_t* tsteps = nullptr;        // device copy of a chain's timesteps (latte_t2v_guided_ddim_loop)
+  int tsteps_cap = 0;
   int64_t stage_numel = 0;
   std::vector<T2VSlot> slots;
   std::map<std::string, int> slot_index;
@@ -256,6 +263,9 @@ int latte_t2v_create(const latte_t2v_config_t* cfg, int max_batch, latte_t2v_t**
   TRY(t2v_alloc(e, &e->ctx1, (size_t)TR * D));
   TRY(t2v_alloc(e, &e->ctx, (size_t)TR * D));
   TRY(t2v_alloc(e, &e->kv, (size_t)TR * 2 * D));
+  TRY(t2v_alloc(e, &e->kv_all, (size_t)c.num_layers * TR * 2 * D));
+  TRY(t2v_alloc(e, &e->tsteps, (size_t)1024));
+  e->tsteps_cap = 1024;
   TRY(t2v_alloc(e, &e->kbias, (size_t)max_batch * e->maxk));
   TRY(t2v_alloc(e, &e->temb0, (size_t)max_batch * D));
   TRY(t2v_alloc(e, &e->temb, (size_t)max_batch * D));
@@ -304,6 +314,7 @@ int latte_t2v_load_tensor(latte_t2v_t* e, const char* key, const float* data, in
   if (rc) return rc;
   if (!on_device) LATTE_HIP(hipStreamSynchronize(st));
   s.loaded = true;
+  e->txt_batch = 0;   // an installed text context was projected with the old weights
   return LATTE_OK;
 }
 
@@ -314,48 +325,62 @@ int latte_t2v_check_weights(latte_t2v_t* e) {
   return LATTE_OK;
 }
 
-int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const float* encoder_hidden_states,
-                      const float* encoder_attention_mask, int batch, int n_text, int enable_temporal_attentions, float* out,
-                      void* stream) {
-  if (!e || !x || !t || !encoder_hidden_states || !out) return fail(LATTE_ERR_INVALID, "t2v_forward: null argument");
-  int rc = latte_t2v_check_weights(e);
-  if (rc) return rc;
-  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "t2v_forward: batch exceeds max_batch of the engine");
-  if (n_text <= 0 || n_text > e->maxk) return fail(LATTE_ERR_STATE, "t2v_forward: more text tokens than max_text_tokens");
-  hipStream_t st = (hipStream_t)stream;
+// Text context: caption projection (latte_t2v.py:781-793: Linear -> GELU(tanh) -> Linear on [B * Lk, caption_channels]),
+// the k|v projection of every spatial block's cross-attention on it, and the additive score bias of the padded tokens
+// ((1 - mask) * -10000, :746-749).  All of it depends on the text only.
+static int t2v_text_context(latte_t2v* e, const float* enc, const float* mask, int B, int Lk, hipStream_t st) {
   const auto& c = e->cfg;
-  const int D = e->D, T = e->T, F = e->F, B = batch, dt = c.compute_dtype, Lk = n_text;
-  const int M = B * F * T, rps = F * T, MT = B * Lk;
-  const int mstride = (6 * e->nblk + 2) * D;
-
-  // ---- conditioning: embedded timestep, its 6D projection, all adaLN-single rows (latte_t2v.py:398-428,775-779)
-  if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t1_w, e->t1_b, nullptr, nullptr, e->temb0, B, D, 256, D, st))) return rc;
-  if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, nullptr, nullptr, e->temb, B, D, D, D, st))) return rc;
-  if ((rc = launch_small_linear(IN_SILU, e->temb, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->t6, B, 6 * D, D, 6 * D, st))) return rc;
-  if ((rc = launch_adaln_single(e->tables, e->head_table, e->t6, e->temb, e->mod, B, e->nblk, D, st))) return rc;
-
-  // ---- caption projection (latte_t2v.py:781-793): Linear -> GELU(tanh) -> Linear on [B * Lk, caption_channels]
+  const int D = e->D, dt = c.compute_dtype, MT = B * Lk;
+  int rc;
   GemmArgs g{};
   g.rows_per_sample = MT; g.gate_stride = 0;
-  if ((rc = launch_convert_f32_to_h16(encoder_hidden_states, e->ctx_in, (int64_t)MT * e->Cc, dt, st))) return rc;
+  if ((rc = launch_convert_f32_to_h16(enc, e->ctx_in, (int64_t)MT * e->Cc, dt, st))) return rc;
   g.M = MT; g.A = e->ctx_in; g.W = e->cap1_w; g.bias = e->cap1_b; g.out = e->ctx1; g.N = D; g.K = e->Cc;
   if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, 0, st))) return rc;
   g.A = e->ctx1; g.W = e->cap2_w; g.bias = e->cap2_b; g.out = e->ctx; g.K = D;
   if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, 0, st))) return rc;
-  // additive score bias of the padded text tokens: (1 - mask) * -10000 (latte_t2v.py:746-749)
-  const float* kbias = nullptr;
-  if (encoder_attention_mask) {
-    if ((rc = launch_mask_bias(encoder_attention_mask, e->kbias, (size_t)MT, st))) return rc;
-    kbias = e->kbias;
+  for (int l = 0; l < e->L; ++l) {
+    const T2VBlock& w = e->blocks[2 * l];
+    GemmArgs gk{};
+    gk.M = MT; gk.rows_per_sample = MT; gk.A = e->ctx; gk.W = w.kv2_w; gk.bias = w.kv2_b;
+    gk.out = e->kv_all + (size_t)l * e->trows_pad * 2 * D; gk.N = 2 * D; gk.K = D;
+    if ((rc = launch_gemm(gk, EPI_BIAS_H16, dt, 0, st))) return rc;
   }
+  e->txt_has_mask = mask != nullptr;
+  if (mask && (rc = launch_mask_bias(mask, e->kbias, (size_t)MT, st))) return rc;
+  e->txt_batch = B;
+  e->txt_nk = Lk;
+  return LATTE_OK;
+}
 
-  // ---- [B, C, F, H, W] -> frames, patch embed + positions
-  if ((rc = launch_permute_cf(x, e->xin, B, c.in_channels, F, e->H * e->H, 1, st))) return rc;
-  if ((rc = launch_patch_embed(e->xin, e->pe_wt, e->pe_b, e->pos, e->xres, B * F, c.in_channels, e->H, c.patch_size, D, st))) return rc;
+// The denoiser on an installed text context.  x: [xb, C, F, H, W] with xb = B, or B / 2 when `dup` (guidance pair: both
+// halves of the batch see the same latents, pipeline_latte.py:725); t: device int64, one per sample or ONE shared by all
+// (t_shared: the adaLN-single rows are then computed once, row stride 0).  Result: e->out_bf, frame layout [B * F, Cout, H, W].
+static int t2v_core(latte_t2v* e, const float* x, const int64_t* t, bool t_shared, int B, bool dup, int enable_temporal,
+                    hipStream_t st) {
+  const auto& c = e->cfg;
+  const int D = e->D, T = e->T, F = e->F, dt = c.compute_dtype, Lk = e->txt_nk;
+  const int M = B * F * T, rps = F * T;
+  const int nt = t_shared ? 1 : B;
+  const int mstride = t_shared ? 0 : (6 * e->nblk + 2) * D;
+  const float* kbias = e->txt_has_mask ? e->kbias : nullptr;
+  int rc;
+  // ---- conditioning: embedded timestep, its 6D projection, all adaLN-single rows (latte_t2v.py:398-428,775-779)
+  if ((rc = launch_small_linear(IN_TFREQ, nullptr, t, e->t1_w, e->t1_b, nullptr, nullptr, e->temb0, nt, D, 256, D, st))) return rc;
+  if ((rc = launch_small_linear(IN_SILU, e->temb0, nullptr, e->t2_w, e->t2_b, nullptr, nullptr, e->temb, nt, D, D, D, st))) return rc;
+  if ((rc = launch_small_linear(IN_SILU, e->temb, nullptr, e->ada_w, e->ada_b, nullptr, nullptr, e->t6, nt, 6 * D, D, 6 * D, st))) return rc;
+  if ((rc = launch_adaln_single(e->tables, e->head_table, e->t6, e->temb, e->mod, nt, e->nblk, D, st))) return rc;
+  // ---- [xb, C, F, H, W] -> frames, patch embed + positions (twice for the guidance pair)
+  const int xb = dup ? B / 2 : B;
+  if ((rc = launch_permute_cf(x, e->xin, xb, c.in_channels, F, e->H * e->H, 1, st))) return rc;
+  if ((rc = launch_patch_embed(e->xin, e->pe_wt, e->pe_b, e->pos, e->xres, xb * F, c.in_channels, e->H, c.patch_size, D, st))) return rc;
+  if (dup && (rc = launch_patch_embed(e->xin, e->pe_wt, e->pe_b, e->pos, e->xres + (size_t)xb * rps * D, xb * F, c.in_channels,
+                                      e->H, c.patch_size, D, st))) return rc;
 
+  GemmArgs g{};
   for (int i = 0; i < e->nblk; ++i) {
     const bool spatial = (i % 2) == 0;
-    if (!spatial && !enable_temporal_attentions) continue;
+    if (!spatial && !enable_temporal) continue;
     const T2VBlock& w = e->blocks[i];
     const float* mb = e->mod + (size_t)i * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const float* te = (i == 1 && F > 1) ? e->temp : nullptr;                  // latte_t2v.py:889-890
@@ -370,18 +395,16 @@ int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const fl
     if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
     else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
     if ((rc = launch_attention(a, dt, st))) return rc;
-    g.A = e->xn; g.W = w.o_w; g.bias = w.o_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D;
+    g.A = e->xn; g.W = w.o_w; g.bias = w.o_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, 0, st))) return rc;
     if (spatial) {
       // cross-attention on the UN-normalised stream (PixArt: no norm before attn2, no gate after it)
       if ((rc = launch_convert_f32_to_h16(e->xres, e->xn, (int64_t)M * D, dt, st))) return rc;
       g.A = e->xn; g.W = w.q2_w; g.bias = w.q2_b; g.out = e->qkv; g.gate = nullptr; g.N = D; g.K = D;
       if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, 0, st))) return rc;
-      GemmArgs gk{};
-      gk.M = MT; gk.rows_per_sample = MT; gk.A = e->ctx; gk.W = w.kv2_w; gk.bias = w.kv2_b; gk.out = e->kv; gk.N = 2 * D; gk.K = D;
-      if ((rc = launch_gemm(gk, EPI_BIAS_H16, dt, 0, st))) return rc;
       AttnArgs x2{};
-      x2.qkv = e->qkv; x2.q_ld = D; x2.kv = e->kv; x2.kbias = kbias; x2.Lk = Lk; x2.out = e->xn;
+      x2.qkv = e->qkv; x2.q_ld = D; x2.kv = e->kv_all + (size_t)(i / 2) * e->trows_pad * 2 * D; x2.kbias = kbias; x2.Lk = Lk;
+      x2.out = e->xn;
       x2.heads = e->heads; x2.hd = e->hd; x2.D = D; x2.sample_stride = rps; x2.scale = a.scale;
       x2.num_seq = B * F; x2.L = T; x2.U = F; x2.seq_stride = T; x2.row_stride = 1;
       if ((rc = launch_cross_attention(x2, dt, st))) return rc;
@@ -392,14 +415,77 @@ int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const fl
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, 0, st))) return rc;
-    g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm;
+    g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, 0, st))) return rc;
   }
-  // ---- output head (latte_t2v.py:913-931) and back to [B, C, F, H, W]
+  // ---- output head (latte_t2v.py:913-931), frame layout
   const float* hm = e->mod + (size_t)e->nblk * 6 * D;   // chunk(2): shift, scale
-  if ((rc = launch_final_layer(e->xres, hm, hm + D, mstride, e->fin_wt, e->fin_b, e->out_bf, M, D, rps, T, c.patch_size,
-                               c.out_channels, e->H, st))) return rc;
-  return launch_permute_cf(e->out_bf, out, B, c.out_channels, F, e->H * e->H, 0, st);
+  return launch_final_layer(e->xres, hm, hm + D, mstride, e->fin_wt, e->fin_b, e->out_bf, M, D, rps, T, c.patch_size,
+                            c.out_channels, e->H, st);
+}
+
+int latte_t2v_set_text(latte_t2v_t* e, const float* encoder_hidden_states, const float* encoder_attention_mask, int batch,
+                       int n_text, void* stream) {
+  if (!e) return fail(LATTE_ERR_INVALID, "t2v_set_text: null engine");
+  if (!encoder_hidden_states) {   // uninstall
+    e->txt_batch = 0;
+    return LATTE_OK;
+  }
+  int rc = latte_t2v_check_weights(e);
+  if (rc) return rc;
+  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "t2v_set_text: batch exceeds max_batch of the engine");
+  if (n_text <= 0 || n_text > e->maxk) return fail(LATTE_ERR_STATE, "t2v_set_text: more text tokens than max_text_tokens");
+  return t2v_text_context(e, encoder_hidden_states, encoder_attention_mask, batch, n_text, (hipStream_t)stream);
+}
+
+int latte_t2v_forward(latte_t2v_t* e, const float* x, const int64_t* t, const float* encoder_hidden_states,
+                      const float* encoder_attention_mask, int batch, int n_text, int enable_temporal_attentions, float* out,
+                      void* stream) {
+  if (!e || !x || !t || !out) return fail(LATTE_ERR_INVALID, "t2v_forward: null argument");
+  int rc = latte_t2v_check_weights(e);
+  if (rc) return rc;
+  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "t2v_forward: batch exceeds max_batch of the engine");
+  hipStream_t st = (hipStream_t)stream;
+  if (encoder_hidden_states) {
+    if (n_text <= 0 || n_text > e->maxk) return fail(LATTE_ERR_STATE, "t2v_forward: more text tokens than max_text_tokens");
+    if ((rc = t2v_text_context(e, encoder_hidden_states, encoder_attention_mask, batch, n_text, st))) return rc;
+  } else if (e->txt_batch != batch) {
+    return fail(LATTE_ERR_STATE, "t2v_forward: no encoder_hidden_states and no installed text context for this batch (latte_t2v_set_text)");
+  }
+  if ((rc = t2v_core(e, x, t, false, batch, false, enable_temporal_attentions, st))) return rc;
+  const auto& c = e->cfg;
+  return launch_permute_cf(e->out_bf, out, batch, c.out_channels, e->F, e->H * e->H, 0, st);   // back to [B, C, F, H, W]
+}
+
+int latte_t2v_guided_ddim_loop(latte_t2v_t* e, float* x, int samples, int n_steps, const int64_t* timesteps,
+                               const double* alpha_t, const double* alpha_prev, float guidance_scale,
+                               int enable_temporal_attentions, void* stream) {
+  if (!e || !x || !timesteps || !alpha_t || !alpha_prev || samples <= 0 || n_steps <= 0)
+    return fail(LATTE_ERR_INVALID, "t2v_guided_ddim_loop: bad arguments");
+  int rc = latte_t2v_check_weights(e);
+  if (rc) return rc;
+  const int B = 2 * samples;
+  if (B > e->max_batch) return fail(LATTE_ERR_STATE, "t2v_guided_ddim_loop: the guidance pair exceeds max_batch of the engine");
+  if (e->txt_batch != B)
+    return fail(LATTE_ERR_STATE, "t2v_guided_ddim_loop: install the text context of the guidance pair first "
+                                 "(latte_t2v_set_text with [negative | prompt] embeddings, 2 * samples rows)");
+  const auto& c = e->cfg;
+  if (c.out_channels != c.in_channels && c.out_channels != 2 * c.in_channels)
+    return fail(LATTE_ERR_INVALID, "t2v_guided_ddim_loop: out_channels must be C or 2C (learned sigma)");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_steps > e->tsteps_cap) return fail(LATTE_ERR_INVALID, "t2v_guided_ddim_loop: more than 1024 steps");
+  LATTE_HIP(hipMemcpyAsync(e->tsteps, timesteps, sizeof(int64_t) * n_steps, hipMemcpyHostToDevice, st));
+  LATTE_HIP(hipStreamSynchronize(st));   // the caller's host array may go away
+  for (int k = 0; k < n_steps; ++k) {
+    if ((rc = t2v_core(e, x, e->tsteps + k, true, B, true, enable_temporal_attentions, st))) return rc;
+    // diffusers DDIMScheduler.step, eta = 0, no clipping: Python-float coefficients times fp32 tensors
+    const double at = alpha_t[k], ap = alpha_prev[k];
+    if (!(at > 0.0 && at < 1.0) || !(ap > 0.0 && ap <= 1.0)) return fail(LATTE_ERR_INVALID, "t2v_guided_ddim_loop: alpha out of range");
+    if ((rc = launch_t2v_guided_ddim(x, e->out_bf, samples, c.in_channels, c.out_channels, e->F, e->H * e->H, guidance_scale,
+                                     (float)std::sqrt(1.0 - at), (float)std::sqrt(at), (float)std::sqrt(ap),
+                                     (float)std::sqrt(1.0 - ap), st))) return rc;
+  }
+  return LATTE_OK;
 }
 
 }  // extern "C"

@@ -4,9 +4,11 @@ denoiser: the sampling loop of Latte-1 text-to-video (SURVEY.md section 8(f) ran
 What runs where: the transformer call of every step (``latte_amd.LatteT2V``, the hot path) and the VAE decode
 (``latte_amd.AutoencoderKL``) run on the HIP engine.  The text encoder / tokenizer are whatever the caller passes (a
 ``transformers`` T5 in the reference) or are bypassed with ``prompt_embeds`` / ``negative_prompt_embeds``; the scheduler is
-any object with the diffusers interface (``latte_amd.schedulers.DDIMScheduler`` is a self-contained stand-in).  The
-guidance combine, the learned-sigma drop and the scheduler update are the reference's own few elementwise lines
-(:747-758) on device tensors.  ``enable_vae_temporal_decoder=True`` needs diffusers' ``AutoencoderKLTemporalDecoder`` and
+any object with the diffusers interface (``latte_amd.schedulers.DDIMScheduler`` is a self-contained stand-in).  With that
+scheduler at eta = 0 the whole guided loop (:700-760) runs inside the engine (``latte_t2v_guided_ddim_loop``: text context
+computed once, guidance combine + learned-sigma drop + DDIM update fused into one kernel per step); with any other
+scheduler object the guidance combine, the learned-sigma drop and the scheduler update are the reference's own few
+elementwise lines (:747-758) on device tensors around the engine denoiser.  ``enable_vae_temporal_decoder=True`` needs diffusers' ``AutoencoderKLTemporalDecoder`` and
 is not available; the per-frame decode of :773-785 is.
 """
 import inspect
@@ -104,6 +106,23 @@ class LattePipeline:
             return masked.squeeze(1), neg
         return prompt_embeds, negative_prompt_embeds
 
+    def _fused_loop(self, steps, do_cfg, eta, callback, latent_channels):
+        """(timesteps, alpha_t, alpha_prev) when the loop can run inside the engine (latte_t2v_guided_ddim_loop): guidance on,
+        the self-contained DDIM scheduler at eta = 0 without clipping, the engine transformer, no per-step callback.  Any
+        other scheduler object / configuration takes the step-by-step loop below."""
+        from .schedulers import DDIMScheduler
+        from .t2v import LatteT2V
+        sch, tr = self.scheduler, self.transformer
+        if not (do_cfg and callback is None and eta == 0.0 and type(sch) is DDIMScheduler and not sch.clip_sample
+                and isinstance(tr, LatteT2V) and tr.config.out_channels in (latent_channels, 2 * latent_channels)
+                and getattr(self, "allow_fused_loop", True)):
+            return None
+        ts = [int(t) for t in steps]
+        ratio = sch.num_train_timesteps // sch.num_inference_steps
+        a_t = [float(sch.alphas_cumprod[t]) for t in ts]
+        a_p = [float(sch.alphas_cumprod[t - ratio]) if t - ratio >= 0 else float(sch.final_alpha_cumprod) for t in ts]
+        return ts, a_t, a_p
+
     def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, device, generator, latents=None):
         shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if latents is None:
@@ -165,6 +184,13 @@ class LattePipeline:
         if "generator" in params:
             extra["generator"] = generator
         added_cond_kwargs = {"resolution": None, "aspect_ratio": None}
+        fused = self._fused_loop(steps, do_cfg, eta, callback, latent_channels)
+        if fused is not None:
+            # the whole guided DDIM chain inside the engine: no torch op between the first and the last step
+            self.transformer.set_text(prompt_embeds)
+            latents = self.transformer.guided_ddim_loop(latents, fused[0], fused[1], fused[2], guidance_scale,
+                                                        enable_temporal_attentions)
+            steps = []
         for i, t in enumerate(steps):
             latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)

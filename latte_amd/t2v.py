@@ -169,3 +169,39 @@ class LatteT2V:
         return Transformer3DModelOutput(out) if return_dict else (out,)
 
     __call__ = forward
+
+    # ------------------------------------------------------------------ chain-level entry points (pipeline_latte.py:700-760)
+    def set_text(self, encoder_hidden_states, encoder_attention_mask=None):
+        """Install the text context of a sampling chain in the engine: caption projection, every spatial block's
+        cross-attention K|V and the mask bias are computed once instead of once per step."""
+        dev = self._device
+        enc = encoder_hidden_states.to(device=dev, dtype=torch.float32).contiguous()
+        if enc.dim() != 3 or enc.shape[2] != self.config.caption_channels:
+            raise LatteError(f"encoder_hidden_states must be [B, tokens, {self.config.caption_channels}]")
+        mask = None
+        if encoder_attention_mask is not None:
+            mask = encoder_attention_mask.to(device=dev, dtype=torch.float32).contiguous()
+        eng = self._engine(enc.shape[0], enc.shape[1])
+        with torch.cuda.device(dev):
+            check(load_library().latte_t2v_set_text(eng, ptr(enc), ptr(mask), enc.shape[0], enc.shape[1], stream_ptr()))
+            torch.cuda.current_stream().synchronize()          # the inputs may be released by the caller
+        return self
+
+    def guided_ddim_loop(self, latents, timesteps, alphas_t, alphas_prev, guidance_scale, enable_temporal_attentions=True):
+        """The classifier-free-guidance DDIM loop (eta = 0) inside the engine on ``latents`` [b, C, F, H, W]; ``set_text`` must
+        hold the 2 b rows [negative | prompt].  ``timesteps`` / ``alphas_*``: one entry per step (host sequences)."""
+        import numpy as np
+        dev = self._device
+        x = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
+        at = np.ascontiguousarray(np.asarray(alphas_t, dtype=np.float64))
+        ap = np.ascontiguousarray(np.asarray(alphas_prev, dtype=np.float64))
+        if not (len(ts) == len(at) == len(ap)) or len(ts) == 0:
+            raise LatteError("guided_ddim_loop: timesteps, alphas_t and alphas_prev must have one entry per step")
+        if self._h is None:
+            raise LatteError("guided_ddim_loop: call set_text first")
+        with torch.cuda.device(dev):
+            check(load_library().latte_t2v_guided_ddim_loop(self._h, ptr(x), x.shape[0], len(ts), ts.ctypes.data, at.ctypes.data,
+                                                            ap.ctypes.data, float(guidance_scale),
+                                                            int(bool(enable_temporal_attentions)), stream_ptr()))
+        return x

@@ -84,7 +84,9 @@ def test_gemm_gated_residual_call_site_tags(lib, dev, dt):
 
 
 CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),
-         (2, 4, 4, 2, 64), (1, 2, 200, 2, 72), (1, 3, 144, 3, 64), (2, 2, 256, 4, 64), (1, 2, 129, 1, 72)]
+         (2, 4, 4, 2, 64), (1, 2, 200, 2, 72), (1, 3, 144, 3, 64), (2, 2, 256, 4, 64), (1, 2, 129, 1, 72),
+         # L > 256: the 256-key-block kernel with the online softmax (whole blocks, ragged last block, partial query block)
+         (1, 2, 1024, 2, 72), (1, 1, 300, 2, 72), (2, 1, 700, 4, 64), (1, 1, 513, 1, 72), (1, 8, 512, 3, 64)]
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -126,6 +128,25 @@ def test_attention_forced_rescale(lib, dev):
     check(lib.latte_debug_attention(ptr(qh), ptr(out), 1, T, 1, hd, 1, T, T, 1, dt, stream_ptr()))
     torch.cuda.synchronize()
     assert float((out.float() - want).norm() / want.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("hd,spike_key", [(72, 900), (64, 300), (72, 1023)])
+def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key):
+    """The 256-key-block kernel (L = 1024): a key in a LATE block dominates one query, so the running maximum jumps and the
+    accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
+    T, dt = 1024, 1
+    g = torch.Generator("cpu").manual_seed(spike_key)
+    qkv = torch.randn(T, 3 * hd, generator=g)
+    qkv[spike_key, hd:2 * hd] = qkv[37, :hd] * 6.0        # key spike_key spikes against query 37
+    qkv[10, hd:2 * hd] = qkv[700, :hd] * 5.0              # and an EARLY key dominates a query of a later query block
+    qh = qkv.to(dev).to(TD[dt])
+    q, k, v = qh.float()[:, :hd], qh.float()[:, hd:2 * hd], qh.float()[:, 2 * hd:]
+    want = (torch.softmax((q.double() @ k.double().t()) * hd ** -0.5, dim=-1) @ v.double()).float()
+    out = torch.zeros(T, hd, dtype=TD[dt], device=dev)
+    check(lib.latte_debug_attention(ptr(qh), ptr(out), 1, T, 1, hd, 1, T, T, 1, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((out.float() - want).norm() / want.norm()) < 2e-3
+    assert float((out.float()[37] - want[37]).norm() / want[37].norm()) < 4e-3
 
 
 @pytest.mark.parametrize("dt", [0, 1])

@@ -179,6 +179,23 @@ def test_pipeline_guided_ddim_chain_matches_oracle_loop():
                output_type="latents").video
     print(f"t2v guided chain rel-L2 vs oracle loop: {rel_l2(got, want):.3e}")
     assert rel_l2(got, want) < TOL
+    # that was the loop fused into the engine (latte_t2v_guided_ddim_loop); the step-by-step loop around the engine denoiser
+    # (any scheduler object) must give the same latents
+    pipe.allow_fused_loop = False
+    slow = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps, guidance_scale=scale, latents=lat,
+                output_type="latents").video
+    assert rel_l2(got, slow) < 1e-5 and rel_l2(slow, want) < TOL
+    # a text context installed once serves every later forward without encoder_hidden_states
+    m = pipe.transformer
+    x2 = torch.cat([lat, lat]).cuda()
+    tt = torch.tensor([500, 500]).cuda()
+    direct = m(x2, tt, torch.cat([ne, pe]).cuda()).sample
+    m.set_text(torch.cat([ne, pe]))
+    out = torch.empty_like(direct)
+    from latte_amd._lib import check, load_library, ptr, stream_ptr
+    check(load_library().latte_t2v_forward(m._h, ptr(x2.contiguous()), ptr(tt), None, None, 2, 6, 1, ptr(out), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, direct)
     # decode hand-off (pipeline_latte.py:773-785) on a 16x16 latent (the VAE engine's smallest): uint8 [b, f, h, w, c]
     vsd = vo.init_state_dict(seed=2)
     vae = latte_amd.AutoencoderKL(latent_size=16, max_frames=2, compute_dtype="f16")
