@@ -721,8 +721,9 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
   const bool small = a0.L <= 16;
   AttnArgs a = a_in;
   if (const char* ab = getenv("LATTE_ATTN_ABLATE")) a.variant = atoi(ab);   // measurement only (tools/attn_pmc.py)
-  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1;   // variant 1 forces the generic flash kernel (tests)
-  const bool blocks = a.L > 256 && a.variant != 1;               // 256-key blocks + online softmax (Latte-1: L = 1024)
+  // variant 1 forces the generic flash kernel (tests); variant 4 (measurement) sends 128 < L <= 256 to the block kernel
+  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1 && a.variant != 4;
+  const bool blocks = (a.L > 256 && a.variant != 1) || (a.L > 128 && a.variant == 4);   // 256-key blocks + online softmax
   constexpr int FULL_LDS = 2 * 256 * 160;
   dim3 block(256);
   dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4)

@@ -83,6 +83,7 @@ struct GemmArgs {
   int gate_stride;
   int rows_per_sample;
   int stagger;        // persistent kernel: number of start cohorts (0/1 = none); cohort c sleeps c/stagger of a tile time
+  int group_m;        // persistent kernel: tile rows walked together by the grouped tile order (0 = 8)
   int rmw_mode;       // measurement build only: look-ahead depth + 16 * non-temporal loads of the read-modify-write epilogue
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
 };

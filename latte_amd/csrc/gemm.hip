@@ -16,6 +16,7 @@
 //  * XCD-aware, grouped block->tile mapping so that co-resident tiles of one XCD share A/W panels in
 //    that XCD's private L2.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -389,11 +390,12 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
     const long long t0 = __builtin_readcyclecounter();
     while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
+  const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;   // tile rows walked together (L2 reuse of the W panels)
   auto decode = [&](int wg, int& tm, int& tn) {
-    const int per_group = GROUP_M * tiles_n;
+    const int per_group = group_m * tiles_n;
     const int group = wg / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int first_m = group * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
     const int in_group = wg - group * per_group;
     tm = first_m + in_group % gsz;
     tn = in_group / gsz;
@@ -869,9 +871,22 @@ int gemm_auto_variant(int M, int N, int epi) {
 
 int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
   GemmArgs a = a_in;
+  // grouped tile order of the persistent kernel: the gated-residual GEMMs (192-wide tiles: an A K-tile is 32 KB, a W K-tile
+  // 24 KB) walk 4 tile rows together instead of 8 (fc2 in the XL/2 forward at B = 8: 341 -> 333 us, round-2 sweep)
+  if (a.group_m == 0 && epi == EPI_GATE_RES_F32) a.group_m = 4;
 #ifdef LATTE_GEMM_ABLATE
   if (const char* m = getenv("LATTE_RMW_MODE")) a.rmw_mode = atoi(m);
   if (const char* m = getenv("LATTE_RMW_VARIANT")) { if (epi == EPI_GATE_RES_F32 && variant == 0) variant = atoi(m); }
+  if (const char* m = getenv("LATTE_GROUP_M")) {   // "epi:value[,epi:value]" e.g. "2:5" = gated-residual GEMMs walk 5 tile rows together
+    for (const char* q = m; q && *q;) {
+      const int e_ = atoi(q);
+      const char* c_ = strchr(q, ':');
+      if (!c_) break;
+      if (e_ == epi) a.group_m = atoi(c_ + 1);
+      q = strchr(c_, ',');
+      if (q) ++q;
+    }
+  }
 #endif
   if (variant == 0) {
     variant = gemm_auto_variant(a.M, a.N, epi);

@@ -164,7 +164,9 @@ __global__ void __launch_bounds__(256) small_linear_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int PE_TOK = 8;
+constexpr int PE_TOK = 16;
+// block = 16 tokens x 128 output features: thread (token group tg = tid >> 5, feature quad q = tid & 31) computes 4 tokens x 4
+// consecutive features, so weights / positions / outputs move as 16-byte accesses (512 B per token row and instruction)
 __global__ void __launch_bounds__(128) patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, const float* __restrict__ pos,
                                                           float* __restrict__ out, int ntok, int C, int H, int p, int D) {
@@ -185,20 +187,31 @@ __global__ void __launch_bounds__(128) patch_embed_kernel(const float* __restric
     xs[i] = v;
   }
   __syncthreads();
-  const int d = blockIdx.y * 128 + threadIdx.x;
-  float acc[PE_TOK];
+  const int tg = threadIdx.x >> 5, q = threadIdx.x & 31;
+  const int d = blockIdx.y * 128 + q * 4;
+  float4 acc[4];
 #pragma unroll
-  for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] = 0.f;
+  for (int tk = 0; tk < 4; ++tk) acc[tk] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = 0; k < K; ++k) {
-    const float w = Wt[(size_t)k * D + d];
+    const float4 w = *(const float4*)(Wt + (size_t)k * D + d);
 #pragma unroll
-    for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] = fmaf(xs[tk * K + k], w, acc[tk]);
+    for (int tk = 0; tk < 4; ++tk) {
+      const float xv = xs[(tg * 4 + tk) * K + k];
+      acc[tk].x = fmaf(xv, w.x, acc[tk].x);
+      acc[tk].y = fmaf(xv, w.y, acc[tk].y);
+      acc[tk].z = fmaf(xv, w.z, acc[tk].z);
+      acc[tk].w = fmaf(xv, w.w, acc[tk].w);
+    }
   }
-  const float bv = bias[d];
+  const float4 bv = *(const float4*)(bias + d);
 #pragma unroll
-  for (int tk = 0; tk < PE_TOK; ++tk) {
-    const int n = tok0 + tk;
-    if (n < ntok) out[(size_t)n * D + d] = acc[tk] + bv + pos[(size_t)(n % T) * D + d];
+  for (int tk = 0; tk < 4; ++tk) {
+    const int n = tok0 + tg * 4 + tk;
+    if (n < ntok) {
+      const float4 pv = *(const float4*)(pos + (size_t)(n % T) * D + d);
+      *(float4*)(out + (size_t)n * D + d) = make_float4(acc[tk].x + bv.x + pv.x, acc[tk].y + bv.y + pv.y, acc[tk].z + bv.z + pv.z,
+                                                        acc[tk].w + bv.w + pv.w);
+    }
   }
 }
 
@@ -251,6 +264,40 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
   __syncthreads();
   const int P = p * p * Cout;
   const int G = H / p;
+  if (P == 32) {
+    // patch 2 x 2 x 8 channels (every "/2" model with learned sigma): thread = (output feature j, one of 8 K slices); a weight
+    // element is loaded ONCE per block and used for all FL_ROWS rows (the generic path below loads it once per row), the
+    // row values are LDS broadcasts; partial sums meet through a half-wave shuffle and a [4 waves][rows][32] LDS patch.
+    const int j = lane & 31, ksl = wave * 2 + (lane >> 5);
+    constexpr int KSL = D / 8;
+    float acc[FL_ROWS];
+#pragma unroll
+    for (int r = 0; r < FL_ROWS; ++r) acc[r] = 0.f;
+    for (int k = ksl * KSL; k < (ksl + 1) * KSL; ++k) {
+      const float w = Wt[(size_t)k * 32 + j];
+#pragma unroll
+      for (int r = 0; r < FL_ROWS; ++r) acc[r] = fmaf(xs[r * D + k], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < FL_ROWS; ++r) acc[r] += __shfl_xor(acc[r], 32, 64);
+    __syncthreads();                       // every wave is done reading the rows: reuse the LDS for the partial sums
+    if (lane < 32) {
+#pragma unroll
+      for (int r = 0; r < FL_ROWS; ++r) xs[(wave * FL_ROWS + r) * 32 + j] = acc[r];
+    }
+    __syncthreads();
+    const int rr = threadIdx.x >> 5, jj = threadIdx.x & 31;
+    const int row = row0 + rr;
+    if (row < M) {
+      const float r = ((xs[(0 * FL_ROWS + rr) * 32 + jj] + xs[(1 * FL_ROWS + rr) * 32 + jj]) +
+                       (xs[(2 * FL_ROWS + rr) * 32 + jj] + xs[(3 * FL_ROWS + rr) * 32 + jj])) + bias[jj];
+      const int c = jj % Cout, qi = (jj / Cout) % p, pi = jj / (Cout * p);
+      const int bf = row / T, tt = row % T;
+      const int hp = tt / G, wp = tt % G;
+      out[(((size_t)bf * Cout + c) * H + hp * p + pi) * H + wp * p + qi] = r;
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < FL_ROWS * P; idx += 256) {
     const int rr = idx / P, j = idx % P;
     const int row = row0 + rr;

@@ -77,6 +77,22 @@ def main():
                     oras = do.sample_loop(s, lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt, y, te), x, method=method, noises=noises)
                 rows.append((f"{title}: {method.upper()}-{steps} loop final latents", f"rel-L2 {rel(oras, refs):.2e}"))
                 assert rel(oras, refs) < 1e-5
+    # --- training losses (gd:719-795 through rs:95-98) for the loss / model types create_diffusion builds
+    from oracle.make_golden import TRAINING_CASES, training_inputs
+    loss_of = {"mse_learned": "mse", "rescaled_mse_learned_100": "rescaled_mse", "rescaled_kl_learned": "rescaled_kl",
+               "mse_fixed_large": "mse", "mse_xstart_learned": "mse"}
+    for tag, kw, spec in TRAINING_CASES:
+        d = rd.create_diffusion(spec, **kw)
+        s = do.Schedule(spec, predict_xstart=kw.get("predict_xstart", False), learn_sigma=kw.get("learn_sigma", True))
+        x0, noise, t = training_inputs(d.num_timesteps)
+        oc = 8 if kw.get("learn_sigma", True) else 4
+        ref = d.training_losses(lambda x, tt, **k: do.synthetic_model(x, tt, oc), x0, t, model_kwargs={}, noise=noise)
+        ora = do.training_losses(s, lambda x, tt: do.synthetic_model(x, tt, oc), x0, t, noise, loss_of[tag])
+        ok = set(ref) == set(ora) and all(torch.equal(ref[k], ora[k]) for k in ref)
+        ok = ok and torch.equal(d.q_sample(x0, t, noise=noise), do.q_sample(s, x0, t, noise))
+        rows.append((f"training_losses + q_sample, create_diffusion('{spec}', {kw}) [{', '.join(sorted(ref))}]",
+                     "bit-identical" if ok else "MISMATCH"))
+        assert ok, tag
     with open("oracle/VALIDATION.md", "w") as f:
         f.write("# Oracle vs. the real reference (run in the build container)\n\n"
                 "Produced by `python -m oracle.validate_oracle --xl`; reference = `/root/reference` unmodified "

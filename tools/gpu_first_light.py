@@ -346,6 +346,68 @@ def rmw_ahead():
     del os.environ["LATTE_RMW_VARIANT"]
 
 
+def attn_variants():
+    """Attention kernels on the model shapes: XL/2 spatial (L = 256) through attn_full / the block kernel / the generic flash
+    kernel, Latte-1 spatial (L = 1024, B = 2) through the block kernel / flash, temporal (L = 16)."""
+    def run(B, F, T, mode, env):
+        H, hd = 16, 72
+        D, rows = H * hd, B * F * T
+        qkv = torch.randn(rows, 3 * D, device=dev).bfloat16()
+        out = torch.zeros(rows, D, dtype=torch.bfloat16, device=dev)
+        args = (B * F, T, H, hd, F, F * T, T, 1) if mode == "spatial" else (B * T, F, H, hd, T, F * T, 1, T)
+        if env is None:
+            os.environ.pop("LATTE_ATTN_ABLATE", None)
+        else:
+            os.environ["LATTE_ATTN_ABLATE"] = str(env)
+        for _ in range(3):
+            check(lib.latte_debug_attention(ptr(qkv), ptr(out), *args, 0, stream_ptr()))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            check(lib.latte_debug_attention(ptr(qkv), ptr(out), *args, 0, stream_ptr()))
+        e1.record()
+        torch.cuda.synchronize()
+        os.environ.pop("LATTE_ATTN_ABLATE", None)
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        fl = 4.0 * B * F * T * T * D if mode == "spatial" else 4.0 * B * T * F * F * D
+        return us, fl / us / 1e6, out.float()
+    for (B, F, T, nm) in [(8, 16, 256, "XL/2 spatial L=256 B=8"), (2, 16, 1024, "Latte-1 spatial L=1024 B=2")]:
+        row, ref = [], None
+        for env, name in ((None, "default"), (4, "blocks"), (1, "flash")):
+            us, tf, o = run(B, F, T, "spatial", env)
+            ref = o if ref is None else ref
+            row.append(f"{name}: {us:7.1f}us {tf:5.0f}TF d={float((o - ref).abs().max()):.1e}")
+        log(f"attn_variants {nm}: " + " | ".join(row))
+    us, tf, _ = run(8, 16, 256, "temporal", None)
+    log(f"attn_variants XL/2 temporal L=16 B=8: {us:.1f}us, {8*16*256*4*1152*2/us/1e6:.2f} TB/s algorithmic")
+
+
+def group_m_sweep():
+    """Measurement build: tile rows walked together by the persistent GEMM (LATTE_GROUP_M=epi:value), inside the XL/2 forward."""
+    from latte_amd.models import Latte_models
+    B = 8
+    m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.normal_(0, 0.02)
+    m = m.to(dev)
+    x = torch.randn(B, 16, 4, 32, 32, device=dev)
+    t = torch.full((B,), 500, device=dev, dtype=torch.int64)
+    for spec in ("", "2:5", "2:6", "2:4", "2:3", "2:16", "0:4,1:4", "0:6,1:6", "0:16,1:16", "0:2,1:2", ""):
+        if spec:
+            os.environ["LATTE_GROUP_M"] = spec
+        else:
+            os.environ.pop("LATTE_GROUP_M", None)
+        m.profile_forward(x, t)
+        pr = [m.profile_forward(x, t) for _ in range(3)]
+        row = " ".join(f"{k}: {min(p[k][0] for p in pr) / max(pr[0][k][1], 1) * 1e3:6.1f}us" for k in
+                       ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+        log(f"group_m '{spec}': {row} | forward {min(sum(v_[0] for v_ in p.values()) for p in pr):.3f} ms")
+    os.environ.pop("LATTE_GROUP_M", None)
+
+
 def gemm_stagger():
     ms = _lib.c_f32()
     for (M, N, K, epi, v, nm) in [(32768, 4608, 1152, 1, 9, "fc1"), (32768, 3456, 1152, 0, 9, "qkv"), (32768, 1152, 4608, 2, 8, "fc2"),

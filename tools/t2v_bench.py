@@ -47,6 +47,28 @@ def main():
     attn = L * (4.0 * B * F * T * T * D + 4.0 * B * T * F * F * D + 4.0 * B * F * T * 120 * D)
     print(f"LatteT2V {a.dtype} B={B} layers={L}+{L}: {dt*1e3:.2f} ms per forward, finite={bool(torch.isfinite(out).all())}; "
           f"algorithmic {(lin + attn)/1e12:.2f} TFLOP -> {(lin + attn)/dt/1e12:.0f} TF/s ({(lin + attn)/dt/2.5e15*100:.1f} % of the dense bf16 peak)")
+    if B % 2 == 0:
+        # the guided DDIM loop inside the engine (text context once, one fused update kernel per step)
+        from latte_amd.schedulers import DDIMScheduler
+        sch = DDIMScheduler()
+        sch.set_timesteps(50)
+        pipe = latte_amd.LattePipeline(transformer=m, scheduler=sch)
+        n = max(a.steps, 4)
+        ts = [int(v) for v in sch.timesteps[:n]]
+        ratio = sch.num_train_timesteps // sch.num_inference_steps
+        at = [float(sch.alphas_cumprod[v]) for v in ts]
+        ap = [float(sch.alphas_cumprod[v - ratio]) if v >= ratio else 1.0 for v in ts]
+        lat = torch.randn(B // 2, 4, 16, 64, 64, device="cuda")
+        m.set_text(enc)
+        m.guided_ddim_loop(lat, ts[:2], at[:2], ap[:2], 7.5)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        outl = m.guided_ddim_loop(lat, ts, at, ap, 7.5)
+        torch.cuda.synchronize()
+        dl = (time.time() - t0) / n
+        print(f"guided DDIM loop in the engine ({B // 2} video(s), guidance pair): {dl*1e3:.2f} ms per step "
+              f"({dl / dt:.3f} x one forward), finite={bool(torch.isfinite(outl).all())}; 50 steps = {50*dl:.2f} s")
+        del pipe
 
 
 if __name__ == "__main__":
