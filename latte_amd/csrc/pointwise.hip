@@ -273,10 +273,14 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
     float acc[FL_ROWS];
 #pragma unroll
     for (int r = 0; r < FL_ROWS; ++r) acc[r] = 0.f;
-    for (int k = ksl * KSL; k < (ksl + 1) * KSL; ++k) {
-      const float w = Wt[(size_t)k * 32 + j];
+    for (int k = ksl * KSL; k < (ksl + 1) * KSL; k += 4) {   // KSL = D / 8 is a multiple of 16
+      const float w0 = Wt[(size_t)k * 32 + j], w1 = Wt[(size_t)(k + 1) * 32 + j], w2 = Wt[(size_t)(k + 2) * 32 + j],
+                  w3 = Wt[(size_t)(k + 3) * 32 + j];
 #pragma unroll
-      for (int r = 0; r < FL_ROWS; ++r) acc[r] = fmaf(xs[r * D + k], w, acc[r]);
+      for (int r = 0; r < FL_ROWS; ++r) {
+        const float4 xv = *(const float4*)(xs + r * D + k);     // one 16-byte LDS broadcast per row and 4 k
+        acc[r] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[r]))));
+      }
     }
 #pragma unroll
     for (int r = 0; r < FL_ROWS; ++r) acc[r] += __shfl_xor(acc[r], 32, 64);
