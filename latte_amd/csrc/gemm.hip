@@ -838,7 +838,7 @@ int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: return 256;
-    case 5: case 8: return 192;
+    case 5: case 8: case 10: return 192;
     default: return 128;
   }
 }
@@ -893,6 +893,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
     //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
   }
+  if (variant == 10) return launch_gemm_pw(a, epi, dtype, st);
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)

@@ -1,0 +1,367 @@
+// Producer-wave GEMM (round 2):  C[M,N] = A[M,K] · W[N,K]^T, 256 x 192 tile, TWELVE waves per workgroup.
+//
+// Same operand layout, LDS image (source-side swizzle), persistent XCD-chunked tile walk and segment schedule as
+// gemm_pps_kernel (gemm.hip), with ONE change of structure: the operand DMA is not issued by the MFMA waves.
+// What round 1 measured: a `buffer_load ... lds` holds the wave that issues it for 26-105 shader
+// clocks, so in the 8-wave kernel every K tile serialises [64 MFMAs | 12 DMA issues | 24 fragment reads] inside group 0's
+// waves and the matrix pipe idles for a third of the period; a DMA wave NEXT TO MFMA waves does not slow them at all
+// (`latte_debug_dma_probe` modes 7-9: 16.4 clocks per MFMA beside 4 streaming DMA waves).  So:
+//   * waves 0-7  = consumers, 2 groups x 4 (output rows 0-127 / 128-255, 48 columns each): fragment reads + MFMAs + epilogue;
+//   * waves 8-11 = producers, one per SIMD (a workgroup's waves are placed on the SIMDs cyclically, so waves w, w + 4, w + 8
+//     share one): they only issue the LDS DMA of K tile u + 1 while the consumers work on K tile u, confirm it with counted
+//     `vmcnt` and take part in the workgroup barriers.
+// Three waves per SIMD means 168 VGPRs per wave (512 / 3, one allocation for the whole kernel), which is why the tile is
+// 256 x 192 (96 accumulators) and the fragments of the second half of a K tile are read INSIDE the compute segment, each
+// A fragment into the registers its first-half twin has just left: 96 + 24 (B, both halves) + 32 (A) = 152.
+//
+// Barrier-delimited intervals (barrier b ends interval I(b); P = the barrier after the pipeline fill):
+//   group 0:   L(u) in I(2u),   C(u) in I(2u+1)          L(u): B(u) both halves + A(u) first half  -> registers
+//   group 1:   L(u) in I(2u+1), C(u) in I(2u+2)          C(u): 48 MFMAs, the 8 second-half A reads between them
+//   producers: I(2v)   issue B(v+1) and A rows 0-127 of K tile v+1  (stage (v+1)&1: last read in I(2v-1)),
+//                      then vmcnt(10): A rows 128-255 of K tile v have landed (group 1 reads them in I(2v+1));
+//              I(2v+1) issue A rows 128-255 of K tile v+1            (last read of that region: group 1's C(v-1) in I(2v)),
+//                      then vmcnt(4): B / A rows 0-127 of K tile v+1 have landed (group 0 reads them in I(2v+2)).
+// The K-tile counter runs across tile boundaries, so the producers never drain; a consumer group runs its epilogue
+// around the barrier that ends its last compute segment (group 1 before, group 0 after it), as in gemm_pps_kernel.
+#include "common.h"
+#include "mfma_util.h"
+
+namespace latte {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_pw;
+__device__ __forceinline__ void pw_bload_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_pw*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int DT, int TAG>
+__global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int NA = 3, NB = 2;                 // LDS rings: 3 A stages (96 KB) at offset 0, 2 B stages (48 KB) behind them
+  constexpr int B_BASE = NA * A_BYTES;
+  constexpr int AH_INSTR = 4, BG_INSTR = 6;   // per producer wave: 128 A rows / (4 waves x 8 rows), 192 W rows / (4 x 8)
+  constexpr int GROUP_M = 8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = g.K;
+  const unsigned row_bytes = (unsigned)K * 2u;
+
+  // ---- this workgroup's tile sequence (identical to gemm_pps_kernel)
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN, nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+  const int nk = K / 64;
+  const int ntile = (cnt - slot + per - 1) / per;   // tiles this workgroup walks
+  // measurement build only: per-wave phase times of workgroup 0 (s_memtime ticks), no output written
+  constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
+  if constexpr (TRACE) tstart = tprev = (long long)__builtin_readcyclecounter();
+#define LATTE_TS(IDX)                                                \
+  if constexpr (TRACE) {                                             \
+    const long long now_ = (long long)__builtin_readcyclecounter();  \
+    tacc[IDX] += now_ - tprev;                                       \
+    tprev = now_;                                                    \
+  }
+  auto trace_out = [&](int n_it) {
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && lane == 0) {
+        long long* o = (long long*)g.out + wave * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+        o[6] = (long long)__builtin_readcyclecounter() - tstart;
+        o[7] = n_it;
+      }
+    }
+  };
+
+  if (wave >= 8) {
+    // ================================ producer ================================
+    const int pw = wave - 8;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)tiles_m * BM * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)g.N * row_bytes, 0x00020000);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    // row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7) ^ swizzle(row); rows pw*8 + 32 j: 32 j does not move the swizzle
+    const unsigned voff = (unsigned)lrow * row_bytes + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
+    unsigned step32 = 32u * row_bytes;
+    asm volatile("" : "+s"(step32));
+    auto dma_a = [&](int half, int tm_, int kt, int stg) {
+      char* sA = smem + stg * A_BYTES + half * 128 * 128 + pw * 1024;
+      const unsigned so = (unsigned)(tm_ * BM + half * 128 + pw * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+      for (int j = 0; j < AH_INSTR; ++j) pw_bload_lds16(rsA, sA + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    auto dma_b = [&](int tn_, int kt, int stg) {
+      char* sB = smem + B_BASE + stg * B_BYTES + pw * 1024;
+      const unsigned so = (unsigned)(tn_ * BN + pw * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+      for (int j = 0; j < BG_INSTR; ++j) pw_bload_lds16(rsB, sB + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    // Two walkers over the K tiles of this workgroup's tile sequence: `b` (for B) is one K tile ahead of the consumers,
+    // `a` (for A, the operand that streams from HBM in the long-K GEMMs) two.
+    struct Walk { int pos, tm, tn, kt; };
+    auto advance = [&](Walk& w) {
+      if (++w.kt == nk) {
+        w.kt = 0;
+        w.pos += per;
+        if (w.pos < cnt) decode(chunk0 + w.pos, w.tm, w.tn);
+      }
+    };
+    Walk wb{slot, 0, 0, 0};
+    decode(chunk0 + slot, wb.tm, wb.tn);
+    Walk wa = wb;
+    const int U = ntile * nk;
+    // pipeline fill: K tile 0 complete, A of K tile 1
+    dma_b(wb.tn, 0, 0);
+    dma_a(0, wa.tm, 0, 0);
+    dma_a(1, wa.tm, 0, 0);
+    advance(wa);
+    advance(wb);                       // wb -> K tile 1
+    if (U > 1) { dma_a(0, wa.tm, wa.kt, 1); dma_a(1, wa.tm, wa.kt, 1); }
+    advance(wa);                       // wa -> K tile 2
+    if (U > 1) wait_vm<2 * AH_INSTR>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // P
+    int sa = 2, sb = 1;             // ring slots of K tile v + 2 (A) and v + 1 (B)
+    for (int v = 0; v < U; ++v) {
+      const bool more_b = v + 1 < U, more_a = v + 2 < U;
+      // I(2v): B(v+1), A rows 0-127 of K tile v+2; then everything of K tile v must have landed
+      LATTE_TS(5)
+      if (more_b) dma_b(wb.tn, wb.kt, sb);
+      if (more_a) dma_a(0, wa.tm, wa.kt, sa);
+      LATTE_TS(0)
+      // newer than K tile v: A(v+1) 8, B(v+1) 6, A0(v+2) 4
+      if (more_a) wait_vm<2 * AH_INSTR + BG_INSTR + AH_INSTR>(); else wait_vm<0>();
+      LATTE_TS(1)
+      __builtin_amdgcn_s_barrier();
+      LATTE_TS(2)
+      // I(2v+1): A rows 128-255 of K tile v+2; then B(v+1) (and with it A(v+1), which is older) must have landed
+      if (more_a) dma_a(1, wa.tm, wa.kt, sa);
+      LATTE_TS(0)
+      if (more_a) wait_vm<2 * AH_INSTR>(); else wait_vm<0>();
+      LATTE_TS(3)
+      __builtin_amdgcn_s_barrier();
+      LATTE_TS(4)
+      advance(wa);
+      advance(wb);
+      sa = sa == NA - 1 ? 0 : sa + 1;
+      sb ^= 1;
+    }
+    __builtin_amdgcn_s_barrier();   // barrier 2U
+    trace_out(U);
+    return;
+  }
+
+  // ================================ consumer ================================
+  const int grp = wave >> 2, wn = wave & 3;
+  const int sw = (lane >> 1) & 7;
+  const int chunkb = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + (lane & 15)) * 128 + chunkb;
+  const int b_off = B_BASE + (wn * WTN + (lane & 15)) * 128 + chunkb;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Epilogue of tile (tm_, tn_) for this wave's 128 x 48 sub-tile, then clear the accumulators.
+  auto epilogue = [&](int tm_, int tn_) {
+    int le = lane;
+    asm volatile("" : "+v"(le));   // opaque: keeps every lane-derived epilogue index out of the K loop's live set
+    const int fr = le & 15;
+    const int ncol = tn_ * BN + wn * WTN + (le >> 4) * 4;
+    const int mbase = tm_ * BM + grp * 128 + fr;
+    if constexpr (TRACE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      return;
+    }
+    if constexpr (EPI == EPI_GATE_RES_F32) {
+      // res[m, n] += gate[sample, n] * (acc + bias); residual loads run two fragments ahead of the stores (gemm.hip)
+      if ((g.rows_per_sample % BM) == 0) {
+        float* const outp = (float*)g.out;
+        const float* gr = g.gate + (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
+        float4 b4[FN], g1[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          b4[j] = *(const float4*)(g.bias + ncol + j * 16);
+          g1[j] = *(const float4*)(gr + j * 16);
+        }
+        constexpr int NF = 8 * FN, AHEAD = 2;
+        auto frag_ptr = [&](int f) -> float* {
+          const int mc = min(mbase + (f / FN) * 16, g.M - 1);
+          return outp + (size_t)mc * g.N + ncol + (f % FN) * 16;
+        };
+        float4 qa[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) qa[a] = *(const float4*)frag_ptr(a);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          float4 rr = qa[f % AHEAD];
+          if (f + AHEAD < NF) qa[f % AHEAD] = *(const float4*)frag_ptr(f + AHEAD);
+          asm volatile("" ::: "memory");
+          const int i = f / FN, j = f % FN;
+          rr.x += g1[j].x * (acc[i][j][0] + b4[j].x);
+          rr.y += g1[j].y * (acc[i][j][1] + b4[j].y);
+          rr.z += g1[j].z * (acc[i][j][2] + b4[j].z);
+          rr.w += g1[j].w * (acc[i][j][3] + b4[j].w);
+          if (mbase + i * 16 < g.M) *(float4*)(outp + (size_t)(mbase + i * 16) * g.N + ncol + j * 16) = rr;
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = mbase + i * 16;
+      if (m < g.M) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = ncol + j * 16;
+          const float4 b4 = *(const float4*)(g.bias + n);
+          float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+          const size_t o = (size_t)m * g.N + n;
+          if constexpr (EPI == EPI_GATE_RES_F32) {
+            const float4 g4 = *(const float4*)(g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride + n);
+            float4* dst = (float4*)((float*)g.out + o);
+            float4 rr = *dst;
+            rr.x += g4.x * v0; rr.y += g4.y * v1; rr.z += g4.z * v2; rr.w += g4.w * v3;
+            *dst = rr;
+          } else if constexpr (EPI == EPI_BIAS_F32) {
+            *(float4*)((float*)g.out + o) = make_float4(v0, v1, v2, v3);
+          } else {
+            if constexpr (EPI == EPI_BIAS_GELU_H16) {
+              auto gelu = [](float x) {
+                const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+                return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
+              };
+              v0 = gelu(v0); v1 = gelu(v1); v2 = gelu(v2); v3 = gelu(v3);
+            }
+            const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+            *(u32x2*)((half_t*)g.out + o) = p;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  int pos = slot, tm, tn;
+  decode(chunk0 + pos, tm, tn);
+  __builtin_amdgcn_s_barrier();                 // P: K tile 0 has landed
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // barrier 0: group 1 runs one segment behind
+
+  int it = 0, ia = 0;   // K-tile counter of the walk, its A ring slot (it % 3)
+  for (;;) {
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      const bool last = kt + 1 == nk;
+      const char* sbufA = smem + ia * A_BYTES;
+      const char* sbufB = smem + (it & 1) * B_BYTES;
+      ia = ia == NA - 1 ? 0 : ia + 1;
+      u32x4 bf[2][FN], af[8];
+      // ---- L(u)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sbufB + (b_off + j * 2048));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *(const u32x4*)(sbufA + (a_off + i * 2048));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[1][j] = *(const u32x4*)(sbufB + ((b_off + j * 2048) ^ 64));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      LATTE_TS(0)
+      __builtin_amdgcn_s_barrier();
+      LATTE_TS(1)
+      // ---- C(u)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[0][j], af[i], acc[i][j]);
+        // second-half fragment of the same rows into the registers the MFMAs above have just read
+        af[i] = *(const u32x4*)(sbufA + ((a_off + i * 2048) ^ 64));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[1][j], af[i], acc[i][j]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      LATTE_TS(2)
+      if (grp == 1 && last) epilogue(tm, tn);
+      LATTE_TS(3)
+      __builtin_amdgcn_s_barrier();
+      LATTE_TS(4)
+      if (grp == 0 && last) epilogue(tm, tn);
+      LATTE_TS(5)
+    }
+    pos += per;
+    if (pos >= cnt) break;
+    decode(chunk0 + pos, tm, tn);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier 2U (group 1 spent it up front)
+  trace_out(it);
+#undef LATTE_TS
+}
+
+template <int DT>
+int launch_pw_dt(const GemmArgs& a, int epi, hipStream_t st) {
+  constexpr int LDS = 3 * 256 * 128 + 2 * 192 * 128;   // A ring + B ring
+  const int tiles = ((a.M + 255) / 256) * (a.N / 192);
+  const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;
+  dim3 grid(nblk), block(768);
+#define LATTE_PW_CASE(E, T)                                                                          \
+  {                                                                                                  \
+    auto kern = gemm_pw_kernel<E, DT, T>;                                                            \
+    static std::atomic<uint64_t> attr_done{0};                                                       \
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+  }
+  if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
+  else if (epi == EPI_GATE_RES_F32) LATTE_PW_CASE(EPI_GATE_RES_F32, 0)
+  else if (epi == EPI_BIAS_F32) LATTE_PW_CASE(EPI_BIAS_F32, 0)
+  else if (epi == EPI_BIAS_H16) LATTE_PW_CASE(EPI_BIAS_H16, 0)
+  else if (epi == EPI_BIAS_GELU_H16) LATTE_PW_CASE(EPI_BIAS_GELU_H16, 0)
+#ifdef LATTE_GEMM_ABLATE
+  else if (epi == EPI_ABLATE_TRACE) LATTE_PW_CASE(EPI_ABLATE_TRACE, 0)
+#endif
+  else return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): unknown epilogue");
+#undef LATTE_PW_CASE
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+}  // namespace
+
+// variant 10: limits of the 32-bit buffer offsets and K >= 128 as for the persistent kernel; whole 192-wide tile columns
+int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, hipStream_t st) {
+  if (a.N % 192 != 0 || a.K % 64 != 0 || a.K < 128 || a.M <= 0)
+    return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): need N % 192 == 0, K % 64 == 0, K >= 128");
+  if ((uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 >= (1ull << 32) || (uint64_t)a.N * a.K * 2 >= (1ull << 32))
+    return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): operand exceeds the 4 GiB buffer-offset range");
+  if (dtype == LATTE_DTYPE_BF16) return launch_pw_dt<LATTE_DTYPE_BF16>(a, epi, st);
+  if (dtype == LATTE_DTYPE_F16) return launch_pw_dt<LATTE_DTYPE_F16>(a, epi, st);
+  return fail(LATTE_ERR_INVALID, "gemm: unknown dtype");
+}
+
+}  // namespace latte
