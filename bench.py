@@ -137,9 +137,9 @@ def roofline_table(prof, B, dtype):
     D, Hm, F, T = 1152, 4608, 16, 256
     M = B * F * T
     mfma = {"gemm_qkv": (2.0 * M * 3 * D * D, "gemm_pps_kernel<256, EPI_BIAS_H16>: qkv projection M=%d N=3456 K=1152" % M),
-            "gemm_proj": (2.0 * M * D * D, "gemm_pps_kernel<192, EPI_GATE_RES_F32, tag 0>: attention out-projection M=%d N=1152 K=1152, gated fp32 residual RMW" % M),
+            "gemm_proj": (2.0 * M * D * D, "gemm_pwr_kernel<EPI_GATE_RES_F32, tag 0> (12-wave producer/consumer, 256x192): attention out-projection M=%d N=1152 K=1152, gated fp32 residual RMW" % M),
             "gemm_fc1": (2.0 * M * Hm * D, "gemm_pps_kernel<256, EPI_BIAS_GELU_H16>: fc1 M=%d N=4608 K=1152, bias+GELU" % M),
-            "gemm_fc2": (2.0 * M * D * Hm, "gemm_pps_kernel<192, EPI_GATE_RES_F32, tag 1>: fc2 M=%d N=1152 K=4608, gated fp32 residual RMW" % M)}
+            "gemm_fc2": (2.0 * M * D * Hm, "gemm_pwr_kernel<EPI_GATE_RES_F32, tag 1> (12-wave producer/consumer, 256x192): fc2 M=%d N=1152 K=4608, gated fp32 residual RMW" % M)}
     qkv_bytes = M * 3 * D * 2 + M * D * 2      # reads q, k, v once, writes the head outputs
     hbm = {"attn_spatial": (qkv_bytes, 4.0 * B * F * T * T * D, "attn_full_kernel<72>: spatial attention, %d sequences x 16 heads x 256 tokens" % (B * F)),
            "attn_temporal": (qkv_bytes, 4.0 * B * T * F * F * D, "attn_small_kernel<72>: temporal attention, %d sequences x 16 heads x 16 frames" % (B * T)),

@@ -91,8 +91,8 @@ struct GemmArgs {
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
 // 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
-// variant 10 = producer-wave kernel, 256x192 tile, 12 waves (gemm_pw.hip)
-int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, hipStream_t st);
+// variants 10 / 11 = producer-wave kernels, 256x192 tile, 12 waves (gemm_pw.hip): two-segment / rolling schedule
+int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, int roll, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);
 int gemm_auto_variant(int M, int N, int epi);

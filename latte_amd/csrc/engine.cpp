@@ -423,7 +423,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 10) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..10");
+    if (value < 0 || value > 11) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..11");
     const int bn = value >= 7 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
@@ -433,7 +433,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   for (int gi = 0; gi < 4; ++gi) {
     static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
     if (k == names[gi]) {
-      if (value < 0 || value > 10) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..10");
+      if (value < 0 || value > 11) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..11");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }

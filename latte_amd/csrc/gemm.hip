@@ -838,7 +838,7 @@ int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: return 256;
-    case 5: case 8: case 10: return 192;
+    case 5: case 8: case 10: case 11: return 192;
     default: return 128;
   }
 }
@@ -890,10 +890,15 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
 #endif
   if (variant == 0) {
     variant = gemm_auto_variant(a.M, a.N, epi);
+    // the gated read-modify-write GEMMs on 192-wide tiles run on the 12-wave producer / consumer kernel (gemm_pw.hip, rolling
+    // schedule): proj 127 -> 119 us, fc2 316 -> 289 us per launch in the XL/2 forward at B = 8 (same box, round-2 sweep)
+    if (variant == 8 && epi == EPI_GATE_RES_F32 && a.N % 192 == 0 && a.K >= 128 &&
+        (uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 < (1ull << 32) && (uint64_t)a.N * a.K * 2 < (1ull << 32))
+      variant = 11;
     // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
     //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
   }
-  if (variant == 10) return launch_gemm_pw(a, epi, dtype, st);
+  if (variant == 10 || variant == 11) return launch_gemm_pw(a, epi, dtype, variant == 11, st);
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)

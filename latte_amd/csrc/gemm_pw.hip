@@ -23,6 +23,8 @@
 //                      then vmcnt(4): B / A rows 0-127 of K tile v+1 have landed (group 0 reads them in I(2v+2)).
 // The K-tile counter runs across tile boundaries, so the producers never drain; a consumer group runs its epilogue
 // around the barrier that ends its last compute segment (group 1 before, group 0 after it), as in gemm_pps_kernel.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma_util.h"
 
@@ -32,6 +34,19 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_pw;
 __device__ __forceinline__ void pw_bload_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_pw*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// In-place accumulate, pinned by inline assembly: with the fragments carried around the loop (rolling kernel) the register
+// allocator otherwise moves accumulators into fragment registers that have just been freed and ends up spilling three of
+// them per K tile.  The compiler's hazard recogniser does not look inside: no VALU / memory instruction may read an
+// accumulator within 11 wait states of the MFMA that wrote it (the kernel issues two `s_nop 15` before its epilogue), and a
+// fragment register is only ever overwritten by an LDS read, which has no hazard against an MFMA reading it as SrcA / SrcB.
+template <int DT>
+__device__ __forceinline__ void mfma16_ip(f32x4& c, const u32x4& a, const u32x4& b) {
+  if constexpr (DT == LATTE_DTYPE_BF16)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -324,18 +339,338 @@ __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
 #undef LATTE_TS
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Rolling variant (variant 11): the same 12-wave workgroup, but NO load segment at all.  The trace of variant 10 shows what is
+// left once the MFMA waves stop issuing DMA: the two consumer groups still hand the matrix pipe to each other through two
+// barriers per K tile (~190 clocks each, 20 % of the period) because a group's fragment reads sit in their own segment.  Here
+// every consumer wave keeps its MFMA stream going and reads the fragments of the NEXT half K tile (32 deep) between the MFMAs
+// of the current one, each A fragment into the registers the MFMAs just issued have left (B fragments are double-buffered:
+// 24 registers) -- a software pipeline one half-step deep that costs no register beyond variant 10's 56.  Both groups run in
+// lock step (two waves per SIMD share the matrix pipe; a read is consumed ~24 own MFMAs after it was issued), and ONE barrier
+// per K tile -- placed 6 MFMAs into the second half-step, when every read of stage u has been issued long ago -- tells the
+// producers that stage u may be overwritten and the consumers that stage u + 1 has landed.
+//   consumer, K tile u:  h0: MFMAs on first-half fragments | second-half A fragments of u roll in
+//                        h1: 6 MFMAs, lgkmcnt(0), barrier B_u, B first half of u+1, 18 MFMAs | first-half A fragments of u+1
+//                            roll in (lagging two fragment rows), then B second half of u+1
+//   producer:            ... vmcnt(8) [stage u+1 landed], barrier B_u, issue B(u+2) and A(u+3)      (3 A stages, 2 B stages)
+// At a tile boundary the pipeline is drained (no look-ahead reads in the last half-step: the epilogue needs the registers)
+// and refilled from stage u + 1 after the epilogue.
+template <int EPI, int DT, int TAG>
+__global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int NA = 3;
+  constexpr int B_BASE = NA * A_BYTES;
+  constexpr int AH_INSTR = 4, BG_INSTR = 6;
+  constexpr int GROUP_M = 8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = g.K;
+  const unsigned row_bytes = (unsigned)K * 2u;
+
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN, nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+  const int nk = K / 64;
+  const int ntile = (cnt - slot + per - 1) / per;
+  constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
+  if constexpr (TRACE) tstart = tprev = (long long)__builtin_readcyclecounter();
+#define LATTE_TS(IDX)                                                \
+  if constexpr (TRACE) {                                             \
+    const long long now_ = (long long)__builtin_readcyclecounter();  \
+    tacc[IDX] += now_ - tprev;                                       \
+    tprev = now_;                                                    \
+  }
+  auto trace_out = [&](int n_it) {
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && lane == 0) {
+        long long* o = (long long*)g.out + wave * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+        o[6] = (long long)__builtin_readcyclecounter() - tstart;
+        o[7] = n_it;
+      }
+    }
+  };
+
+  if (wave >= 8) {
+    // ================================ producer ================================
+    const int pw = wave - 8;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)tiles_m * BM * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)g.N * row_bytes, 0x00020000);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const unsigned voff = (unsigned)lrow * row_bytes + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
+    unsigned step32 = 32u * row_bytes;
+    asm volatile("" : "+s"(step32));
+    auto dma_a = [&](int tm_, int kt, int stg) {   // all 256 rows: row-groups pw + 4 j, j = 0..7
+      char* sA = smem + stg * A_BYTES + pw * 1024;
+      const unsigned so = (unsigned)(tm_ * BM + pw * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+      for (int j = 0; j < 2 * AH_INSTR; ++j) pw_bload_lds16(rsA, sA + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    auto dma_b = [&](int tn_, int kt, int stg) {
+      char* sB = smem + B_BASE + stg * B_BYTES + pw * 1024;
+      const unsigned so = (unsigned)(tn_ * BN + pw * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+      for (int j = 0; j < BG_INSTR; ++j) pw_bload_lds16(rsB, sB + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    struct Walk { int pos, tm, tn, kt; };
+    auto advance = [&](Walk& w) {
+      if (++w.kt == nk) {
+        w.kt = 0;
+        w.pos += per;
+        if (w.pos < cnt) decode(chunk0 + w.pos, w.tm, w.tn);
+      }
+    };
+    const int U = ntile * nk;
+    Walk wb{slot, 0, 0, 0};
+    decode(chunk0 + slot, wb.tm, wb.tn);
+    Walk wa = wb;
+    // pipeline fill, issue order  B0 A0 | B1 A1 | A2   (U >= 2: K >= 128)
+    dma_b(wb.tn, wb.kt, 0); advance(wb);
+    dma_a(wa.tm, wa.kt, 0); advance(wa);
+    dma_b(wb.tn, wb.kt, 1); advance(wb);
+    dma_a(wa.tm, wa.kt, 1); advance(wa);
+    if (U > 2) { dma_a(wa.tm, wa.kt, 2); wait_vm<BG_INSTR + 4 * AH_INSTR>(); } else { wait_vm<BG_INSTR + 2 * AH_INSTR>(); }
+    advance(wa);                    // wa -> K tile 3, wb -> K tile 2
+    __builtin_amdgcn_s_barrier();   // P: K tile 0 has landed
+    int sa = 0, sb = 0;             // ring slots of K tile u + 3 (A: (u + 3) % 3 = u % 3) and u + 2 (B: u & 1)
+    for (int u = 0; u < U; ++u) {
+      LATTE_TS(5)
+      // stage u + 1 must have landed; the only younger DMA is A(u+2)
+      if (u + 2 < U) wait_vm<2 * AH_INSTR>(); else wait_vm<0>();
+      LATTE_TS(1)
+      __builtin_amdgcn_s_barrier();   // B_u: stage u is free
+      LATTE_TS(2)
+      if (u + 2 < U) dma_b(wb.tn, wb.kt, sb);
+      if (u + 3 < U) dma_a(wa.tm, wa.kt, sa);
+      LATTE_TS(0)
+      advance(wa);
+      advance(wb);
+      sa = sa == NA - 1 ? 0 : sa + 1;
+      sb ^= 1;
+    }
+    trace_out(U);
+    return;
+  }
+
+  // ================================ consumer ================================
+  const int grp = wave >> 2, wn = wave & 3;
+  const int sw = (lane >> 1) & 7;
+  const int chunkb = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + (lane & 15)) * 128 + chunkb;
+  const int b_off = B_BASE + (wn * WTN + (lane & 15)) * 128 + chunkb;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto epilogue = [&](int tm_, int tn_) {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int fr = le & 15;
+    const int ncol = tn_ * BN + wn * WTN + (le >> 4) * 4;
+    const int mbase = tm_ * BM + grp * 128 + fr;
+    if constexpr (TRACE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      return;
+    }
+    if constexpr (EPI == EPI_GATE_RES_F32) {
+      if ((g.rows_per_sample % BM) == 0) {
+        float* const outp = (float*)g.out;
+        const float* gr = g.gate + (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
+        float4 b4[FN], g1[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          b4[j] = *(const float4*)(g.bias + ncol + j * 16);
+          g1[j] = *(const float4*)(gr + j * 16);
+        }
+        constexpr int NF = 8 * FN, AHEAD = 2;
+        auto frag_ptr = [&](int f) -> float* {
+          const int mc = min(mbase + (f / FN) * 16, g.M - 1);
+          return outp + (size_t)mc * g.N + ncol + (f % FN) * 16;
+        };
+        float4 qa[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) qa[a] = *(const float4*)frag_ptr(a);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          float4 rr = qa[f % AHEAD];
+          if (f + AHEAD < NF) qa[f % AHEAD] = *(const float4*)frag_ptr(f + AHEAD);
+          asm volatile("" ::: "memory");
+          const int i = f / FN, j = f % FN;
+          rr.x += g1[j].x * (acc[i][j][0] + b4[j].x);
+          rr.y += g1[j].y * (acc[i][j][1] + b4[j].y);
+          rr.z += g1[j].z * (acc[i][j][2] + b4[j].z);
+          rr.w += g1[j].w * (acc[i][j][3] + b4[j].w);
+          if (mbase + i * 16 < g.M) *(float4*)(outp + (size_t)(mbase + i * 16) * g.N + ncol + j * 16) = rr;
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = mbase + i * 16;
+      if (m < g.M) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = ncol + j * 16;
+          const float4 b4 = *(const float4*)(g.bias + n);
+          float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+          const size_t o = (size_t)m * g.N + n;
+          if constexpr (EPI == EPI_GATE_RES_F32) {
+            const float4 g4 = *(const float4*)(g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride + n);
+            float4* dst = (float4*)((float*)g.out + o);
+            float4 rr = *dst;
+            rr.x += g4.x * v0; rr.y += g4.y * v1; rr.z += g4.z * v2; rr.w += g4.w * v3;
+            *dst = rr;
+          } else if constexpr (EPI == EPI_BIAS_F32) {
+            *(float4*)((float*)g.out + o) = make_float4(v0, v1, v2, v3);
+          } else {
+            if constexpr (EPI == EPI_BIAS_GELU_H16) {
+              auto gelu = [](float x) {
+                const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+                return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
+              };
+              v0 = gelu(v0); v1 = gelu(v1); v2 = gelu(v2); v3 = gelu(v3);
+            }
+            const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+            *(u32x2*)((half_t*)g.out + o) = p;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  u32x4 bf[2][FN], af[8];
+  auto fill = [&](const char* sA, const char* sB) {   // the complete first half-step and the B fragments of the second
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sB + (b_off + j * 2048));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *(const u32x4*)(sA + (a_off + i * 2048));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[1][j] = *(const u32x4*)(sB + ((b_off + j * 2048) ^ 64));
+  };
+
+  int pos = slot, tm, tn;
+  decode(chunk0 + pos, tm, tn);
+  __builtin_amdgcn_s_barrier();   // P: K tile 0 has landed
+  fill(smem, smem);
+
+  // One K tile of the pipeline; LOOK = read the fragments of stage u + 1 while the second half-step computes.
+  auto ktile = [&](const char* sA, const char* sAn, const char* sBn, auto look) {
+    constexpr bool LOOK = decltype(look)::value;
+    // ---- h0(u): first-half MFMAs, second-half A fragments roll in
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[0][j], af[i]);
+      af[i] = *(const u32x4*)(sA + ((a_off + i * 2048) ^ 64));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    LATTE_TS(0)
+    // ---- h1(u), fragment rows 0-1; then every read of stage u has completed: B_u
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    LATTE_TS(1)
+    __builtin_amdgcn_s_barrier();
+    LATTE_TS(2)
+    if constexpr (LOOK) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sBn + (b_off + j * 2048));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 2; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
+      if constexpr (LOOK) af[i - 2] = *(const u32x4*)(sAn + (a_off + (i - 2) * 2048));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LOOK) {
+      af[6] = *(const u32x4*)(sAn + (a_off + 6 * 2048));
+      af[7] = *(const u32x4*)(sAn + (a_off + 7 * 2048));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[1][j] = *(const u32x4*)(sBn + ((b_off + j * 2048) ^ 64));
+    }
+    LATTE_TS(3)
+  };
+
+  int it = 0, ia = 0;
+  for (;;) {
+    for (int kt = 0; kt + 1 < nk; ++kt, ++it) {
+      const char* sA = smem + ia * A_BYTES;
+      ia = ia == NA - 1 ? 0 : ia + 1;
+      ktile(sA, smem + ia * A_BYTES, smem + ((it + 1) & 1) * B_BYTES, std::true_type{});
+    }
+    {  // last K tile of the output tile: drain, epilogue, refill from stage u + 1 (landed at B_u)
+      const char* sA = smem + ia * A_BYTES;
+      ia = ia == NA - 1 ? 0 : ia + 1;
+      ktile(sA, nullptr, nullptr, std::false_type{});
+      ++it;
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see mfma16_ip)
+      epilogue(tm, tn);
+      LATTE_TS(4)
+    }
+    pos += per;
+    if (pos >= cnt) break;
+    decode(chunk0 + pos, tm, tn);
+    fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
+    LATTE_TS(5)
+  }
+  trace_out(it);
+#undef LATTE_TS
+}
+
 template <int DT>
-int launch_pw_dt(const GemmArgs& a, int epi, hipStream_t st) {
+int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
   constexpr int LDS = 3 * 256 * 128 + 2 * 192 * 128;   // A ring + B ring
   const int tiles = ((a.M + 255) / 256) * (a.N / 192);
   const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;
   dim3 grid(nblk), block(768);
 #define LATTE_PW_CASE(E, T)                                                                          \
   {                                                                                                  \
-    auto kern = gemm_pw_kernel<E, DT, T>;                                                            \
-    static std::atomic<uint64_t> attr_done{0};                                                       \
-    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
-    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+    if (roll) {                                                                                      \
+      auto kern = gemm_pwr_kernel<E, DT, T>;                                                         \
+      static std::atomic<uint64_t> attr_done{0};                                                     \
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;               \
+      hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                             \
+    } else {                                                                                         \
+      auto kern = gemm_pw_kernel<E, DT, T>;                                                          \
+      static std::atomic<uint64_t> attr_done{0};                                                     \
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;               \
+      hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                             \
+    }                                                                                                \
   }
   if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
   else if (epi == EPI_GATE_RES_F32) LATTE_PW_CASE(EPI_GATE_RES_F32, 0)
@@ -354,13 +689,13 @@ int launch_pw_dt(const GemmArgs& a, int epi, hipStream_t st) {
 }  // namespace
 
 // variant 10: limits of the 32-bit buffer offsets and K >= 128 as for the persistent kernel; whole 192-wide tile columns
-int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, hipStream_t st) {
+int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, int roll, hipStream_t st) {
   if (a.N % 192 != 0 || a.K % 64 != 0 || a.K < 128 || a.M <= 0)
     return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): need N % 192 == 0, K % 64 == 0, K >= 128");
   if ((uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 >= (1ull << 32) || (uint64_t)a.N * a.K * 2 >= (1ull << 32))
     return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): operand exceeds the 4 GiB buffer-offset range");
-  if (dtype == LATTE_DTYPE_BF16) return launch_pw_dt<LATTE_DTYPE_BF16>(a, epi, st);
-  if (dtype == LATTE_DTYPE_F16) return launch_pw_dt<LATTE_DTYPE_F16>(a, epi, st);
+  if (dtype == LATTE_DTYPE_BF16) return launch_pw_dt<LATTE_DTYPE_BF16>(a, epi, roll, st);
+  if (dtype == LATTE_DTYPE_F16) return launch_pw_dt<LATTE_DTYPE_F16>(a, epi, roll, st);
   return fail(LATTE_ERR_INVALID, "gemm: unknown dtype");
 }
 

@@ -17,15 +17,15 @@ def dev():
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608), (700, 384, 64),
                                    (8292, 2304, 192), (8292, 2432, 192)])  # last: > 256 tiles, odd K-tile count (persistent kernel))
 def test_gemm_epilogues(lib, dev, dt, variant, shape):
     M, N, K = shape
-    tile_n = {0: 64, 1: 128, 2: 128, 3: 256, 4: 128, 5: 192, 6: 256, 7: 32, 8: 48, 9: 64, 10: 192}[variant]   # 7-9: wave width
+    tile_n = {0: 64, 1: 128, 2: 128, 3: 256, 4: 128, 5: 192, 6: 256, 7: 32, 8: 48, 9: 64, 10: 192, 11: 192}[variant]   # 7-9: wave width
     if N % tile_n:
         pytest.skip(f"tile width {tile_n} does not divide N")
-    if variant >= 7 and K < 128 and (variant == 10 or N % (4 * tile_n)):
+    if variant >= 7 and K < 128 and (variant >= 10 or N % (4 * tile_n)):
         pytest.skip("single K tile: the persistent kernel defers to the plain one, which needs whole tile columns")
     g = torch.Generator("cpu").manual_seed(M + N + K)
     Mp = (M + 255) // 256 * 256
@@ -86,9 +86,9 @@ def test_gemm_gated_residual_call_site_tags(lib, dev, dt):
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("shape", [(4096, 1152, 1152, 4096), (8192, 1152, 4608, 4096), (33000, 1152, 1152, 256), (2304, 384, 256, 256)])
 def test_gemm_producer_wave_kernel(lib, dev, dt, shape):
-    """Variant 10 (12 waves: 8 MFMA waves + 4 DMA waves, gemm_pw.hip) on the gated read-modify-write epilogue's fast path
-    (whole tiles inside one sample), > 256 tiles, a partial last tile row; bit-identical to the 8-wave kernel of the same tile
-    (same MFMA order per output element)."""
+    """Variants 10 / 11 (12 waves: 8 MFMA waves + 4 DMA waves, gemm_pw.hip; two-segment and rolling schedule) on the gated
+    read-modify-write epilogue's fast path (whole tiles inside one sample), > 256 tiles, a partial last tile row; bit-identical
+    to the 8-wave kernel of the same tile (same MFMA order per output element)."""
     M, N, K, rps = shape
     g = torch.Generator("cpu").manual_seed(M + K)
     Mp = (M + 255) // 256 * 256
@@ -99,7 +99,7 @@ def test_gemm_producer_wave_kernel(lib, dev, dt, shape):
     out0 = torch.randn(Mp, N, generator=g).to(dev)
     want = out0[:M] + gate[torch.arange(M, device=dev) // rps, :N] * (A.float()[:M] @ W.float().t() + bias)
     outs = {}
-    for variant in (10, 1010, 8):
+    for variant in (10, 1010, 11, 1011, 8):
         out = out0.clone()
         check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 2 * N, rps, 2, dt, variant,
                                    stream_ptr()))
@@ -107,7 +107,7 @@ def test_gemm_producer_wave_kernel(lib, dev, dt, shape):
         assert float((out[:M] - want).norm() / want.norm()) < 2e-5, variant
         assert torch.equal(out[M:], out0[M:])
         outs[variant] = out
-    assert torch.equal(outs[10], outs[1010]) and torch.equal(outs[10], outs[8])
+    assert all(torch.equal(outs[v], outs[8]) for v in (10, 1010, 11, 1011))
 
 
 CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),

@@ -184,8 +184,8 @@ def gemm_bench():
     for M in (4096, 8192, 32768):
         for (N, K, epi, nm) in [(3456, 1152, 0, "qkv"), (1152, 1152, 2, "proj"), (4608, 1152, 1, "fc1"), (1152, 4608, 2, "fc2")]:
             row = []
-            for variant in (1, 5, 6, 7, 8, 9, 10):
-                if N % {1: 128, 5: 192, 6: 256, 7: 128, 8: 192, 9: 256, 10: 192}[variant]:
+            for variant in (1, 5, 6, 7, 8, 9, 10, 11):
+                if N % {1: 128, 5: 192, 6: 256, 7: 128, 8: 192, 9: 256, 10: 192, 11: 192}[variant]:
                     continue
                 check(lib.latte_bench_gemm(M, N, K, epi, 0, variant, 20, ctypes.byref(ms), stream_ptr()))
                 tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
@@ -257,9 +257,12 @@ def gemm_trace_pw():
     """Measurement build: per-wave phase times of the producer-wave kernel (variant 10, workgroup 0), s_memtime ticks.
     Consumers: L(reads) | barrier-1 wait | C (MFMAs + second-half reads) | epilogue g1 | barrier-2 wait | epilogue g0.
     Producers: DMA issue | vmcnt wait (even interval) | barrier | vmcnt wait (odd, incl. issue) | barrier | bookkeeping."""
-    cn = ["L(reads)", "bar1 wait", "C", "epi(g1)", "bar2 wait", "epi(g0)"]
-    pn = ["DMA issue", "vmcnt even", "bar even", "vmcnt odd", "bar odd", "bookkeep"]
-    for (M, N, K) in [(32768, 1152, 4608), (32768, 1152, 1152), (32768, 4608, 1152)]:
+    names = {10: (["L(reads)", "bar1 wait", "C", "epi(g1)", "bar2 wait", "epi(g0)"],
+                  ["DMA issue", "vmcnt even", "bar even", "vmcnt odd", "bar odd", "bookkeep"]),
+             11: (["h0", "h1 head+lgkm", "barrier", "h1 rest", "epilogue", "refill"],
+                  ["DMA issue", "vmcnt wait", "barrier", "-", "-", "bookkeep"])}
+    for (M, N, K, var) in [(32768, 1152, 4608, 10), (32768, 1152, 4608, 11), (32768, 1152, 1152, 11), (32768, 4608, 1152, 11)]:
+        cn, pn = names[var]
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device=dev)
@@ -268,12 +271,12 @@ def gemm_trace_pw():
         for rep in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 0, M, 12, 0, 10, stream_ptr()))
+            check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 0, M, 12, 0, var, stream_ptr()))
             e1.record()
             torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3
         t = out.view(torch.int64)[:96].cpu().view(12, 8)
-        log(f"trace v10 M={M} N={N} K={K}: launch {us:.1f} us; per-K-tile ticks")
+        log(f"trace v{var} M={M} N={N} K={K}: launch {us:.1f} us; per-K-tile ticks")
         for w in range(12):
             kt = max(int(t[w, 7]), 1)
             nm = cn if w < 8 else pn
@@ -323,7 +326,7 @@ def gemm_in_model():
         t = torch.full((B,), 500, device=dev, dtype=torch.int64)
         for gname, key in (("qkv", "gemm_qkv"), ("proj", "gemm_proj"), ("fc1", "gemm_fc1"), ("fc2", "gemm_fc2")):
             row = []
-            for v in (1, 5, 6, 7, 8, 9, 10):
+            for v in (1, 5, 6, 7, 8, 9, 10, 11):
                 try:
                     m.set_engine_option("gemm_variant_" + gname, v, B)
                     m.profile_forward(x, t)

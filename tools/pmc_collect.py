@@ -26,6 +26,8 @@ def classify(name):
         return "gemm_fc1"
     if "gemm_pps_kernel<192,2," in n:
         return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
+    if "gemm_pwr_kernel<2," in n or "gemm_pw_kernel<2," in n:   # 12-wave kernels: <EPI, DT, TAG>
+        return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
     if "attn_full_kernel" in n:
         return "attn_spatial"
     if "attn_small_kernel" in n:
