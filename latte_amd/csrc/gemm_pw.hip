@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   constexpr int B_BASE = NA * A_BYTES;
   constexpr int AH_INSTR = 4, BG_INSTR = 6;
   constexpr int GROUP_M = 8;
+  constexpr int PATCH_BYTES = 16 * 112;   // wave-private epilogue patch (half-precision outputs): 16 rows, pitch 112 B
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -496,6 +497,47 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      return;
+    }
+    if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
+      // Half-precision outputs: a fragment row (16 rows x 48 columns = 96 B per row) goes through a wave-private LDS patch
+      // (pitch 112 B, behind the operand rings) so that the global stores are 16 B per lane on contiguous 96-byte row
+      // segments: 1.5 store instructions per fragment row instead of 3 with 8 B per lane on 32-byte pieces.
+      char* patch = smem + B_BASE + 2 * B_BYTES + wave * PATCH_BYTES;
+      const int ncol0 = tn_ * BN + wn * WTN;
+      const int gq = le >> 4;
+      float4 b4[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);
+      const int r0 = le / 6, p0 = le - r0 * 6;               // piece le      -> (row, 16-byte piece) of the 16 x 6 grid
+      const int r1 = (le + 64) / 6, p1 = (le + 64) - r1 * 6; // piece le + 64 (lanes 0-31)
+      half_t* const outp = (half_t*)g.out;
+      const int mrow0 = tm_ * BM + grp * 128;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+          if constexpr (EPI == EPI_BIAS_GELU_H16) {
+            auto gelu = [](float x) {
+              const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+              return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
+            };
+            v0 = gelu(v0); v1 = gelu(v1); v2 = gelu(v2); v3 = gelu(v3);
+          }
+          const u32x2 pk = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+          *(u32x2*)(patch + fr * 112 + j * 32 + gq * 8) = pk;
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
+        const int m0_ = mrow0 + i * 16 + r0;
+        if (m0_ < g.M) *(u32x4*)(outp + (size_t)m0_ * g.N + ncol0 + p0 * 8) = w0;
+        if (le < 32) {
+          const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1 * 16);
+          const int m1_ = mrow0 + i * 16 + r1;
+          if (m1_ < g.M) *(u32x4*)(outp + (size_t)m1_ * g.N + ncol0 + p1 * 8) = w1;
+        }
+      }
       return;
     }
     if constexpr (EPI == EPI_GATE_RES_F32) {
@@ -654,7 +696,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
 
 template <int DT>
 int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
-  constexpr int LDS = 3 * 256 * 128 + 2 * 192 * 128;   // A ring + B ring
+  constexpr int LDS = 3 * 256 * 128 + 2 * 192 * 128 + 8 * 16 * 112;   // A ring + B ring + epilogue patches (rolling kernel)
   const int tiles = ((a.M + 255) / 256) * (a.N / 192);
   const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;
   dim3 grid(nblk), block(768);
