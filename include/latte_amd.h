@@ -189,6 +189,42 @@ int latte_training_losses(const latte_schedule_t* s, int loss_type, const float*
                           const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw, float* workspace,
                           int64_t workspace_floats, float* mse_out, float* vb_out, float* loss_out, void* stream);
 
+/* ------------------------------------------------------------------ training step
+ * Replaces the body of the reference's optimisation loop, train.py:197-236, for the class-conditional / unconditional Latte
+ * (train.py:213-218 refuses text-to-video training):
+ *     x_t = q_sample(x_0, t); terms = diffusion.training_losses(model, x_0, t, dict(y=y)); loss = terms["loss"].mean()
+ *     loss.backward(); clip_grad_norm_(...); opt.step() [torch.optim.AdamW(lr, weight_decay=0), train.py:127]; update_ema(...)
+ * on device buffers.  Parameters, gradients, AdamW moments and the EMA live in caller-owned FLAT fp32 device buffers of
+ * latte_trainer_total_numel() floats; tensor i (reference named_parameters() order, latte.py:226-255, without the frozen
+ * pos_embed / temp_embed tables, which latte_trainer_set_frozen supplies) occupies [offset_i, offset_i + numel_i) in reference
+ * shape.  The data-parallel driver (train.py:125 DDP) all-reduces the gradient buffer between latte_trainer_forward_backward
+ * and latte_trainer_optimizer_step; nothing here communicates.  MFMA operands are half copies (cfg->compute_dtype) of the fp32
+ * masters, fp32 accumulation, fp32 residual stream / LayerNorm / softmax statistics / loss. */
+typedef struct latte_trainer latte_trainer_t;
+int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_trainer_t** out);
+void latte_trainer_destroy(latte_trainer_t* e);
+int latte_trainer_num_params(const latte_trainer_t* e);
+const char* latte_trainer_param_key(const latte_trainer_t* e, int i);
+int64_t latte_trainer_param_offset(const latte_trainer_t* e, int i);
+int64_t latte_trainer_param_numel(const latte_trainer_t* e, int i);
+int64_t latte_trainer_total_numel(const latte_trainer_t* e);
+/* device pointers; ema may be NULL (no EMA update) */
+int latte_trainer_bind(latte_trainer_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema);
+int latte_trainer_set_frozen(latte_trainer_t* e, const float* pos_embed, const float* temp_embed, int on_device, void* stream);
+/* re-packs the half operand copies from the fp32 masters (after the caller changed the parameter buffer, e.g. load_state_dict) */
+int latte_trainer_sync_weights(latte_trainer_t* e, void* stream);
+/* One micro-batch: forward with saved activations, loss terms, backward; the gradient of terms["loss"].mean() is ASSIGNED to the
+ * bound gradient buffer (label-table rows are accumulated: the optimiser step leaves the buffer zeroed).  x_start / noise
+ * [batch, F, C, H, W] fp32, t int64[batch] RESPACED indices, y int64[batch] labels AFTER the caller's label dropout
+ * (LabelEmbedder.token_drop, latte.py:138-153: dropped labels = num_classes) or NULL, loss_type 0 MSE | 1 RESCALED_MSE,
+ * terms_out device float [3][batch] = loss, mse, vb; model_out_copy optional [batch, F, C_out, H, W]. */
+int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
+                                   const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream);
+/* clip_grad_norm_ (utils.py:72-117: total 2-norm, g *= min(max_norm / (norm + 1e-6), 1) when clip != 0) + AdamW + update_ema
+ * (utils.py:191-200) on the bound buffers; step counts from 1; norm_out: optional device float[2] = {norm, applied coefficient} */
+int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float clip_max_norm, int clip, float ema_decay, float* norm_out, void* stream);
+
 /* ------------------------------------------------------------------ VAE decoder
  * Replaces diffusers.AutoencoderKL (sample/sample.py:69 from_pretrained, :113-115 vae.decode(z / 0.18215).sample;
  * sample_ddp.py:90,165-168) for the stabilityai/sd-vae-ft-* architecture: latent_channels 4,

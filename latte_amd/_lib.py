@@ -68,6 +68,18 @@ PROTOTYPES = {
     "latte_training_workspace_floats": (c_i64, [c_int, c_i64]),
     "latte_training_losses": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void,
                                       c_i64, c_void, c_void, c_void, c_void]),
+    "latte_trainer_create": (c_int, [ctypes.POINTER(ModelConfig), c_int, ctypes.POINTER(c_void)]),
+    "latte_trainer_destroy": (None, [c_void]),
+    "latte_trainer_num_params": (c_int, [c_void]),
+    "latte_trainer_param_key": (c_char, [c_void, c_int]),
+    "latte_trainer_param_offset": (c_i64, [c_void, c_int]),
+    "latte_trainer_param_numel": (c_i64, [c_void, c_int]),
+    "latte_trainer_total_numel": (c_i64, [c_void]),
+    "latte_trainer_bind": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
+    "latte_trainer_set_frozen": (c_int, [c_void, c_void, c_void, c_int, c_void]),
+    "latte_trainer_sync_weights": (c_int, [c_void, c_void]),
+    "latte_trainer_forward_backward": (c_int, [c_void, c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void]),
+    "latte_trainer_optimizer_step": (c_int, [c_void, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_int, c_f32, c_void, c_void]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),

@@ -26,6 +26,9 @@ struct latte_schedule {
 enum DevTable : int { DT_SQRT_AC = 0, DT_SQRT_1MAC, DT_COEF1, DT_COEF2, DT_POST_LOGVAR, DT_LOG_BETAS, DT_SQRT_RECIP, DT_SQRT_RECIPM1,
                       DT_FIXED_LOGVAR, LATTE_NUM_DEV_TABLES };
 
+// fp32 device copies of a schedule's tables (engine.cpp), [LATTE_NUM_DEV_TABLES][num_timesteps]
+extern "C" int schedule_device_tables(const latte_schedule_t* s, const float** out, hipStream_t st);
+
 namespace latte {
 
 // ---- error plumbing -------------------------------------------------------------------------
@@ -86,6 +89,8 @@ struct GemmArgs {
   int group_m;        // persistent kernel: tile rows walked together by the grouped tile order (0 = 8)
   int rmw_mode;       // measurement build only: look-ahead depth + 16 * non-temporal loads of the read-modify-write epilogue
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
+  int k_chunk;        // plain kernels (variants 1-3) only: > 0 splits the contraction, grid.y = ceil(K / k_chunk) partial products
+  long split_stride;  // ... written to (float*)out + blockIdx.y * split_stride (use EPI_BIAS_F32 with a zero bias)
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
@@ -178,6 +183,41 @@ int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* o
 int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st);
 int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st);
 int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t st);
+
+// ---- training-step kernels (train.hip, train_attn.hip) --------------------------------------------------------------
+int train_rows_per_run(int rps);
+int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, int M, int D, int rps,
+                     int dtype, hipStream_t st);
+int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
+                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st);
+int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_stride, const float* dx_in, float* dx_out, float* partial,
+                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st);
+int launch_gelu_fwd(const half_t* u, half_t* h, size_t n, int dtype, hipStream_t st);
+int launch_gelu_bwd(const half_t* u, const half_t* dh, half_t* du, size_t n, int dtype, hipStream_t st);
+int colsum_chunks(int M);
+int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* out, int accumulate, int dtype, hipStream_t st);
+int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st);
+int launch_transpose_half(const half_t* in, half_t* out, int M, int C, int ldo, hipStream_t st);
+int launch_pack_weight(const float* w, half_t* wn, half_t* wt, int N, int K, int dtype, hipStream_t st);
+int launch_naive_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, int M, int N,
+                      int K, float alpha, int accumulate, hipStream_t st, int splits = 1, float* ws = nullptr);
+int launch_tfreq(const int64_t* t, float* out, int B, hipStream_t st);
+int launch_gather_i64(const int64_t* table, const int64_t* idx, int64_t* out, int n, hipStream_t st);
+int launch_unpatchify_bwd(const float* dout, float* dtok, int BF, int G, int p, int Cout, hipStream_t st);
+int launch_im2col_patch(const float* x, float* pix, int BF, int G, int p, int C, hipStream_t st);
+int launch_embedding_bwd(const float* dc, const int64_t* idx, float* dtable, int B, int D, hipStream_t st);
+int launch_silu_bwd(const float* dout, const float* pre, float* din, size_t n, int accumulate, hipStream_t st);
+int launch_add_rows(float* dst, const float* src, size_t n, hipStream_t st);
+int launch_rows_sum(const float* in, int B, long stride, int N, float* out, int accumulate, hipStream_t st);
+int launch_loss_grad(const float* tables, int n_steps, int mean_type, int var_type, const float* x_start, const float* x_t,
+                     const float* noise, const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw,
+                     float vb_scale, float* dmodel_out, hipStream_t st);
+int sumsq_blocks();
+int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, hipStream_t st);
+int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                     int step, float ema_decay, const float* stats, hipStream_t st);
+int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout, half_t* dqkv, float* stats, int num_seq, int L, int heads,
+                         int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, hipStream_t st);
 
 struct SamplerCoefs {  // fp32 values of the fp64 tables at the step (gaussian_diffusion.py:869-881)
   float min_log, max_log, sqrt_recip, sqrt_recipm1, coef1, coef2;

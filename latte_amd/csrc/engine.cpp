@@ -674,7 +674,7 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
 }
 
 // fp32 device copies of the schedule tables for the batched-timestep kernels (one device per schedule object)
-static int schedule_device_tables(const latte_schedule_t* s, const float** out, hipStream_t st) {
+int schedule_device_tables(const latte_schedule_t* s, const float** out, hipStream_t st) {
   int dev = 0;
   LATTE_HIP(hipGetDevice(&dev));
   const int n = s->num_timesteps;

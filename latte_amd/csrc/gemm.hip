@@ -93,14 +93,22 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
   tile_coords((g.M + BM - 1) / BM, g.N / BN, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int K = g.K;
+  // split K (weight-gradient GEMMs: few output tiles, a very long contraction): blockIdx.y owns K range
+  // [y k_chunk, (y + 1) k_chunk) and writes its partial product to out + y * split_stride (EPI_BIAS_F32, bias = 0)
+  int k_begin = 0, k_len = K;
+  if (g.k_chunk > 0) {
+    k_begin = blockIdx.y * g.k_chunk;
+    k_len = min(g.k_chunk, K - k_begin);
+    g.out = (void*)((float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride);
+  }
 
   // ---- staging addresses: lane i of a wave-instruction fills LDS bytes [16 i, 16 i + 16) of an
   // 8-row group; it must therefore FETCH the chunk that belongs at that (row, chunk-position).
   const int lrow = lane >> 3, cpos = lane & 7;
   const int srow = wave * 8 + lrow;                       // tile row handled by instruction 0
   const int schunk = cpos ^ ((srow >> 1) & 7);            // same for every instruction (NW*8 % 16 == 0)
-  const half_t* a_src = g.A + (size_t)(m0 + srow) * K + schunk * 8;
-  const half_t* b_src = g.W + (size_t)(n0 + srow) * K + schunk * 8;
+  const half_t* a_src = g.A + (size_t)(m0 + srow) * K + schunk * 8 + k_begin;
+  const half_t* b_src = g.W + (size_t)(n0 + srow) * K + schunk * 8 + k_begin;
   const size_t jstride = (size_t)NW * 8 * K;
 
   auto stage = [&](int buf, int kt) {
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / 64;
+  const int nk = k_len / 64;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed (own DMA drained, then everybody's via the barrier); the barrier also
@@ -166,7 +174,9 @@ template <int BM, int BN, int WGM, int WGN, int DT>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  dim3 grid(tiles), block(WGM * WGN * 64);
+  const int splits = a.k_chunk > 0 ? (a.K + a.k_chunk - 1) / a.k_chunk : 1;
+  if (a.k_chunk % 64) return fail(LATTE_ERR_INVALID, "gemm: k_chunk must be a multiple of 64");
+  dim3 grid(tiles, splits), block(WGM * WGN * 64);
 #define LATTE_GEMM_CASE(E)                                                                           \
   case E: {                                                                                          \
     auto kern = gemm_kernel<BM, BN, WGM, WGN, E, DT>;                                                \

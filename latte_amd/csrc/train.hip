@@ -1,0 +1,754 @@
+// Kernels of the training step (round 2): everything of forward-with-saved-activations,
+// backward and the optimiser that is NOT a big GEMM or the attention backward (train_attn.hip).
+//
+//   loss gradient      d mean(terms["loss"]) / d model_output                      gaussian_diffusion.py:719-795
+//   gated residual     x' = x + gate * y  (training forward keeps y)               latte.py:179-180
+//   its backward       dy = gate * dx (half), dgate[s] = sum_rows dx * y
+//   LN + modulate bwd  dx, dshift[s], dscale[s]                                    latte.py:28-29,166,168
+//   GELU(tanh)         h = gelu(u);  du = dh * gelu'(u)                            latte.py:170
+//   column sums        bias gradients  db[n] += sum_m dy[m, n]
+//   transposes         half [M, C] -> [C, M]: operands of the weight-gradient GEMMs (dW = dY^T X)
+//   split reduce       dW (+)= sum of the split-K partial products
+//   small GEMMs        strided fp32 (adaLN / embedder / final-layer linears with <= 64 rows or <= 32 columns)
+//   unpatchify^-1, im2col of the patch embed, label-table scatter, SiLU backward
+//   AdamW + EMA        torch.optim.AdamW(lr, weight_decay = 0) + update_ema        train.py:127,233-236, utils.py:191-200
+//   grad norm / clip   clip_grad_norm_                                              utils.py:72-117
+//
+// Row-wise kernels use one wave per token row (lane owns the float4 chunks {lane + 64 c} of the row, as ln_modulate_kernel);
+// per-sample column reductions (dshift / dscale / dgate) are two-stage and deterministic: a wave walks a run of consecutive
+// rows of ONE sample and writes one partial row, a finalize kernel adds the partial rows in a fixed order.
+#include <cmath>
+
+#include "common.h"
+
+namespace latte {
+namespace {
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int DT>
+__device__ __forceinline__ unsigned int pack2t(float lo, float hi) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+  }
+}
+template <int DT>
+__device__ __forceinline__ float h2f(unsigned short h) {
+  if constexpr (DT == LATTE_DTYPE_BF16) return __builtin_bit_cast(float, (unsigned int)h << 16);
+  else return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int DT>
+__device__ __forceinline__ void unpack4(const uint2 p, float& a, float& b, float& c, float& d) {
+  a = h2f<DT>((unsigned short)(p.x & 0xffffu)); b = h2f<DT>((unsigned short)(p.x >> 16));
+  c = h2f<DT>((unsigned short)(p.y & 0xffffu)); d = h2f<DT>((unsigned short)(p.y >> 16));
+}
+
+constexpr int NQ_MAX = 5;   // float4 chunk groups per lane: D <= 1280
+
+// ---------------------------------------------------------------------------------------------- gated residual, forward
+template <int DT>
+__global__ void __launch_bounds__(256) gated_add_kernel(const float* __restrict__ x_in, const half_t* __restrict__ y,
+                                                        const float* __restrict__ gate, int gate_stride, float* __restrict__ x_out,
+                                                        int M, int D, int rps) {
+  const int nt = D >> 2;
+  const size_t total = (size_t)M * nt;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / nt), c = (int)(i % nt);
+    const float4 xv = ((const float4*)x_in)[i];
+    const float4 g = ((const float4*)(gate + (size_t)(row / rps) * gate_stride))[c];
+    float a, b, cc, d;
+    unpack4<DT>(((const uint2*)y)[i], a, b, cc, d);
+    ((float4*)x_out)[i] = make_float4(xv.x + g.x * a, xv.y + g.y * b, xv.z + g.z * cc, xv.w + g.w * d);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- gated residual, backward
+// one wave per run of R consecutive rows of one sample: dy = gate * dx (half), partial[run][col] = sum_rows dx * y
+template <int DT>
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ dx, const half_t* __restrict__ y,
+                                                       const float* __restrict__ gate, int gate_stride, half_t* __restrict__ dy,
+                                                       float* __restrict__ partial, int M, int D, int rps, int R) {
+  const int lane = threadIdx.x & 63;
+  const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = run * R;
+  if (row0 >= M) return;
+  const int nt = D >> 2;
+  const float4* g4 = (const float4*)(gate + (size_t)(row0 / rps) * gate_stride);
+  float4 g[NQ_MAX], acc[NQ_MAX];
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    g[c] = ch < nt ? g4[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = 0; r < R; ++r) {
+    const size_t ro = (size_t)(row0 + r) * nt;
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch < nt) {
+        const float4 d = ((const float4*)dx)[ro + ch];
+        float a, b, cc, e;
+        unpack4<DT>(((const uint2*)y)[ro + ch], a, b, cc, e);
+        acc[c].x += d.x * a; acc[c].y += d.y * b; acc[c].z += d.z * cc; acc[c].w += d.w * e;
+        uint2 o;
+        o.x = pack2t<DT>(g[c].x * d.x, g[c].y * d.y);
+        o.y = pack2t<DT>(g[c].z * d.z, g[c].w * d.w);
+        ((uint2*)dy)[ro + ch] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nt) ((float4*)(partial + (size_t)run * D))[ch] = acc[c];
+  }
+}
+
+// out[s * out_stride + col] = sum over the runs of sample s of partial[run][which][col]   (nsum partial rows per run)
+__global__ void sample_colsum_finalize_kernel(const float* __restrict__ partial, int runs_per_sample, int nsum, int which, int D,
+                                              float* __restrict__ out, int out_stride) {
+  const int s = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D) return;
+  float a = 0.f;
+  for (int r = 0; r < runs_per_sample; ++r) a += partial[(((size_t)s * runs_per_sample + r) * nsum + which) * D + col];
+  out[(size_t)s * out_stride + col] = a;
+}
+
+// ---------------------------------------------------------------------------------------------- LN + modulate, backward
+// y = LN(x) (1 + scale) + shift.  Given dy (half):  dshift = sum dy, dscale = sum dy * xhat (per sample),
+// dxhat = dy (1 + scale),  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)),  dx_out = dx_in + dx.
+template <int DT>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ scale, int mod_stride, const float* dx_in,
+                                                     float* dx_out, float* __restrict__ partial, int M, int D, int rps, int R) {
+  const int lane = threadIdx.x & 63;
+  const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = run * R;
+  if (row0 >= M) return;
+  const int nt = D >> 2;
+  const float invD = 1.0f / (float)D;
+  const float4* sc4 = (const float4*)(scale + (size_t)(row0 / rps) * mod_stride);
+  float4 sc[NQ_MAX], a_sh[NQ_MAX], a_sc[NQ_MAX];
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    sc[c] = ch < nt ? sc4[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    a_sh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a_sc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = 0; r < R; ++r) {
+    const size_t ro = (size_t)(row0 + r) * nt;
+    float4 v[NQ_MAX], g[NQ_MAX];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      v[c] = ch < nt ? ((const float4*)x)[ro + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    }
+    const float mean = wave_sum_t(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      if (c * 64 + lane < nt) {
+        v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
+        q += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_t(q) * invD + 1e-6f);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ch < nt) {
+        v[c].x *= rstd; v[c].y *= rstd; v[c].z *= rstd; v[c].w *= rstd;       // xhat
+        float a, b, cc, e;
+        unpack4<DT>(((const uint2*)dy)[ro + ch], a, b, cc, e);
+        a_sh[c].x += a; a_sh[c].y += b; a_sh[c].z += cc; a_sh[c].w += e;
+        a_sc[c].x += a * v[c].x; a_sc[c].y += b * v[c].y; a_sc[c].z += cc * v[c].z; a_sc[c].w += e * v[c].w;
+        g[c] = make_float4(a * (1.0f + sc[c].x), b * (1.0f + sc[c].y), cc * (1.0f + sc[c].z), e * (1.0f + sc[c].w));   // dxhat
+        m1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
+        m2 += (g[c].x * v[c].x + g[c].y * v[c].y) + (g[c].z * v[c].z + g[c].w * v[c].w);
+      }
+    }
+    m1 = wave_sum_t(m1) * invD;
+    m2 = wave_sum_t(m2) * invD;
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch < nt) {
+        float4 o = make_float4(rstd * (g[c].x - m1 - v[c].x * m2), rstd * (g[c].y - m1 - v[c].y * m2),
+                               rstd * (g[c].z - m1 - v[c].z * m2), rstd * (g[c].w - m1 - v[c].w * m2));
+        if (dx_in) {
+          const float4 p = ((const float4*)dx_in)[ro + ch];
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        ((float4*)dx_out)[ro + ch] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nt) {
+      ((float4*)(partial + ((size_t)run * 2 + 0) * D))[ch] = a_sh[c];
+      ((float4*)(partial + ((size_t)run * 2 + 1) * D))[ch] = a_sc[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- GELU(tanh)
+// gelu(x) = x s(x), s = sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3);  gelu'(x) = s + x s (1 - s) 2 u',  u' = sqrt(2/pi)(1 + 3*0.044715 x^2)
+__device__ __forceinline__ float gelu_sig(float x) {
+  const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);     // -2 log2(e) sqrt(2/pi) (1 + 0.044715 x^2)
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
+}
+template <int DT, bool BWD>
+__global__ void __launch_bounds__(256) gelu_kernel(const half_t* __restrict__ u, const half_t* __restrict__ dh, half_t* __restrict__ out,
+                                                   size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float x[4];
+    unpack4<DT>(((const uint2*)u)[i], x[0], x[1], x[2], x[3]);
+    float o[4];
+    if constexpr (BWD) {
+      float d[4];
+      unpack4<DT>(((const uint2*)dh)[i], d[0], d[1], d[2], d[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float s = gelu_sig(x[k]);
+        const float du = 0.7978845608f * (1.0f + 0.134145f * x[k] * x[k]);
+        o[k] = d[k] * (s + x[k] * s * (1.0f - s) * 2.0f * du);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = x[k] * gelu_sig(x[k]);
+    }
+    uint2 p;
+    p.x = pack2t<DT>(o[0], o[1]);
+    p.y = pack2t<DT>(o[2], o[3]);
+    ((uint2*)out)[i] = p;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- column sums of a half matrix
+// partial[chunk][col] = sum over the chunk's rows of in[row][col]; tile = 128 columns x CS_ROWS rows per block
+constexpr int CS_ROWS = 512;
+template <int DT>
+__global__ void __launch_bounds__(256) colsum_half_kernel(const half_t* __restrict__ in, int M, int C, float* __restrict__ partial) {
+  __shared__ float red[16][128];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int col0 = blockIdx.x * 128 + tx * 8;
+  const int r0 = blockIdx.y * CS_ROWS;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col0 < C) {
+    const int rend = min(r0 + CS_ROWS, M);
+    for (int r = r0 + ty; r < rend; r += 16) {
+      const uint4 p = *(const uint4*)(in + (size_t)r * C + col0);
+      float v[8];
+      unpack4<DT>(make_uint2(p.x, p.y), v[0], v[1], v[2], v[3]);
+      unpack4<DT>(make_uint2(p.z, p.w), v[4], v[5], v[6], v[7]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[ty][tx * 8 + k] = a[k];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x];
+    const int col = blockIdx.x * 128 + threadIdx.x;
+    if (col < C) partial[(size_t)blockIdx.y * C + col] = s;
+  }
+}
+// out[i] (+)= sum_s partial[s * stride + i]
+__global__ void split_reduce_kernel(const float* __restrict__ partial, int splits, size_t stride, size_t n, float* __restrict__ out,
+                                    int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float a = accumulate ? out[i] : 0.f;
+    for (int s = 0; s < splits; ++s) a += partial[(size_t)s * stride + i];
+    out[i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- half transpose [M, C] -> [C, ldo]
+__global__ void __launch_bounds__(256) transpose_half_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int M, int C,
+                                                             int ldo) {
+  __shared__ unsigned short tile[64][66];
+  const int m0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  // load 64 rows x 64 columns (8 chunks of 16 B per row): 512 chunks, 2 per thread
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = threadIdx.x + 256 * k;
+    const int r = id >> 3, ch = id & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (m0 + r < M && c0 + ch * 8 < C) v = *(const uint4*)(in + (size_t)(m0 + r) * C + c0 + ch * 8);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tile[r][ch * 8 + 2 * e] = (unsigned short)(w[e] & 0xffffu);
+      tile[r][ch * 8 + 2 * e + 1] = (unsigned short)(w[e] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = threadIdx.x + 256 * k;
+    const int c = id >> 3, ch = id & 7;          // output row c (a column of the input), 8 consecutive m
+    if (c0 + c < C && m0 + ch * 8 < M) {
+      unsigned int w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = (unsigned int)tile[ch * 8 + 2 * e][c] | ((unsigned int)tile[ch * 8 + 2 * e + 1][c] << 16);
+      *(uint4*)(out + (size_t)(c0 + c) * ldo + m0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+// fp32 [N, K] master weight -> half [N, K] and half [K, N] (the operand of the input-gradient GEMM dX = dY W)
+template <int DT>
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, half_t* __restrict__ wn, half_t* __restrict__ wt,
+                                                          int N, int K) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    float v = 0.f;
+    if (n0 + r < N && k0 + tx < K) v = w[(size_t)(n0 + r) * K + k0 + tx];
+    tile[r][tx] = v;
+    if (wn && n0 + r < N && k0 + tx < K) {
+      const unsigned int p = pack2t<DT>(v, 0.f);
+      wn[(size_t)(n0 + r) * K + k0 + tx] = (half_t)(p & 0xffffu);
+    }
+  }
+  __syncthreads();
+  if (wt) {
+    for (int r = ty; r < 32; r += 8) {
+      if (k0 + r < K && n0 + tx < N) {
+        const unsigned int p = pack2t<DT>(tile[tx][r], 0.f);
+        wt[(size_t)(k0 + r) * N + n0 + tx] = (half_t)(p & 0xffffu);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- strided fp32 GEMM (small shapes)
+// C[m scm + n scn] (+)= alpha * sum_k A[m sam + k sak] * B[k sbk + n sbn];  threads run along n.  k_chunk > 0: blockIdx.z owns
+// the K range [z k_chunk, (z + 1) k_chunk) and ASSIGNS its partial product to C + z * c_split_stride (reduce afterwards).
+__global__ void __launch_bounds__(256) naive_gemm_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
+                                                         long sbk, long sbn, float* __restrict__ C, long scm, long scn, int M, int N,
+                                                         int K, float alpha, int accumulate, int k_chunk, long c_split_stride) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (n >= N || m >= M) return;
+  int k0 = 0, k1 = K;
+  if (k_chunk > 0) {
+    k0 = blockIdx.z * k_chunk;
+    k1 = min(K, k0 + k_chunk);
+    C += (size_t)blockIdx.z * c_split_stride;
+  }
+  const float* a = A + (size_t)m * sam;
+  const float* b = B + (size_t)n * sbn;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    s0 += a[(size_t)k * sak] * b[(size_t)k * sbk];
+    s1 += a[(size_t)(k + 1) * sak] * b[(size_t)(k + 1) * sbk];
+    s2 += a[(size_t)(k + 2) * sak] * b[(size_t)(k + 2) * sbk];
+    s3 += a[(size_t)(k + 3) * sak] * b[(size_t)(k + 3) * sbk];
+  }
+  for (; k < k1; ++k) s0 += a[(size_t)k * sak] * b[(size_t)k * sbk];
+  const float r = alpha * ((s0 + s1) + (s2 + s3));
+  float* c = C + (size_t)m * scm + (size_t)n * scn;
+  *c = (accumulate && k_chunk == 0) ? *c + r : r;
+}
+
+__global__ void tfreq_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B) {
+  // timestep_embedding (latte.py:96-117): [cos(t f_i), sin(t f_i)], f_i = exp(-ln(10000) i / 128), 256 columns
+  const int b = blockIdx.x, i = threadIdx.x;   // 128 threads
+  const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+  const float a = (float)t[b] * f;
+  out[(size_t)b * 256 + i] = cosf(a);
+  out[(size_t)b * 256 + 128 + i] = sinf(a);
+}
+__global__ void gather_i64_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ idx, int64_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = table[idx[i]];
+}
+
+// ---------------------------------------------------------------------------------------------- token <-> latent layout helpers
+// dtok[m][(p q c)] = dout[bf][c][gh p_ + p][gw p_ + q]   (inverse of unpatchify, latte.py:297-310), m = bf * T + gh * G + gw
+__global__ void unpatchify_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtok, int BF, int G, int p, int Cout) {
+  const int P = p * p * Cout, H = G * p;
+  const size_t total = (size_t)BF * G * G * P;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int j = (int)(i % P);
+    const size_t m = i / P;
+    const int gw = (int)(m % G), gh = (int)((m / G) % G);
+    const size_t bf = m / ((size_t)G * G);
+    const int c = j % Cout, q = (j / Cout) % p, pp = j / (Cout * p);
+    dtok[i] = dout[((bf * Cout + c) * H + gh * p + pp) * H + gw * p + q];
+  }
+}
+// pix[m][(c p q)] = x[bf][c][gh p_ + p][gw p_ + q]  (the Conv2d(k = s = p) patch of token m, x_embedder.proj.weight order)
+__global__ void im2col_patch_kernel(const float* __restrict__ x, float* __restrict__ pix, int BF, int G, int p, int C) {
+  const int P = C * p * p, H = G * p;
+  const size_t total = (size_t)BF * G * G * P;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int j = (int)(i % P);
+    const size_t m = i / P;
+    const int gw = (int)(m % G), gh = (int)((m / G) % G);
+    const size_t bf = m / ((size_t)G * G);
+    const int q = j % p, pp = (j / p) % p, c = j / (p * p);
+    pix[i] = x[((bf * C + c) * H + gh * p + pp) * H + gw * p + q];
+  }
+}
+// dtable[idx[b]][:] += dc[b][:]  (serial over b: a label may repeat)
+__global__ void embedding_bwd_kernel(const float* __restrict__ dc, const int64_t* __restrict__ idx, float* __restrict__ dtable, int B,
+                                     int D) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D) return;
+  for (int b = 0; b < B; ++b) dtable[(size_t)idx[b] * D + col] += dc[(size_t)b * D + col];
+}
+// din[i] = dout[i] * silu'(pre[i]),  silu'(x) = s (1 + x (1 - s)),  s = sigmoid(x)
+__global__ void silu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pre, float* __restrict__ din, size_t n,
+                                int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float x = pre[i];
+    const float s = 1.0f / (1.0f + __expf(-x));
+    const float v = dout[i] * (s * (1.0f + x * (1.0f - s)));
+    din[i] = accumulate ? din[i] + v : v;
+  }
+}
+__global__ void add_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+// out[col] (+)= sum_b in[b * stride + col]
+__global__ void rows_sum_kernel(const float* __restrict__ in, int B, long stride, int N, float* __restrict__ out, int accumulate) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float a = accumulate ? out[col] : 0.f;
+  for (int b = 0; b < B; ++b) a += in[(size_t)b * stride + col];
+  out[col] = a;
+}
+
+// ---------------------------------------------------------------------------------------------- loss gradient
+// d/d model_output of  mean_b( mse_b + vb_scale * vb_b ),  mse_b = mean_flat((target - eps)^2),
+// vb_b = mean_flat(t == 0 ? decoder NLL : KL) / ln 2 evaluated on cat([eps.detach(), v])  (gaussian_diffusion.py:743-787):
+// the eps channels get the MSE gradient only, the variance channels the bound's.
+__device__ __forceinline__ float cdf_approx(float x) {
+  return 0.5f * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float cdf_approx_grad(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float th = tanhf(u);
+  return 0.5f * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 0.134145f * x * x);
+}
+__global__ void __launch_bounds__(256) loss_grad_kernel(const float* __restrict__ tab, int n_steps, int mean_type, int var_type,
+                                                        const float* __restrict__ x0, const float* __restrict__ xt,
+                                                        const float* __restrict__ noise, const float* __restrict__ mo,
+                                                        const int64_t* __restrict__ t, int batch, int frames, int C, int hw,
+                                                        float vb_scale, float* __restrict__ dmo) {
+  const int b = blockIdx.y;
+  const int ti = (int)t[b];
+  const float coef1 = tab[DT_COEF1 * n_steps + ti], coef2 = tab[DT_COEF2 * n_steps + ti];
+  const float plv = tab[DT_POST_LOGVAR * n_steps + ti], lb = tab[DT_LOG_BETAS * n_steps + ti];
+  const float srec = tab[DT_SQRT_RECIP * n_steps + ti], srecm1 = tab[DT_SQRT_RECIPM1 * n_steps + ti];
+  const size_t chw = (size_t)C * hw, per = (size_t)frames * chw;
+  const int Cm = var_type == 0 ? 2 * C : C;
+  const float wmse = 2.0f / ((float)per * (float)batch);
+  const float wvb = vb_scale / ((float)per * (float)batch * 0.6931471805599453f);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) {
+    const size_t f = e / chw, r = e % chw;
+    const size_t i = (size_t)b * per + e;
+    const size_t o = (((size_t)b * frames + f) * Cm) * hw + r;
+    const float pred = mo[o];
+    const float xs = x0[i], xv = xt[i];
+    const float target = mean_type == 1 ? xs : noise[i];
+    dmo[o] = wmse * (pred - target);
+    if (var_type == 0) {
+      const float v = mo[o + chw];
+      const float frac = (v + 1.0f) / 2.0f;
+      const float lv = frac * lb + (1.0f - frac) * plv;
+      const float x0p = mean_type == 1 ? pred : srec * xv - srecm1 * pred;
+      const float mean = coef1 * x0p + coef2 * xv;
+      float dlv;
+      if (ti != 0) {
+        const float dm = (coef1 * xs + coef2 * xv) - mean;
+        dlv = 0.5f * (1.0f - expf(plv - lv) - dm * dm * expf(-lv));
+      } else {
+        const float centered = xs - mean;
+        const float inv_stdv = expf(-(0.5f * lv));
+        const float pin = inv_stdv * (centered + 0.00392156862745098f), min_ = inv_stdv * (centered - 0.00392156862745098f);
+        const float cp = cdf_approx(pin), cm = cdf_approx(min_);
+        // d/d log_scale of the selected log-probability (d pin / d ls = -pin, d min / d ls = -min)
+        float dls;
+        if (xs < -0.999f) dls = cp > 1e-12f ? cdf_approx_grad(pin) * (-pin) / cp : 0.f;
+        else if (xs > 0.999f) dls = (1.0f - cm) > 1e-12f ? -cdf_approx_grad(min_) * (-min_) / (1.0f - cm) : 0.f;
+        else dls = (cp - cm) > 1e-12f ? (cdf_approx_grad(pin) * (-pin) - cdf_approx_grad(min_) * (-min_)) / (cp - cm) : 0.f;
+        dlv = -0.5f * dls;                                         // term = -log p, log_scale = lv / 2
+      }
+      dmo[o + chw] = wvb * dlv * 0.5f * (lb - plv);                 // d lv / d v = (max_log - min_log) / 2
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- optimiser
+// sum of squares of the flat gradient: partial per block, then a single-block finalize -> norm, clip coefficient
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ partial) {
+  double a = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += (double)g[i] * (double)g[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// stats[0] = total 2-norm, stats[1] = coefficient the optimiser multiplies every gradient with (utils.py:108-114)
+__global__ void gradnorm_finalize_kernel(const double* __restrict__ partial, int blocks, float max_norm, int clip, float* __restrict__ stats) {
+  double a = 0.0;
+  for (int k = 0; k < blocks; ++k) a += partial[k];
+  const float norm = (float)sqrt(a);
+  stats[0] = norm;
+  stats[1] = clip ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+}
+// torch.optim.AdamW single-tensor update + update_ema; g is multiplied by stats[1] first (clipping) and zeroed afterwards
+__global__ void __launch_bounds__(256) adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ ema, size_t n, float lr, float b1,
+                                                        float b2, float eps, float wd, float bc1, float sqrt_bc2, float ema_decay,
+                                                        const float* __restrict__ stats) {
+#pragma clang fp contract(off)
+  const float coef = stats ? stats[1] : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] * b1 + gi * (1.0f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi = pi - (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (ema) ema[i] = ema[i] * ema_decay + pi * (1.0f - ema_decay);
+    g[i] = 0.f;
+  }
+}
+
+inline int blocks_for(size_t n, int cap = 4096) {
+  const size_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? (size_t)cap : b));
+}
+
+}  // namespace
+
+#define LATTE_DT_SWITCH(dtype, CALL)                                    \
+  do {                                                                  \
+    if ((dtype) == LATTE_DTYPE_BF16) { CALL(LATTE_DTYPE_BF16); }        \
+    else if ((dtype) == LATTE_DTYPE_F16) { CALL(LATTE_DTYPE_F16); }     \
+    else return fail(LATTE_ERR_INVALID, "train kernel: unknown dtype"); \
+  } while (0)
+
+int train_rows_per_run(int rps) {
+  for (int r = 64; r > 1; r >>= 1)
+    if (rps % r == 0) return r;
+  return 1;
+}
+
+int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, int M, int D, int rps,
+                     int dtype, hipStream_t st) {
+  if (D % 4) return fail(LATTE_ERR_INVALID, "gated_add: D % 4 != 0");
+#define CALL(DT) hipLaunchKernelGGL(gated_add_kernel<DT>, dim3(blocks_for((size_t)M * D / 4)), dim3(256), 0, st, x_in, y, gate, gate_stride, x_out, M, D, rps)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+// partial: float [M / R][D];  dgate: [B][out_stride] (assigned)
+int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
+                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
+  if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "gate_bwd: need D % 4 == 0 and D <= 1280");
+  const int R = train_rows_per_run(rps), runs = M / R;
+#define CALL(DT) hipLaunchKernelGGL(gate_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dx, y, gate, gate_stride, dy, partial, M, D, rps, R)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 1, 0, D, dgate,
+                     out_stride);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+// partial: float [M / R][2][D];  dshift / dscale: [B][out_stride] (assigned)
+int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_stride, const float* dx_in, float* dx_out, float* partial,
+                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
+  if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "ln_bwd: need D % 4 == 0 and D <= 1280");
+  const int R = train_rows_per_run(rps), runs = M / R;
+#define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 2, 0, D, dshift,
+                     out_stride);
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 2, 1, D, dscale,
+                     out_stride);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_gelu_fwd(const half_t* u, half_t* h, size_t n, int dtype, hipStream_t st) {
+  if (n % 4) return fail(LATTE_ERR_INVALID, "gelu: n % 4 != 0");
+#define CALL(DT) hipLaunchKernelGGL((gelu_kernel<DT, false>), dim3(blocks_for(n / 4, 16384)), dim3(256), 0, st, u, (const half_t*)nullptr, h, n / 4)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_gelu_bwd(const half_t* u, const half_t* dh, half_t* du, size_t n, int dtype, hipStream_t st) {
+  if (n % 4) return fail(LATTE_ERR_INVALID, "gelu: n % 4 != 0");
+#define CALL(DT) hipLaunchKernelGGL((gelu_kernel<DT, true>), dim3(blocks_for(n / 4, 16384)), dim3(256), 0, st, u, dh, du, n / 4)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int colsum_chunks(int M) { return (M + CS_ROWS - 1) / CS_ROWS; }
+// out[col] (+)= sum_m in[m][col];  partial: float [colsum_chunks(M)][C]
+int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* out, int accumulate, int dtype, hipStream_t st) {
+  if (C % 8) return fail(LATTE_ERR_INVALID, "colsum: C % 8 != 0");
+  const int chunks = colsum_chunks(M);
+#define CALL(DT) hipLaunchKernelGGL(colsum_half_kernel<DT>, dim3((C + 127) / 128, chunks), dim3(256), 0, st, in, M, C, partial)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for((size_t)C)), dim3(256), 0, st, partial, chunks, (size_t)C, (size_t)C, out, accumulate);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, partial, splits, stride, n, out, accumulate);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_transpose_half(const half_t* in, half_t* out, int M, int C, int ldo, hipStream_t st) {
+  if (C % 8 || M % 8 || ldo % 8) return fail(LATTE_ERR_INVALID, "transpose_half: dimensions must be multiples of 8");
+  hipLaunchKernelGGL(transpose_half_kernel, dim3((C + 63) / 64, (M + 63) / 64), dim3(256), 0, st, in, out, M, C, ldo);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_pack_weight(const float* w, half_t* wn, half_t* wt, int N, int K, int dtype, hipStream_t st) {
+#define CALL(DT) hipLaunchKernelGGL(pack_weight_kernel<DT>, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, w, wn, wt, N, K)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+// splits > 1: the contraction is cut into `splits` ranges, partial products go to `ws` (splits * M * N floats, dense [M][N]) and are
+// reduced into C (which must then be dense row-major: scm = N, scn = 1)
+int launch_naive_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, int M, int N,
+                      int K, float alpha, int accumulate, hipStream_t st, int splits, float* ws) {
+  if (splits > 1) {
+    if (!ws || scm != N || scn != 1) return fail(LATTE_ERR_INVALID, "naive_gemm: split needs a workspace and a dense output");
+    const int chunk = (K + splits - 1) / splits;
+    const int ns = (K + chunk - 1) / chunk;
+    hipLaunchKernelGGL(naive_gemm_kernel, dim3((N + 63) / 64, (M + 3) / 4, ns), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, ws, (long)N, 1L, M,
+                       N, K, alpha, 0, chunk, (long)M * N);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, st, ws, ns, (size_t)M * N, (size_t)M * N, C,
+                       accumulate);
+  } else {
+    hipLaunchKernelGGL(naive_gemm_kernel, dim3((N + 63) / 64, (M + 3) / 4, 1), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, scm, scn, M, N,
+                       K, alpha, accumulate, 0, 0L);
+  }
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_tfreq(const int64_t* t, float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(tfreq_kernel, dim3(B), dim3(128), 0, st, t, out, B);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_gather_i64(const int64_t* table, const int64_t* idx, int64_t* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(gather_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, st, table, idx, out, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_unpatchify_bwd(const float* dout, float* dtok, int BF, int G, int p, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL(unpatchify_bwd_kernel, dim3(blocks_for((size_t)BF * G * G * p * p * Cout)), dim3(256), 0, st, dout, dtok, BF, G, p, Cout);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_im2col_patch(const float* x, float* pix, int BF, int G, int p, int C, hipStream_t st) {
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(blocks_for((size_t)BF * G * G * p * p * C)), dim3(256), 0, st, x, pix, BF, G, p, C);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_embedding_bwd(const float* dc, const int64_t* idx, float* dtable, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((D + 255) / 256), dim3(256), 0, st, dc, idx, dtable, B, D);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_silu_bwd(const float* dout, const float* pre, float* din, size_t n, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dout, pre, din, n, accumulate);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_add_rows(float* dst, const float* src, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dst, src, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_rows_sum(const float* in, int B, long stride, int N, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, in, B, stride, N, out, accumulate);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_loss_grad(const float* tables, int n_steps, int mean_type, int var_type, const float* x_start, const float* x_t,
+                     const float* noise, const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw,
+                     float vb_scale, float* dmodel_out, hipStream_t st) {
+  const size_t per = (size_t)frames * channels * hw;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks_for(per, 256), batch), dim3(256), 0, st, tables, n_steps, mean_type, var_type, x_start,
+                     x_t, noise, model_out, t, batch, frames, channels, hw, vb_scale, dmodel_out);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+int sumsq_blocks() { return SUMSQ_BLOCKS; }
+// stats: float[2] = {norm, clip coefficient};  partial: double [sumsq_blocks()]
+int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, g, n, partial);
+  hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(1), 0, st, partial, SUMSQ_BLOCKS, max_norm, clip, stats);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                     int step, float ema_decay, const float* stats, hipStream_t st) {
+  const float bc1 = 1.0f - (float)std::pow((double)b1, (double)step);
+  const float sqrt_bc2 = (float)std::sqrt(1.0 - std::pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks_for(n, 8192)), dim3(256), 0, st, p, g, m, v, ema, n, lr, b1, b2, eps, wd, bc1, sqrt_bc2,
+                     ema_decay, stats);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+}  // namespace latte

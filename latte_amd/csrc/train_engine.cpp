@@ -1,0 +1,450 @@
+// Training step on the engine (round 2): forward with saved activations, backward, AdamW + EMA.
+//
+//   train.py:197-236       x_t = q_sample(x_0, t), loss = training_losses(model, x_0, t)["loss"].mean(); loss.backward();
+//                          clip_grad_norm_; opt.step(); update_ema
+//   gaussian_diffusion.py:719-795   MSE on the mean head, variational bound on the variance head (mean detached)
+//   latte.py:177-181,314-377        the block and the forward whose backward this is
+//
+// Layout: the same canonical token order as the inference engine (row = (b F + f) T + t); parameters, gradients and the
+// optimiser state live in caller-owned FLAT fp32 buffers (reference named_parameters() order without the two frozen sin-cos
+// tables; the host shim makes the nn.Parameters views of the parameter buffer and all-reduces the gradient buffer over RCCL).
+// MFMA operands are half copies of the masters ([N, K] for the forward / weight-gradient GEMMs, [K, N] for the
+// input-gradient GEMMs), re-packed after every optimiser step.  Saved per block: the two fp32 residual inputs of its LayerNorms
+// and the half tensors xn1, qkv, attention output, y1, xn2, u (pre-GELU), h, y2.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace latte;
+
+namespace {
+struct ParamInfo {
+  std::string key;
+  int64_t offset, numel;
+};
+struct BlockBuf {
+  half_t *xn1, *qkv, *att, *y1, *xn2, *u, *h, *y2;
+  half_t *qkv_w, *qkv_wt, *proj_w, *proj_wt, *fc1_w, *fc1_wt, *fc2_w, *fc2_wt;
+};
+}  // namespace
+
+struct latte_trainer {
+  latte_model_config_t cfg;
+  int max_batch = 0;
+  int D = 0, T = 0, F = 0, G = 0, Cin = 0, Cout = 0, H = 0, P = 0, KPE = 0, Hm = 0, hd = 0, nmod = 0, dt = 0;
+  int64_t rows_max = 0, rows_pad = 0, ld = 0;
+  std::vector<ParamInfo> params;
+  std::map<std::string, int> index;
+  int64_t total = 0;
+  float *Pm = nullptr, *Gr = nullptr, *M1 = nullptr, *V2 = nullptr, *Ema = nullptr;   // bound flat buffers (caller-owned)
+  float *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *fin_wt = nullptr;
+  std::vector<float*> xs;        // 2 depth + 1 residual-stream snapshots, fp32 [rows_pad, D]
+  std::vector<BlockBuf> blk;
+  // conditioning
+  float *tfreq = nullptr, *temb_pre = nullptr, *temb_act = nullptr, *cvec = nullptr, *csilu = nullptr, *mod = nullptr, *dmod = nullptr,
+        *dc = nullptr, *dtmp = nullptr, *dtmp2 = nullptr;
+  int64_t* t_orig = nullptr;
+  int64_t* tmap_dev = nullptr;
+  int tmap_n = 0;
+  const latte_schedule_t* tmap_of = nullptr;
+  // scratch
+  float *x_t = nullptr, *model_out = nullptr, *dmodel_out = nullptr, *dtok = nullptr, *f32a = nullptr, *f32b = nullptr, *dx = nullptr,
+        *pix = nullptr, *ones = nullptr, *zeros = nullptr, *part_rows = nullptr, *part_cols = nullptr, *wg_ws = nullptr, *ng_ws = nullptr,
+        *attn_stats = nullptr, *loss_ws = nullptr, *stats = nullptr;
+  double* sumsq = nullptr;
+  half_t *dyD = nullptr, *dhH = nullptr, *dxnH = nullptr, *dqkvH = nullptr, *xnh = nullptr, *at = nullptr, *bt = nullptr;
+  int64_t wg_ws_floats = 0, ng_ws_floats = 0, loss_ws_floats = 0;
+  bool weights_synced = false;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+template <typename Tp>
+int talloc(latte_trainer* e, Tp** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(Tp), 16);
+  LATTE_HIP(hipMalloc(&q, bytes));
+  if (zero) LATTE_HIP(hipMemset(q, 0, bytes));
+  e->allocs.push_back(q);
+  *p = (Tp*)q;
+  return LATTE_OK;
+}
+
+void add_param(latte_trainer* e, const std::string& key, int64_t numel) {
+  ParamInfo p{key, e->total, numel};
+  e->index[key] = (int)e->params.size();
+  e->params.push_back(p);
+  e->total += (numel + 3) / 4 * 4;   // 16-byte aligned tensors inside the flat buffers
+}
+
+float* P_(latte_trainer* e, const std::string& key) { return e->Pm + e->params[e->index.at(key)].offset; }
+float* G_(latte_trainer* e, const std::string& key) { return e->Gr + e->params[e->index.at(key)].offset; }
+
+int gemm_half(latte_trainer* e, const half_t* A, const half_t* W, const float* bias, half_t* out, int M, int N, int K, hipStream_t st) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M; g.gate_stride = 0;
+  return launch_gemm(g, EPI_BIAS_H16, e->dt, 0, st);
+}
+
+// dW[N, K] = dY[M, N]^T X[M, K] through two half transposes and the split-K tile GEMM; result ASSIGNED to dW (fp32)
+int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st) {
+  int rc;
+  const int ld = M;   // M = batch * F * T is a multiple of 64: the transposed operands are dense [N, M] / [K, M]
+  if ((rc = launch_transpose_half(dY, e->at, M, N, ld, st))) return rc;
+  if ((rc = launch_transpose_half(X, e->bt, M, K, ld, st))) return rc;
+  const int tiles = ((N + 127) / 128) * (K / 128);
+  int splits = std::max(1, std::min(ld / 64, (1024 + tiles - 1) / tiles));
+  int chunk = ((ld + splits - 1) / splits + 63) / 64 * 64;
+  splits = (ld + chunk - 1) / chunk;
+  if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
+  GemmArgs g{};
+  g.A = e->at; g.W = e->bt; g.bias = e->zeros; g.out = e->wg_ws; g.M = N; g.N = K; g.K = ld; g.rows_per_sample = N;
+  g.k_chunk = chunk; g.split_stride = (long)N * K;
+  if ((rc = launch_gemm(g, EPI_BIAS_F32, e->dt, 1, st))) return rc;
+  return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_trainer_t** out) {
+  if (!cfg || !out || max_batch <= 0) return fail(LATTE_ERR_INVALID, "trainer_create: bad arguments");
+  const auto& c = *cfg;
+  if (c.extras != 1 && c.extras != 2) return fail(LATTE_ERR_INVALID, "trainer: extras must be 1 or 2 (train.py:213-218 refuses text-to-video training)");
+  if (c.hidden_size % 128 || c.hidden_size > 1280 || c.depth % 2 || c.hidden_size % c.num_heads)
+    return fail(LATTE_ERR_INVALID, "trainer: hidden_size must be a multiple of 128 (<= 1280), depth even");
+  const int hd = c.hidden_size / c.num_heads;
+  if (hd != 64 && hd != 72) return fail(LATTE_ERR_INVALID, "trainer: head dim must be 64 or 72");
+  if (c.mlp_hidden % 128) return fail(LATTE_ERR_INVALID, "trainer: mlp_hidden must be a multiple of 128");
+  if (c.input_size % c.patch_size) return fail(LATTE_ERR_INVALID, "trainer: input_size % patch_size != 0");
+  auto* e = new latte_trainer();
+  e->cfg = c;
+  e->max_batch = max_batch;
+  e->D = c.hidden_size; e->F = c.num_frames; e->G = c.input_size / c.patch_size; e->T = e->G * e->G;
+  e->Cin = c.in_channels; e->Cout = c.learn_sigma ? 2 * c.in_channels : c.in_channels; e->H = c.input_size;
+  e->P = c.patch_size * c.patch_size * e->Cout; e->KPE = c.in_channels * c.patch_size * c.patch_size;
+  e->Hm = c.mlp_hidden; e->hd = hd; e->dt = c.compute_dtype;
+  e->nmod = c.depth * 6 * e->D + 2 * e->D;
+  if ((e->F * e->T) % 64) { delete e; return fail(LATTE_ERR_INVALID, "trainer: frames * tokens per sample must be a multiple of 64"); }
+  e->rows_max = (int64_t)max_batch * e->F * e->T;
+  e->rows_pad = (e->rows_max + 255) / 256 * 256;
+  e->ld = (e->rows_max + 63) / 64 * 64;
+  const int D = e->D, Hm = e->Hm;
+  // ---- parameter table: reference named_parameters() order (latte.py:226-255), frozen tables excluded
+  add_param(e, "x_embedder.proj.weight", (int64_t)D * e->KPE);
+  add_param(e, "x_embedder.proj.bias", D);
+  add_param(e, "t_embedder.mlp.0.weight", (int64_t)D * 256);
+  add_param(e, "t_embedder.mlp.0.bias", D);
+  add_param(e, "t_embedder.mlp.2.weight", (int64_t)D * D);
+  add_param(e, "t_embedder.mlp.2.bias", D);
+  if (c.extras == 2) add_param(e, "y_embedder.embedding_table.weight", (int64_t)(c.num_classes + 1) * D);
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    add_param(e, p + "attn.qkv.weight", (int64_t)3 * D * D);
+    add_param(e, p + "attn.qkv.bias", 3 * D);
+    add_param(e, p + "attn.proj.weight", (int64_t)D * D);
+    add_param(e, p + "attn.proj.bias", D);
+    add_param(e, p + "mlp.fc1.weight", (int64_t)Hm * D);
+    add_param(e, p + "mlp.fc1.bias", Hm);
+    add_param(e, p + "mlp.fc2.weight", (int64_t)D * Hm);
+    add_param(e, p + "mlp.fc2.bias", D);
+    add_param(e, p + "adaLN_modulation.1.weight", (int64_t)6 * D * D);
+    add_param(e, p + "adaLN_modulation.1.bias", 6 * D);
+  }
+  add_param(e, "final_layer.linear.weight", (int64_t)e->P * D);
+  add_param(e, "final_layer.linear.bias", e->P);
+  add_param(e, "final_layer.adaLN_modulation.1.weight", (int64_t)2 * D * D);
+  add_param(e, "final_layer.adaLN_modulation.1.bias", 2 * D);
+
+  int rc = LATTE_OK;
+  const size_t R = (size_t)e->rows_pad;
+  auto A = [&](auto** p, size_t n) { if (!rc) rc = talloc(e, p, n); };
+  A(&e->pos, (size_t)e->T * D); A(&e->temp, (size_t)e->F * D); A(&e->pe_wt, (size_t)e->KPE * D); A(&e->fin_wt, (size_t)D * e->P);
+  e->xs.resize(2 * c.depth + 1);
+  for (auto& x : e->xs) A(&x, R * D);
+  e->blk.resize(c.depth);
+  for (auto& b : e->blk) {
+    A(&b.xn1, R * D); A(&b.qkv, R * 3 * D); A(&b.att, R * D); A(&b.y1, R * D); A(&b.xn2, R * D); A(&b.u, R * Hm); A(&b.h, R * Hm);
+    A(&b.y2, R * D);
+    A(&b.qkv_w, (size_t)3 * D * D); A(&b.qkv_wt, (size_t)3 * D * D); A(&b.proj_w, (size_t)D * D); A(&b.proj_wt, (size_t)D * D);
+    A(&b.fc1_w, (size_t)Hm * D); A(&b.fc1_wt, (size_t)Hm * D); A(&b.fc2_w, (size_t)Hm * D); A(&b.fc2_wt, (size_t)Hm * D);
+  }
+  const size_t Bm = (size_t)max_batch;
+  A(&e->tfreq, Bm * 256); A(&e->temb_pre, Bm * D); A(&e->temb_act, Bm * D); A(&e->cvec, Bm * D); A(&e->csilu, Bm * D);
+  A(&e->mod, Bm * e->nmod); A(&e->dmod, Bm * e->nmod); A(&e->dc, Bm * D); A(&e->dtmp, Bm * D); A(&e->dtmp2, Bm * D);
+  A(&e->t_orig, Bm);
+  const size_t lat = Bm * e->F * e->H * e->H;
+  A(&e->x_t, lat * e->Cin); A(&e->model_out, lat * e->Cout); A(&e->dmodel_out, lat * e->Cout);
+  A(&e->dtok, R * e->P); A(&e->f32a, R * D); A(&e->f32b, R * D); A(&e->dx, R * D); A(&e->pix, R * e->KPE);
+  A(&e->ones, R); A(&e->zeros, (size_t)std::max(Hm, 3 * D) + 256);
+  const int Rr = train_rows_per_run(e->F * e->T);
+  A(&e->part_rows, (size_t)(e->rows_max / Rr + 4) * 2 * D);
+  A(&e->part_cols, (size_t)(colsum_chunks((int)e->rows_max) + 1) * std::max(Hm, 3 * D));
+  {
+    // split-K partial products: splits * N * K with splits <= ceil(1024 / tiles) (+1), tiles = N K / 16384
+    int64_t worst = 0;
+    const int shapes[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
+    for (auto& s : shapes) {
+      const int tiles = (s[0] / 128) * (s[1] / 128);
+      const int64_t splits = std::min<int64_t>(e->ld / 64, (1024 + tiles - 1) / tiles) + 1;
+      worst = std::max<int64_t>(worst, splits * s[0] * s[1]);
+    }
+    e->wg_ws_floats = worst;
+    A(&e->wg_ws, (size_t)worst);
+  }
+  e->ng_ws_floats = 64LL * std::max<int64_t>((int64_t)e->P * D, (int64_t)max_batch * D) + 64LL * D * e->KPE + 64LL * D;
+  A(&e->ng_ws, (size_t)e->ng_ws_floats);
+  A(&e->attn_stats, (size_t)e->rows_max * c.num_heads * 3 + 16);
+  e->loss_ws_floats = latte_training_workspace_floats(max_batch, (int64_t)e->F * e->Cin * e->H * e->H) + 3 * max_batch;
+  A(&e->loss_ws, (size_t)e->loss_ws_floats);
+  A(&e->stats, 4);
+  A(&e->sumsq, (size_t)sumsq_blocks());
+  A(&e->dyD, R * D); A(&e->dhH, R * Hm); A(&e->dxnH, R * D); A(&e->dqkvH, R * 3 * D); A(&e->xnh, R * D);
+  const size_t maxn = (size_t)(std::max(Hm, 3 * D) + 127) / 128 * 128;
+  A(&e->at, maxn * e->ld); A(&e->bt, maxn * e->ld);
+  if (!rc) rc = launch_fill_f32(e->ones, 1.0f, R, nullptr);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(LATTE_ERR_HIP, "trainer_create: device error");
+  if (rc) { latte_trainer_destroy(e); return rc; }
+  *out = e;
+  return LATTE_OK;
+}
+
+void latte_trainer_destroy(latte_trainer_t* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+int latte_trainer_num_params(const latte_trainer_t* e) { return e ? (int)e->params.size() : 0; }
+const char* latte_trainer_param_key(const latte_trainer_t* e, int i) {
+  return (e && i >= 0 && i < (int)e->params.size()) ? e->params[i].key.c_str() : nullptr;
+}
+int64_t latte_trainer_param_offset(const latte_trainer_t* e, int i) { return (e && i >= 0 && i < (int)e->params.size()) ? e->params[i].offset : -1; }
+int64_t latte_trainer_param_numel(const latte_trainer_t* e, int i) { return (e && i >= 0 && i < (int)e->params.size()) ? e->params[i].numel : -1; }
+int64_t latte_trainer_total_numel(const latte_trainer_t* e) { return e ? e->total : 0; }
+
+int latte_trainer_bind(latte_trainer_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema) {
+  if (!e || !params || !grads || !exp_avg || !exp_avg_sq) return fail(LATTE_ERR_INVALID, "trainer_bind: null buffer");
+  e->Pm = params; e->Gr = grads; e->M1 = exp_avg; e->V2 = exp_avg_sq; e->Ema = ema;
+  e->weights_synced = false;
+  return LATTE_OK;
+}
+
+int latte_trainer_set_frozen(latte_trainer_t* e, const float* pos_embed, const float* temp_embed, int on_device, void* stream) {
+  if (!e || !pos_embed || !temp_embed) return fail(LATTE_ERR_INVALID, "trainer_set_frozen: null");
+  const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  LATTE_HIP(hipMemcpyAsync(e->pos, pos_embed, sizeof(float) * e->T * e->D, k, (hipStream_t)stream));
+  LATTE_HIP(hipMemcpyAsync(e->temp, temp_embed, sizeof(float) * e->F * e->D, k, (hipStream_t)stream));
+  LATTE_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return LATTE_OK;
+}
+
+int latte_trainer_sync_weights(latte_trainer_t* e, void* stream) {
+  if (!e || !e->Pm) return fail(LATTE_ERR_STATE, "trainer_sync_weights: bind the parameter buffers first");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = e->D, Hm = e->Hm;
+  int rc;
+  for (int i = 0; i < e->cfg.depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    BlockBuf& b = e->blk[i];
+    if ((rc = launch_pack_weight(P_(e, p + "attn.qkv.weight"), b.qkv_w, b.qkv_wt, 3 * D, D, e->dt, st))) return rc;
+    if ((rc = launch_pack_weight(P_(e, p + "attn.proj.weight"), b.proj_w, b.proj_wt, D, D, e->dt, st))) return rc;
+    if ((rc = launch_pack_weight(P_(e, p + "mlp.fc1.weight"), b.fc1_w, b.fc1_wt, Hm, D, e->dt, st))) return rc;
+    if ((rc = launch_pack_weight(P_(e, p + "mlp.fc2.weight"), b.fc2_w, b.fc2_wt, D, Hm, e->dt, st))) return rc;
+  }
+  if ((rc = launch_transpose_f32(P_(e, "x_embedder.proj.weight"), e->pe_wt, D, e->KPE, st))) return rc;
+  if ((rc = launch_transpose_f32(P_(e, "final_layer.linear.weight"), e->fin_wt, e->P, D, st))) return rc;
+  e->weights_synced = true;
+  return LATTE_OK;
+}
+
+// terms_out: device float [3][batch] = loss, mse, vb;  model_out_copy: optional device copy of the model output
+int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
+                                   const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream) {
+  if (!e || !s || !x_start || !noise || !t || !terms_out) return fail(LATTE_ERR_INVALID, "train step: null argument");
+  if (!e->Pm) return fail(LATTE_ERR_STATE, "train step: bind the parameter buffers first");
+  if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "train step: batch exceeds max_batch");
+  if (loss_type != 0 && loss_type != 1) return fail(LATTE_ERR_INVALID, "train step: loss_type must be 0 (MSE) or 1 (RESCALED_MSE); the KL losses train no mean head (gaussian_diffusion.py:741-752)");
+  if (s->mean_type != 0) return fail(LATTE_ERR_INVALID, "train step: only the epsilon-prediction models of train.py:92 are supported");
+  if ((s->var_type == 0) != (e->cfg.learn_sigma != 0)) return fail(LATTE_ERR_INVALID, "train step: schedule / model disagree on learn_sigma");
+  const auto& c = e->cfg;
+  if (c.extras == 2 && !y) return fail(LATTE_ERR_INVALID, "train step: class-conditional model needs y");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (!e->weights_synced && (rc = latte_trainer_sync_weights(e, stream))) return rc;
+  const int D = e->D, T = e->T, F = e->F, Hm = e->Hm, B = batch, dt = e->dt, nmod = e->nmod;
+  const int M = B * F * T, rps = F * T;
+  const int hw = e->H * e->H;
+  const float* tab = nullptr;
+  if ((rc = schedule_device_tables(s, &tab, st))) return rc;
+  // ---- x_t, original timesteps
+  if ((rc = launch_q_sample(tab, s->num_timesteps, x_start, noise, t, B, (size_t)F * e->Cin * hw, e->x_t, st))) return rc;
+  if (e->tmap_of != s || e->tmap_n != s->num_timesteps) {
+    if (e->tmap_n < s->num_timesteps) { if ((rc = talloc(e, &e->tmap_dev, (size_t)s->num_timesteps, false))) return rc; }
+    LATTE_HIP(hipMemcpyAsync(e->tmap_dev, s->timestep_map.data(), sizeof(int64_t) * s->num_timesteps, hipMemcpyHostToDevice, st));
+    LATTE_HIP(hipStreamSynchronize(st));
+    e->tmap_n = s->num_timesteps;
+    e->tmap_of = s;
+  }
+  if ((rc = launch_gather_i64(e->tmap_dev, t, e->t_orig, B, st))) return rc;
+
+  // ================================================================ forward
+  // conditioning (latte.py:119-123,332-348): temb_pre = W0 freq(t) + b0; c = W2 SiLU(temb_pre) + b2 (+ y_emb); mod = adaLN(SiLU(c))
+  if ((rc = launch_tfreq(e->t_orig, e->tfreq, B, st))) return rc;
+  if ((rc = launch_small_linear(IN_PLAIN, e->tfreq, nullptr, P_(e, "t_embedder.mlp.0.weight"), P_(e, "t_embedder.mlp.0.bias"), nullptr,
+                                nullptr, e->temb_pre, B, D, 256, D, st))) return rc;
+  if ((rc = launch_silu_rows(e->temb_pre, e->temb_act, (size_t)B * D, st))) return rc;
+  if ((rc = launch_small_linear(IN_PLAIN, e->temb_act, nullptr, P_(e, "t_embedder.mlp.2.weight"), P_(e, "t_embedder.mlp.2.bias"),
+                                c.extras == 2 ? P_(e, "y_embedder.embedding_table.weight") : nullptr, c.extras == 2 ? y : nullptr, e->cvec, B,
+                                D, D, D, st))) return rc;
+  if ((rc = launch_silu_rows(e->cvec, e->csilu, (size_t)B * D, st))) return rc;
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".adaLN_modulation.1.";
+    if ((rc = launch_small_linear(IN_PLAIN, e->csilu, nullptr, P_(e, p + "weight"), P_(e, p + "bias"), nullptr, nullptr,
+                                  e->mod + (size_t)i * 6 * D, B, 6 * D, D, nmod, st))) return rc;
+  }
+  if ((rc = launch_small_linear(IN_PLAIN, e->csilu, nullptr, P_(e, "final_layer.adaLN_modulation.1.weight"),
+                                P_(e, "final_layer.adaLN_modulation.1.bias"), nullptr, nullptr, e->mod + (size_t)c.depth * 6 * D, B, 2 * D, D,
+                                nmod, st))) return rc;
+  if ((rc = launch_patch_embed(e->x_t, e->pe_wt, P_(e, "x_embedder.proj.bias"), e->pos, e->xs[0], B * F, e->Cin, e->H, c.patch_size, D, st)))
+    return rc;
+  for (int i = 0; i < c.depth; ++i) {
+    const bool spatial = (i % 2) == 0;
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    BlockBuf& b = e->blk[i];
+    const float* mb = e->mod + (size_t)i * 6 * D;
+    float* x0 = e->xs[2 * i];
+    float* x1 = e->xs[2 * i + 1];
+    float* x2 = e->xs[2 * i + 2];
+    if ((rc = launch_ln_modulate(x0, x0, b.xn1, mb, mb + D, nmod, M, D, rps, i == 1 ? e->temp : nullptr, T, F, dt, st))) return rc;
+    if ((rc = gemm_half(e, b.xn1, b.qkv_w, P_(e, p + "attn.qkv.bias"), b.qkv, M, 3 * D, D, st))) return rc;
+    AttnArgs a{};
+    a.qkv = b.qkv; a.out = b.att; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
+    a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
+    if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
+    else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
+    if ((rc = launch_attention(a, dt, st))) return rc;
+    if ((rc = gemm_half(e, b.att, b.proj_w, P_(e, p + "attn.proj.bias"), b.y1, M, D, D, st))) return rc;
+    if ((rc = launch_gated_add(x0, b.y1, mb + 2 * D, nmod, x1, M, D, rps, dt, st))) return rc;
+    if ((rc = launch_ln_modulate(x1, x1, b.xn2, mb + 3 * D, mb + 4 * D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    if ((rc = gemm_half(e, b.xn2, b.fc1_w, P_(e, p + "mlp.fc1.bias"), b.u, M, Hm, D, st))) return rc;
+    if ((rc = launch_gelu_fwd(b.u, b.h, (size_t)M * Hm, dt, st))) return rc;
+    if ((rc = gemm_half(e, b.h, b.fc2_w, P_(e, p + "mlp.fc2.bias"), b.y2, M, D, Hm, st))) return rc;
+    if ((rc = launch_gated_add(x1, b.y2, mb + 5 * D, nmod, x2, M, D, rps, dt, st))) return rc;
+  }
+  float* xl = e->xs[2 * c.depth];
+  const float* fm = e->mod + (size_t)c.depth * 6 * D;
+  if ((rc = launch_final_layer(xl, fm, fm + D, nmod, e->fin_wt, P_(e, "final_layer.linear.bias"), e->model_out, M, D, rps, T, c.patch_size,
+                               e->Cout, e->H, st))) return rc;
+  if (model_out_copy)
+    LATTE_HIP(hipMemcpyAsync(model_out_copy, e->model_out, sizeof(float) * (size_t)B * F * e->Cout * hw, hipMemcpyDeviceToDevice, st));
+
+  // ================================================================ loss values and d loss / d model_output
+  float vb_scale = 1.0f;
+  if (loss_type == 1) vb_scale = (float)(s->num_timesteps / 1000.0);
+  if ((rc = latte_training_losses(s, loss_type, x_start, e->x_t, noise, e->model_out, t, B, F, e->Cin, hw, e->loss_ws,
+                                  e->loss_ws_floats - 3 * e->max_batch, terms_out + B, terms_out + 2 * B, terms_out, stream))) return rc;
+  if ((rc = launch_loss_grad(tab, s->num_timesteps, s->mean_type, s->var_type, x_start, e->x_t, noise, e->model_out, t, B, F, e->Cin, hw,
+                             vb_scale, e->dmodel_out, st))) return rc;
+
+  // ================================================================ backward
+  // final layer: out = unpatchify(Linear(LN-mod(x)))
+  if ((rc = launch_unpatchify_bwd(e->dmodel_out, e->dtok, B * F, e->G, c.patch_size, e->Cout, st))) return rc;
+  if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dtok, e->P, 1, G_(e, "final_layer.linear.bias"), e->P, 1, 1, e->P, M, 1.0f, 0, st, 64, e->ng_ws)))
+    return rc;
+  if ((rc = launch_ln_modulate(xl, xl, e->xnh, fm, fm + D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+  if ((rc = launch_convert_h16_to_f32(e->xnh, e->f32a, (int64_t)M * D, dt, st))) return rc;
+  if ((rc = launch_naive_gemm(e->dtok, 1, e->P, e->f32a, D, 1, G_(e, "final_layer.linear.weight"), D, 1, e->P, D, M, 1.0f, 0, st, 64, e->ng_ws)))
+    return rc;
+  if ((rc = launch_naive_gemm(e->dtok, e->P, 1, P_(e, "final_layer.linear.weight"), D, 1, e->f32b, D, 1, M, D, e->P, 1.0f, 0, st))) return rc;
+  if ((rc = launch_convert_f32_to_h16(e->f32b, e->dxnH, (int64_t)M * D, dt, st))) return rc;
+  {
+    float* dm = e->dmod + (size_t)c.depth * 6 * D;
+    if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->part_rows, dm, dm + D, nmod, M, D, rps, dt, st))) return rc;
+  }
+  for (int i = c.depth - 1; i >= 0; --i) {
+    const bool spatial = (i % 2) == 0;
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    BlockBuf& b = e->blk[i];
+    const float* mb = e->mod + (size_t)i * 6 * D;
+    float* dm = e->dmod + (size_t)i * 6 * D;
+    // ---- MLP branch: x2 = x1 + g2 * (fc2(gelu(fc1(xn2))))
+    if ((rc = launch_gate_bwd(e->dx, b.y2, mb + 5 * D, nmod, e->dyD, e->part_rows, dm + 5 * D, nmod, M, D, rps, dt, st))) return rc;
+    if ((rc = launch_colsum_half(e->dyD, M, D, e->part_cols, G_(e, p + "mlp.fc2.bias"), 0, dt, st))) return rc;
+    if ((rc = wgrad(e, e->dyD, b.h, M, D, Hm, G_(e, p + "mlp.fc2.weight"), st))) return rc;
+    if ((rc = gemm_half(e, e->dyD, b.fc2_wt, e->zeros, e->dhH, M, Hm, D, st))) return rc;
+    if ((rc = launch_gelu_bwd(b.u, e->dhH, e->dhH, (size_t)M * Hm, dt, st))) return rc;
+    if ((rc = launch_colsum_half(e->dhH, M, Hm, e->part_cols, G_(e, p + "mlp.fc1.bias"), 0, dt, st))) return rc;
+    if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st))) return rc;
+    if ((rc = gemm_half(e, e->dhH, b.fc1_wt, e->zeros, e->dxnH, M, D, Hm, st))) return rc;
+    if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i + 1], mb + 4 * D, nmod, e->dx, e->dx, e->part_rows, dm + 3 * D, dm + 4 * D, nmod, M, D, rps, dt,
+                            st))) return rc;
+    // ---- attention branch: x1 = x0 + g1 * proj(attn(qkv(xn1)))
+    if ((rc = launch_gate_bwd(e->dx, b.y1, mb + 2 * D, nmod, e->dyD, e->part_rows, dm + 2 * D, nmod, M, D, rps, dt, st))) return rc;
+    if ((rc = launch_colsum_half(e->dyD, M, D, e->part_cols, G_(e, p + "attn.proj.bias"), 0, dt, st))) return rc;
+    if ((rc = wgrad(e, e->dyD, b.att, M, D, D, G_(e, p + "attn.proj.weight"), st))) return rc;
+    if ((rc = gemm_half(e, e->dyD, b.proj_wt, e->zeros, e->dxnH, M, D, D, st))) return rc;   // d(attention output)
+    if (spatial) rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * F, T, c.num_heads, e->hd, F, rps, T, 1, dt, st);
+    else         rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * T, F, c.num_heads, e->hd, T, rps, 1, T, dt, st);
+    if (rc) return rc;
+    if ((rc = launch_colsum_half(e->dqkvH, M, 3 * D, e->part_cols, G_(e, p + "attn.qkv.bias"), 0, dt, st))) return rc;
+    if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st))) return rc;
+    if ((rc = gemm_half(e, e->dqkvH, b.qkv_wt, e->zeros, e->dxnH, M, D, 3 * D, st))) return rc;
+    if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->part_rows, dm, dm + D, nmod, M, D, rps, dt, st))) return rc;
+  }
+  // ---- patch embed (latte.py:233,330-331): tokens = pix W^T + b + pos
+  if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dx, D, 1, G_(e, "x_embedder.proj.bias"), D, 1, 1, D, M, 1.0f, 0, st, 64, e->ng_ws))) return rc;
+  if ((rc = launch_im2col_patch(e->x_t, e->pix, B * F, e->G, c.patch_size, e->Cin, st))) return rc;
+  if ((rc = launch_naive_gemm(e->dx, 1, D, e->pix, e->KPE, 1, G_(e, "x_embedder.proj.weight"), e->KPE, 1, D, e->KPE, M, 1.0f, 0, st, 64,
+                              e->ng_ws))) return rc;
+  // ---- conditioning: mod rows -> adaLN linears -> SiLU -> c = temb (+ y_emb) -> t_embedder MLP
+  LATTE_HIP(hipMemsetAsync(e->dc, 0, sizeof(float) * (size_t)B * D, st));   // d SiLU(c), summed over the adaLN linears
+  for (int i = 0; i <= c.depth; ++i) {
+    const bool fin = i == c.depth;
+    const std::string p = fin ? "final_layer.adaLN_modulation.1." : "blocks." + std::to_string(i) + ".adaLN_modulation.1.";
+    const int N = fin ? 2 * D : 6 * D;
+    const float* dm = e->dmod + (size_t)i * 6 * D;
+    if ((rc = launch_rows_sum(dm, B, nmod, N, G_(e, p + "bias"), 0, st))) return rc;
+    // dW[n, k] = sum_b dmod[b, n] csilu[b, k]
+    if ((rc = launch_naive_gemm(dm, 1, nmod, e->csilu, D, 1, G_(e, p + "weight"), D, 1, N, D, B, 1.0f, 0, st))) return rc;
+    // d csilu[b, k] += sum_n dmod[b, n] W[n, k]
+    if ((rc = launch_naive_gemm(dm, nmod, 1, P_(e, p + "weight"), D, 1, e->dtmp, D, 1, B, D, N, 1.0f, 0, st, 48, e->ng_ws))) return rc;
+    if ((rc = launch_add_rows(e->dc, e->dtmp, (size_t)B * D, st))) return rc;
+  }
+  if ((rc = launch_silu_bwd(e->dc, e->cvec, e->dtmp, (size_t)B * D, 0, st))) return rc;     // dtmp = dc (gradient of c = temb + y_emb)
+  if (c.extras == 2) {
+    if ((rc = launch_embedding_bwd(e->dtmp, y, G_(e, "y_embedder.embedding_table.weight"), B, D, st))) return rc;
+  }
+  // temb = W2 SiLU(temb_pre) + b2
+  if ((rc = launch_rows_sum(e->dtmp, B, D, D, G_(e, "t_embedder.mlp.2.bias"), 0, st))) return rc;
+  if ((rc = launch_naive_gemm(e->dtmp, 1, D, e->temb_act, D, 1, G_(e, "t_embedder.mlp.2.weight"), D, 1, D, D, B, 1.0f, 0, st))) return rc;
+  if ((rc = launch_naive_gemm(e->dtmp, D, 1, P_(e, "t_embedder.mlp.2.weight"), D, 1, e->dtmp2, D, 1, B, D, D, 1.0f, 0, st))) return rc;
+  if ((rc = launch_silu_bwd(e->dtmp2, e->temb_pre, e->dtmp2, (size_t)B * D, 0, st))) return rc;
+  // temb_pre = W0 freq(t) + b0
+  if ((rc = launch_rows_sum(e->dtmp2, B, D, D, G_(e, "t_embedder.mlp.0.bias"), 0, st))) return rc;
+  if ((rc = launch_naive_gemm(e->dtmp2, 1, D, e->tfreq, 256, 1, G_(e, "t_embedder.mlp.0.weight"), 256, 1, D, 256, B, 1.0f, 0, st))) return rc;
+  return LATTE_OK;
+}
+
+// clip_grad_norm_ (utils.py:72-117) + AdamW (train.py:127) + update_ema (utils.py:191-200) on the bound flat buffers, then the
+// half operand copies are re-packed.  norm_out: optional device float[2] = {total gradient norm, applied clip coefficient}.
+int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float clip_max_norm, int clip, float ema_decay, float* norm_out, void* stream) {
+  if (!e || !e->Pm) return fail(LATTE_ERR_STATE, "optimizer_step: bind the parameter buffers first");
+  if (step < 1) return fail(LATTE_ERR_INVALID, "optimizer_step: step counts from 1");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = launch_grad_norm(e->Gr, (size_t)e->total, e->sumsq, clip_max_norm, clip, e->stats, st))) return rc;
+  if (norm_out) LATTE_HIP(hipMemcpyAsync(norm_out, e->stats, sizeof(float) * 2, hipMemcpyDeviceToDevice, st));
+  if ((rc = launch_adamw_ema(e->Pm, e->Gr, e->M1, e->V2, e->Ema, (size_t)e->total, lr, beta1, beta2, eps, weight_decay, step, ema_decay,
+                             e->stats, st))) return rc;
+  return latte_trainer_sync_weights(e, stream);
+}
+
+}  // extern "C"

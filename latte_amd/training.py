@@ -1,0 +1,196 @@
+"""Training on the engine: the body of the reference's optimisation loop (train.py:197-236) behind one object.
+
+    trainer = LatteTrainer(model, diffusion, max_batch=5)          # model: latte_amd.Latte, diffusion: create_diffusion("")
+    out = trainer.train_step(x_start, y=labels)                     # q_sample + forward + losses + backward + clip + AdamW + EMA
+    trainer.ema_state_dict() / model.state_dict()                  # reference checkpoint format (train.py:257-262)
+
+What runs where: the forward with saved activations, the loss terms and their gradient, the backward (MFMA GEMMs for the
+input / weight gradients, the attention backward, LayerNorm-modulate / GELU / gate backward kernels), gradient norm + clipping,
+AdamW and the EMA update are engine kernels behind ``latte_trainer_*`` (include/latte_amd.h).  PyTorch holds the flat fp32
+buffers (the model's ``nn.Parameter``s become views of the parameter buffer, as DistributedDataParallel's buckets do) and
+averages the gradient buffer across ranks with ONE RCCL all-reduce per step when ``torch.distributed`` is initialised
+(train.py:125 wraps the model in DDP; the engine itself never communicates).  There is no CPU / autograd fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import LatteError, check, load_library, ptr, stream_ptr
+from .diffusion import SpacedDiffusion, _LOSS
+from .models import Latte
+
+FROZEN = ("pos_embed", "temp_embed")   # nn.Parameter(requires_grad=False), latte.py:246-247
+
+
+def average_gradients(flat_grads, group=None):
+    """DistributedDataParallel's gradient averaging (train.py:125) as ONE all-reduce over a flat gradient buffer: RCCL over
+    xGMI when the process group's backend is nccl, gloo in the CPU tests.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+            flat_grads.div_(world)
+    return flat_grads
+
+
+class LatteTrainer:
+    """One data-parallel replica of train.py's model / ema / AdamW triple.
+
+    lr, betas, eps, weight_decay: ``torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)`` (train.py:127);
+    clip_max_norm / start_clip_iter: train.py:228-231 (the gradient norm is always computed, clipping starts at that step);
+    ema_decay: utils.update_ema's default; class_dropout_prob: LabelEmbedder's (latte.py:130), applied here because the engine
+    takes the labels AFTER token_drop."""
+
+    def __init__(self, model, diffusion, max_batch, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_max_norm=0.1,
+                 start_clip_iter=20000, ema_decay=0.9999, class_dropout_prob=0.1, compute_dtype="bf16", process_group=None):
+        if not isinstance(model, Latte):
+            raise LatteError("LatteTrainer needs a latte_amd.Latte model")
+        if not isinstance(diffusion, SpacedDiffusion):
+            raise LatteError("LatteTrainer needs a latte_amd SpacedDiffusion (create_diffusion)")
+        if model.extras not in (1, 2):
+            raise LatteError("T2V training are Not supported at this moment!")             # train.py:213-214
+        if diffusion.loss_type not in ("mse", "rescaled_mse"):
+            raise LatteError("the engine trains the MSE loss types (create_diffusion's default and rescale_learned_sigmas)")
+        if _lib.DTYPES.get(compute_dtype) != 0:
+            raise LatteError("the engine trains with bf16 MFMA operands: the per-token gradients (1e-7 ... 1e-4) underflow f16 "
+                             "without loss scaling (the reference trains in fp32, train.py has no GradScaler)")
+        _lib.require_gpu()
+        self.model, self.diffusion = model, diffusion
+        self.max_batch = int(max_batch)
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.clip_max_norm, self.start_clip_iter, self.ema_decay = float(clip_max_norm), int(start_clip_iter), float(ema_decay)
+        self.class_dropout_prob = float(class_dropout_prob)
+        self.process_group = process_group
+        self.train_steps = 0
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise LatteError("move the model to the GPU first (model.to('cuda'))")
+        self.device = dev
+        lib = load_library()
+        cfg = model.engine_config(compute_dtype)
+        h = _lib.c_void()
+        with torch.cuda.device(dev):
+            check(lib.latte_trainer_create(cfg, self.max_batch, h))
+        self._h = h
+        n = lib.latte_trainer_num_params(h)
+        self.layout = [(lib.latte_trainer_param_key(h, i).decode(), int(lib.latte_trainer_param_offset(h, i)),
+                        int(lib.latte_trainer_param_numel(h, i))) for i in range(n)]
+        total = int(lib.latte_trainer_total_numel(h))
+        named = dict(model.named_parameters())
+        want = [k for k in named if k not in FROZEN]
+        if [k for k, _, _ in self.layout] != want:
+            raise LatteError("parameter order of the engine and of the model differ")
+        self.params = torch.zeros(total, device=dev)
+        self.grads = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        self.ema = torch.zeros(total, device=dev)
+        with torch.no_grad():
+            for k, off, numel in self.layout:
+                p = named[k]
+                self.params[off:off + numel].copy_(p.detach().reshape(-1).float())
+                p.data = self.params[off:off + numel].view(p.shape)          # the module's parameters are views of the flat buffer
+            self.ema.copy_(self.params)                                        # update_ema(ema, model, decay=0), train.py:165
+        with torch.cuda.device(dev):
+            check(lib.latte_trainer_bind(h, ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.ema)))
+            check(lib.latte_trainer_set_frozen(h, ptr(named["pos_embed"].detach().float().contiguous()),
+                                               ptr(named["temp_embed"].detach().float().contiguous()), 1, stream_ptr()))
+            check(lib.latte_trainer_sync_weights(h, stream_ptr()))
+        self._norm = torch.zeros(2, device=dev)
+        if hasattr(model, "mark_weights_dirty"):
+            model.mark_weights_dirty()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                load_library().latte_trainer_destroy(self._h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ views
+    def grad_dict(self):
+        """{reference key: gradient view} of the last forward_backward."""
+        named = dict(self.model.named_parameters())
+        return {k: self.grads[off:off + numel].view(named[k].shape) for k, off, numel in self.layout}
+
+    def ema_state_dict(self):
+        """The ``"ema"`` entry of train.py's checkpoints (:257-262): every key of model.state_dict()."""
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        for k, off, numel in self.layout:
+            sd[k] = self.ema[off:off + numel].view(sd[k].shape).clone()
+        return sd
+
+    def load_state_dict(self, sd, ema_sd=None):
+        with torch.no_grad():
+            for k, off, numel in self.layout:
+                self.params[off:off + numel].copy_(sd[k].reshape(-1).float())
+                self.ema[off:off + numel].copy_((ema_sd or sd)[k].reshape(-1).float())
+        with torch.cuda.device(self.device):
+            check(load_library().latte_trainer_sync_weights(self._h, stream_ptr()))
+
+    # ------------------------------------------------------------------ one iteration of train.py:197-236
+    def forward_backward(self, x_start, t, noise, y=None, drop_mask=None, return_model_out=False):
+        """q_sample + forward + training_losses + backward; gradients of ``terms['loss'].mean()`` land in ``self.grads``.
+        -> dict(loss, mse, vb [, model_out])."""
+        d = self.diffusion
+        x0 = x_start.to(device=self.device, dtype=torch.float32).contiguous()
+        B = x0.shape[0]
+        if B > self.max_batch:
+            raise LatteError(f"batch {B} exceeds max_batch {self.max_batch}")
+        nz = noise.to(device=self.device, dtype=torch.float32).contiguous()
+        if nz.shape != x0.shape:
+            raise AssertionError("noise.shape == x_start.shape")
+        t64 = t.to(device=self.device, dtype=torch.int64).contiguous()
+        yy = None
+        if self.model.extras == 2:
+            if y is None:
+                raise LatteError("class-conditional model: labels required")
+            yy = y.to(device=self.device, dtype=torch.int64)
+            if drop_mask is not None:                                              # LabelEmbedder.token_drop, latte.py:138-148
+                yy = torch.where(drop_mask.to(self.device), torch.full_like(yy, self.model.num_classes), yy)
+            if int(yy.min()) < 0 or int(yy.max()) > self.model.num_classes:
+                raise IndexError("label out of range")
+            yy = yy.contiguous()
+        terms = torch.empty(3, B, device=self.device)
+        mo = torch.empty(B, x0.shape[1], self.model.out_channels, x0.shape[3], x0.shape[4], device=self.device) if return_model_out else None
+        with torch.cuda.device(self.device):
+            check(load_library().latte_trainer_forward_backward(self._h, d._h, _LOSS[d.loss_type], ptr(x0), ptr(nz), ptr(t64),
+                                                                ptr(yy) if yy is not None else None, B, ptr(terms),
+                                                                ptr(mo) if mo is not None else None, stream_ptr()))
+        out = {"loss": terms[0], "mse": terms[1]}
+        if d.learn_sigma:
+            out["vb"] = terms[2]
+        if mo is not None:
+            out["model_out"] = mo
+        return out
+
+    def all_reduce_gradients(self):
+        """DDP's gradient averaging (train.py:125) as ONE collective over the flat gradient buffer: RCCL over xGMI when the
+        process group's backend is nccl, gloo in the CPU tests."""
+        average_gradients(self.grads, self.process_group)
+
+    def optimizer_step(self):
+        """clip_grad_norm_ + AdamW + update_ema; -> gradient norm (0-d tensor, device)."""
+        self.train_steps += 1
+        clip = int(self.train_steps - 1 >= self.start_clip_iter)                  # train.py:228-231
+        with torch.cuda.device(self.device):
+            check(load_library().latte_trainer_optimizer_step(self._h, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                                              self.train_steps, self.clip_max_norm, clip, self.ema_decay,
+                                                              ptr(self._norm), stream_ptr()))
+        if hasattr(self.model, "mark_weights_dirty"):
+            self.model.mark_weights_dirty()
+        return self._norm[0]
+
+    def train_step(self, x_start, y=None, t=None, noise=None, drop_mask=None):
+        """train.py:197-236 for one micro-batch (gradient_accumulation_steps = 1)."""
+        B = x_start.shape[0]
+        if t is None:
+            t = torch.randint(0, self.diffusion.num_timesteps, (B,), device=self.device)       # train.py:223
+        if noise is None:
+            noise = torch.randn_like(x_start, dtype=torch.float32, device=self.device)          # gd:733-734
+        if drop_mask is None and self.model.extras == 2 and self.class_dropout_prob > 0:
+            drop_mask = torch.rand(B, device=self.device) < self.class_dropout_prob              # latte.py:142-143
+        out = self.forward_backward(x_start, t, noise, y, drop_mask)
+        self.all_reduce_gradients()
+        out["grad_norm"] = self.optimizer_step()
+        return out

@@ -211,6 +211,63 @@ def training(rd):
     np.savez_compressed(os.path.join(OUT, "training_losses.npz"), **out)
 
 
+TRAIN_STEP = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=4, num_classes=5, extras=2,
+                  learn_sigma=True)
+
+
+def train_step_inputs():
+    """Inputs of the training-step fixture (tests/golden/train_step.npz): weights = oracle.latte_oracle.init_state_dict(seed 11)
+    (so the fixture only has to store what the REFERENCE computed), three samples with t = 0 (decoder NLL), an interior step and
+    the last one, one dropped label."""
+    from oracle import latte_oracle as lo
+    cfg = lo.LatteConfig(**TRAIN_STEP)
+    sd = lo.init_state_dict(cfg, seed=11)
+    g = torch.Generator("cpu").manual_seed(31)
+    x0 = (torch.randn(3, 4, 4, 8, 8, generator=g) * 0.6).clamp(-1.0, 1.0)
+    noise = torch.randn(3, 4, 4, 8, 8, generator=g)
+    t = torch.tensor([0, 500, 999], dtype=torch.int64)
+    y = torch.tensor([1, 4, 2], dtype=torch.int64)
+    drop = torch.tensor([False, False, True])
+    return cfg, sd, x0, noise, t, y, drop
+
+
+def train_step(rl, rd):
+    """One iteration of train.py:197-236 run by the reference objects: Latte(...).train() with the fixture's weights, the label
+    dropout forced to the fixture's mask through the RNG-free path (labels replaced by num_classes before the call with
+    class_dropout_prob = 0 -- LabelEmbedder.token_drop does exactly that replacement, latte.py:146-148),
+    create_diffusion("").training_losses, loss.mean().backward(), the gradient norm of utils.clip_grad_norm_ (:103),
+    torch.optim.AdamW(lr=1e-4, weight_decay=0).step(), update_ema(decay=0.9999)."""
+    import copy
+    cfg, sd, x0, noise, t, y, drop = train_step_inputs()
+    # (class_dropout_prob = 0 in the constructor would remove the null-class row from the table, latte.py:130-131: build with
+    #  the row, then switch the RNG path off)
+    model = rl.Latte(**TRAIN_STEP)
+    model.y_embedder.dropout_prob = 0.0
+    model.load_state_dict(sd)
+    model.train()
+    ema = copy.deepcopy(model)
+    yy = torch.where(drop, torch.full_like(y, TRAIN_STEP["num_classes"]), y)
+    d = rd.create_diffusion("")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)
+    terms = d.training_losses(model, x0, t, dict(y=yy), noise=noise)
+    terms["loss"].mean().backward()
+    out = {f"terms::{k}": v.detach().numpy() for k, v in terms.items()}
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    out["grad_norm"] = torch.norm(torch.stack([torch.norm(g_, 2.0) for g_ in grads.values()]), 2.0).numpy()
+    for k, g_ in grads.items():
+        out[f"grad::{k}"] = g_.numpy()
+    opt.step()
+    with torch.no_grad():
+        ep = dict(ema.named_parameters())
+        for n_, p_ in model.named_parameters():
+            ep[n_].mul_(0.9999).add_(p_.data, alpha=1 - 0.9999)
+    # the updated parameters / EMA of two tensors as spot checks (the rest follows from the gradients through the oracle)
+    for k in ("blocks.1.attn.qkv.weight", "final_layer.linear.bias", "y_embedder.embedding_table.weight"):
+        out[f"param::{k}"] = dict(model.named_parameters())[k].detach().numpy()
+        out[f"ema::{k}"] = ep[k].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rl, rd = load_reference_latte(), load_reference_diffusion()
@@ -220,6 +277,7 @@ def main():
     tiny_model(rl, rd, "tiny_textcond", TINY78, use_cfg=True, seed=300)
     sampler_types(rd)
     training(rd)
+    train_step(rl, rd)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
