@@ -19,6 +19,10 @@ Beside the headline, in the same JSON line:
   * `f16`: the same timed loop with f16 MFMA operands (the type guided runs use: latte_amd.Latte docstring);
   * `config3`: BASELINE config 3's per-GPU share -- UCF101 class-conditional Latte-XL/2, CFG 7.0, 8 samples =
     16 sequences per GPU through forward_with_cfg (aggregate guided sample-steps/s over all ranks);
+  * `config5`: BASELINE config 5's per-GPU share -- one optimisation step of train.py on Latte-B/2 16x256x256 synthetic
+    latents, local batch 5 (configs/ffs/ffs_train.yaml), forward + loss + backward + gradient all-reduce (N > 1: one RCCL
+    all-reduce of the 130 M-parameter fp32 gradient buffer) + clip + AdamW + EMA; samples/s over all ranks and the
+    algorithmic TFLOP/s (3 x forward FLOPs);
   * `cpu_baseline` (N = 1): the oracle's forward on the host cores, a forward-only proxy of the reference's
     p_sample_loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
     than it because it skips the reference's repeated adaLN rows: oracle/VALIDATION.md).
@@ -315,6 +319,27 @@ def main():
         side["config3"] = {"ms_per_step": dt3 * 1e3, "steps": n3}
         del m3
         torch.cuda.empty_cache()
+        # BASELINE config 5's per-GPU share: one optimisation step (train.py:197-236) of Latte-B/2, local batch 5
+        tb = 5
+        m5 = latte_amd.Latte_models["Latte-B/2"](input_size=32, num_frames=16, extras=1, max_batch=tb).to(device)
+        with torch.no_grad():
+            for p_ in m5.parameters():
+                if p_.requires_grad and float(p_.abs().max()) == 0.0:
+                    p_.normal_(0, 0.02)
+        trn = latte_amd.LatteTrainer(m5, latte_amd.create_diffusion(""), max_batch=tb)
+        x5 = torch.randn(tb, 16, 4, 32, 32, generator=torch.Generator("cpu").manual_seed(3000 + rank)).to(device)
+        for _ in range(2):
+            trn.train_step(x5)
+        torch.cuda.synchronize()
+        n5 = min(args.steps, 10)
+        t5 = time.perf_counter()
+        for _ in range(n5):
+            o5 = trn.train_step(x5)
+        torch.cuda.synchronize()
+        side["config5"] = {"ms_per_step": (time.perf_counter() - t5) / n5 * 1e3, "steps": n5,
+                           "loss_finite": bool(torch.isfinite(o5["loss"]).all())}
+        del trn, m5
+        torch.cuda.empty_cache()
         if dist is not None:   # max over ranks of every side timing
             keys = sorted(side)
             tt = torch.tensor([side[k]["ms_per_step"] for k in keys], device=device, dtype=torch.float64)
@@ -357,6 +382,15 @@ def main():
                                   "value": round(sps, 3), "unit": "guided sample-steps/s", "ms_per_step": round(v["ms_per_step"], 3),
                                   "steps": v["steps"], "global_batch": 8 * world,
                                   "model_mfma_frac": round(2 * sps / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+            elif k == "config5":
+                tb, D5, dep5, M5 = 5, 768, 12, 5 * 16 * 256
+                fwd5 = dep5 * 2.0 * M5 * 12 * D5 * D5 + (dep5 // 2) * (4.0 * tb * 16 * 256 * 256 * D5 + 4.0 * tb * 256 * 16 * 16 * D5)
+                res["config5"] = {"workload": "train.py step, Latte-B/2 16x256x256 synthetic latents, local batch 5, bf16 operands / "
+                                              "fp32 masters: forward + MSE/VB loss + backward + grad all-reduce + clip + AdamW + EMA",
+                                  "value": round(world * tb / (v["ms_per_step"] * 1e-3), 3), "unit": "training samples/s",
+                                  "ms_per_step": round(v["ms_per_step"], 3), "steps": v["steps"], "global_batch": tb * world,
+                                  "algorithmic_tflops_per_gpu": round(3 * fwd5 / (v["ms_per_step"] * 1e-3) / 1e12, 1),
+                                  "loss_finite": v.get("loss_finite")}
             else:
                 res[k] = {"value": round(world * B / (v["ms_per_step"] * 1e-3), 3), "unit": "sample-steps/s",
                           "ms_per_step": round(v["ms_per_step"], 4), "steps": v["steps"]}

@@ -115,15 +115,20 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
   }
 }
 
-// out[s * out_stride + col] = sum over the runs of sample s of partial[run][which][col]   (nsum partial rows per run)
-__global__ void sample_colsum_finalize_kernel(const float* __restrict__ partial, int runs_per_sample, int nsum, int which, int D,
-                                              float* __restrict__ out, int out_stride) {
+// out[s * out_stride + col] = sum over the runs of sample s of partial[run][which][col]   (nsum partial rows per run).
+// One block per (sample, 64 columns): 4 thread rows walk the runs with stride 4, fixed-order LDS reduction (deterministic).
+__global__ void __launch_bounds__(256) sample_colsum_finalize_kernel(const float* __restrict__ partial, int runs_per_sample, int nsum,
+                                                                     int which, int D, float* __restrict__ out, int out_stride) {
+  __shared__ float red[4][64];
   const int s = blockIdx.y;
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= D) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   float a = 0.f;
-  for (int r = 0; r < runs_per_sample; ++r) a += partial[(((size_t)s * runs_per_sample + r) * nsum + which) * D + col];
-  out[(size_t)s * out_stride + col] = a;
+  if (col < D)
+    for (int r = ty; r < runs_per_sample; r += 4) a += partial[(((size_t)s * runs_per_sample + r) * nsum + which) * D + col];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && col < D) out[(size_t)s * out_stride + col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 // ---------------------------------------------------------------------------------------------- LN + modulate, backward
@@ -565,8 +570,10 @@ inline int blocks_for(size_t n, int cap = 4096) {
     else return fail(LATTE_ERR_INVALID, "train kernel: unknown dtype"); \
   } while (0)
 
+// rows one wave walks: short runs keep >= 10 waves per CU busy at the training batch sizes (64-row runs: 320 waves for
+// M = 20480 -- the first version ran the LN backward at 0.8 TB/s); the partial rows cost 2 D floats per run
 int train_rows_per_run(int rps) {
-  for (int r = 64; r > 1; r >>= 1)
+  for (int r = 8; r > 1; r >>= 1)
     if (rps % r == 0) return r;
   return 1;
 }
@@ -589,7 +596,7 @@ int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gat
 #define CALL(DT) hipLaunchKernelGGL(gate_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dx, y, gate, gate_stride, dy, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 1, 0, D, dgate,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 1, 0, D, dgate,
                      out_stride);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -603,9 +610,9 @@ int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_
 #define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 2, 0, D, dshift,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 2, 0, D, dshift,
                      out_stride);
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 255) / 256, M / rps), dim3(256), 0, st, partial, rps / R, 2, 1, D, dscale,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 2, 1, D, dscale,
                      out_stride);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
