@@ -93,6 +93,61 @@ def main():
         rows.append((f"training_losses + q_sample, create_diffusion('{spec}', {kw}) [{', '.join(sorted(ref))}]",
                      "bit-identical" if ok else "MISMATCH"))
         assert ok, tag
+    # --- one optimisation step of train.py:197-236 (oracle/train_oracle.py) beside the reference objects, two steps each
+    import copy
+    from collections import OrderedDict
+    from oracle import train_oracle as tro
+    for extras in (1, 2):
+        kw = dict(depth=2, hidden_size=128, patch_size=2, num_heads=2, input_size=8, num_frames=4, num_classes=5, extras=extras,
+                  learn_sigma=True)
+        torch.manual_seed(0)
+        model = rl.Latte(**kw)
+        randomize_zero_init(model)
+        model.train()
+        ema = copy.deepcopy(model)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        cfg = lo.LatteConfig(**kw)
+        d = rd.create_diffusion("")
+        s = do.Schedule("")
+        g = torch.Generator("cpu").manual_seed(3)
+        x0 = torch.randn(3, 4, 4, 8, 8, generator=g)
+        noise = torch.randn(3, 4, 4, 8, 8, generator=g)
+        t = torch.tensor([0, 500, 999])
+        y = torch.tensor([1, 4, 2]) if extras == 2 else None
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)          # train.py:127
+        state, ema_sd = {}, {k: v.clone() for k, v in sd.items() if k in dict(model.named_parameters())}
+        worst_g = worst_p = worst_e = 0.0
+        terms_equal = True
+        for step in (1, 2):
+            torch.manual_seed(100 + step)
+            drop = (torch.rand(3) < 0.1) if extras == 2 else None                      # LabelEmbedder.token_drop's draw (latte.py:142-143)
+            torch.manual_seed(100 + step)
+            terms = d.training_losses(model, x0, t, dict(y=y), noise=noise)
+            terms["loss"].mean().backward()
+            gr = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            tot = torch.norm(torch.stack([torch.norm(g_, 2.0) for g_ in gr.values()]), 2.0)     # utils.py:103
+            clip = step == 2
+            coef = torch.clamp(0.1 / (tot + 1e-6), max=1.0) if clip else torch.tensor(1.0)       # utils.py:108-114
+            if clip:
+                for p in model.parameters():
+                    if p.grad is not None:
+                        p.grad.mul_(coef)
+            opt.step()
+            opt.zero_grad()
+            with torch.no_grad():                                                       # utils.update_ema (utils.py:191-200)
+                ep = OrderedDict(ema.named_parameters())
+                for n_, p_ in model.named_parameters():
+                    ep[n_].mul_(0.9999).add_(p_.data, alpha=1 - 0.9999)
+            r = tro.train_step(sd, ema_sd, state, step, cfg, s, x0, t, noise, y, drop, clip=clip)
+            terms_equal = terms_equal and all(torch.allclose(terms[k].detach(), r["terms"][k], rtol=1e-6, atol=1e-7) for k in terms)
+            worst_g = max(worst_g, max(rel(r["grads"][k], gr[k] * coef) for k in gr))
+            worst_p = max(worst_p, max(float((r["sd"][k] - p.data).abs().max()) for k, p in model.named_parameters()))
+            worst_e = max(worst_e, max(float((r["ema"][k] - p.data).abs().max()) for k, p in ema.named_parameters()))
+            assert abs(float(tot) - float(r["grad_norm"])) < 1e-5 * float(tot)
+            sd, state, ema_sd = {**sd, **r["sd"]}, r["state"], r["ema"]
+        rows.append((f"train.py step x2 (extras={extras}; 2nd step clipped): loss terms / gradients / AdamW parameters / EMA",
+                     f"terms equal to 1e-6: {terms_equal}; max rel-L2 gradient diff {worst_g:.1e}; max |param diff| {worst_p:.1e}; max |ema diff| {worst_e:.1e}"))
+        assert terms_equal and worst_g < 1e-5 and worst_p < 1e-6 and worst_e < 1e-6
     with open("oracle/VALIDATION.md", "w") as f:
         f.write("# Oracle vs. the real reference (run in the build container)\n\n"
                 "Produced by `python -m oracle.validate_oracle --xl`; reference = `/root/reference` unmodified "
