@@ -239,6 +239,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
   tile_coords((g.M + BM - 1) / BM, g.N / BN, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int K = g.K;
+  // split K (see gemm_kernel): blockIdx.y owns [y k_chunk, (y + 1) k_chunk) of the contraction, partial product to its own slab
+  int k_begin = 0, k_len = K;
+  if (g.k_chunk > 0) {
+    k_begin = blockIdx.y * g.k_chunk;
+    k_len = min(g.k_chunk, K - k_begin);
+    g.out = (void*)((float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride);
+  }
 
   // DMA addressing: ONE 32-bit per-lane byte offset (row-in-group, swizzled chunk); tile base, row-group
   // stride and K offset stay in scalar registers (SGPR base + VGPR offset form: no 64-bit pointer VGPRs).
@@ -253,8 +260,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
   };
   const unsigned off_pro = lane_off(wave * 8);          // prologue: rows wave*8 + 64 j  (64 j does not move the swizzle)
   const unsigned off_main = lane_off(wn * 8);           // main loop: rows wn*8 + 32 j
-  const char* a_tile = (const char*)(g.A + (size_t)m0 * K);
-  const char* b_tile = (const char*)(g.W + (size_t)n0 * K);
+  const char* a_tile = (const char*)(g.A + (size_t)m0 * K + k_begin);
+  const char* b_tile = (const char*)(g.W + (size_t)n0 * K + k_begin);
   const size_t row_bytes = (size_t)K * 2;
 
   auto dma_a_half = [&](int kt) {   // own 128 A rows of K tile kt: row-groups wn + 4 j
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / 64;
+  const int nk = k_len / 64;
   {  // prologue: K tile 0 by all waves; G1 also places its share of B(1) (its "C(-1)" slot)
     char* sA = smem + wave * 1024;
     char* sB = sA + A_BYTES;
@@ -803,7 +810,9 @@ template <int BN, int DT>
 int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
   constexpr int LDS = 2 * (256 + BN) * 128;
   const int tiles = ((a.M + 255) / 256) * (a.N / BN);
-  dim3 grid(tiles), block(512);
+  const int splits = a.k_chunk > 0 ? (a.K + a.k_chunk - 1) / a.k_chunk : 1;
+  if (a.k_chunk % 64) return fail(LATTE_ERR_INVALID, "gemm: k_chunk must be a multiple of 64");
+  dim3 grid(tiles, splits), block(512);
 #define LATTE_GEMM_CASE(E)                                                                           \
   case E: {                                                                                          \
     auto kern = gemm_pp_kernel<BN, E, DT>;                                                           \

@@ -80,8 +80,7 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ partial, int M, int D, int rps, int R) {
   const int lane = threadIdx.x & 63;
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int row0 = run * R;
-  if (row0 >= M) return;
+  const int row0 = run * R;          // (launcher: M / R is a multiple of 4, so no wave of a block is out of range)
   const int nt = D >> 2;
   const float4* g4 = (const float4*)(gate + (size_t)(row0 / rps) * gate_stride);
   float4 g[NQ_MAX], acc[NQ_MAX];
@@ -108,12 +107,32 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
       }
     }
   }
+  // the block's 4 waves (4 consecutive runs of one sample) are added through LDS: one partial row per block
+  extern __shared__ __attribute__((aligned(16))) float red_t[];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < NQ_MAX; ++c) {
     const int ch = c * 64 + lane;
-    if (ch < nt) ((float4*)(partial + (size_t)run * D))[ch] = acc[c];
+    if (ch < nt && wv > 0) ((float4*)(red_t + (size_t)(wv - 1) * D))[ch] = acc[c];
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch < nt) {
+        float4 a = acc[c];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 o = ((const float4*)(red_t + (size_t)w * D))[ch];
+          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        ((float4*)(partial + (size_t)blockIdx.x * D))[ch] = a;
+      }
+    }
   }
 }
+
 
 // out[s * out_stride + col] = sum over the runs of sample s of partial[run][which][col]   (nsum partial rows per run).
 // One block per (sample, 64 columns): 4 thread rows walk the runs with stride 4, fixed-order LDS reduction (deterministic).
@@ -140,8 +159,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ 
                                                      float* dx_out, float* __restrict__ partial, int M, int D, int rps, int R) {
   const int lane = threadIdx.x & 63;
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int row0 = run * R;
-  if (row0 >= M) return;
+  const int row0 = run * R;          // (launcher: M / R is a multiple of 4)
   const int nt = D >> 2;
   const float invD = 1.0f / (float)D;
   const float4* sc4 = (const float4*)(scale + (size_t)(row0 / rps) * mod_stride);
@@ -205,12 +223,33 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ 
       }
     }
   }
+  extern __shared__ __attribute__((aligned(16))) float red_t[];   // [3 waves][2][D]
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < NQ_MAX; ++c) {
     const int ch = c * 64 + lane;
-    if (ch < nt) {
-      ((float4*)(partial + ((size_t)run * 2 + 0) * D))[ch] = a_sh[c];
-      ((float4*)(partial + ((size_t)run * 2 + 1) * D))[ch] = a_sc[c];
+    if (ch < nt && wv > 0) {
+      ((float4*)(red_t + ((size_t)(wv - 1) * 2 + 0) * D))[ch] = a_sh[c];
+      ((float4*)(red_t + ((size_t)(wv - 1) * 2 + 1) * D))[ch] = a_sc[c];
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int c = 0; c < NQ_MAX; ++c) {
+      const int ch = c * 64 + lane;
+      if (ch < nt) {
+        float4 a = a_sh[c], b = a_sc[c];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 o = ((const float4*)(red_t + ((size_t)w * 2 + 0) * D))[ch];
+          const float4 q = ((const float4*)(red_t + ((size_t)w * 2 + 1) * D))[ch];
+          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+          b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+        }
+        ((float4*)(partial + ((size_t)blockIdx.x * 2 + 0) * D))[ch] = a;
+        ((float4*)(partial + ((size_t)blockIdx.x * 2 + 1) * D))[ch] = b;
+      }
     }
   }
 }
@@ -593,10 +632,11 @@ int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gat
                     int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
   if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "gate_bwd: need D % 4 == 0 and D <= 1280");
   const int R = train_rows_per_run(rps), runs = M / R;
-#define CALL(DT) hipLaunchKernelGGL(gate_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dx, y, gate, gate_stride, dy, partial, M, D, rps, R)
+  if (rps % (4 * R)) return fail(LATTE_ERR_INVALID, "gate_bwd: rows per sample must be a multiple of 4 runs");
+#define CALL(DT) hipLaunchKernelGGL(gate_bwd_kernel<DT>, dim3(runs / 4), dim3(256), 3 * D * sizeof(float), st, dx, y, gate, gate_stride, dy, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 1, 0, D, dgate,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 1, 0, D, dgate,
                      out_stride);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -607,12 +647,13 @@ int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_
                   float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
   if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "ln_bwd: need D % 4 == 0 and D <= 1280");
   const int R = train_rows_per_run(rps), runs = M / R;
-#define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3((runs + 3) / 4), dim3(256), 0, st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
+  if (rps % (4 * R)) return fail(LATTE_ERR_INVALID, "ln_bwd: rows per sample must be a multiple of 4 runs");
+#define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3(runs / 4), dim3(256), 6 * D * sizeof(float), st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 2, 0, D, dshift,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 0, D, dshift,
                      out_stride);
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / R, 2, 1, D, dscale,
+  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 1, D, dscale,
                      out_stride);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
