@@ -220,6 +220,18 @@ int latte_trainer_sync_weights(latte_trainer_t* e, void* stream);
  * terms_out device float [3][batch] = loss, mse, vb; model_out_copy optional [batch, F, C_out, H, W]. */
 int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
                                    const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream);
+/* The same micro-batch in pieces, for a data-parallel driver that overlaps its gradient all-reduce with the backward (what
+ * DistributedDataParallel's buckets do for train.py:125): latte_trainer_begin = forward + loss terms + d loss / d model_output;
+ * then latte_trainer_backward_stage(k) for k = 0 .. latte_trainer_num_stages() - 1 IN ORDER (0 = final layer, 1 .. depth =
+ * blocks depth-1 .. 0, depth + 1 = patch embed and the t / y embedders).  After stage k the contiguous slice
+ * latte_trainer_stage_range(k) of the gradient buffer is final: the driver enqueues its collective on that slice (28 MB per
+ * Latte-B/2 block, 96 MB per XL/2 block: large buckets, as the per-link-bound xGMI ring wants) while the next stages run.
+ * `y` must stay alive until the last stage. */
+int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
+                        const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream);
+int latte_trainer_num_stages(const latte_trainer_t* e);
+int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offset, int64_t* numel);
+int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream);
 /* clip_grad_norm_ (utils.py:72-117: total 2-norm, g *= min(max_norm / (norm + 1e-6), 1) when clip != 0) + AdamW + update_ema
  * (utils.py:191-200) on the bound buffers; step counts from 1; norm_out: optional device float[2] = {norm, applied coefficient} */
 int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

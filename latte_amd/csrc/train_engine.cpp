@@ -59,6 +59,8 @@ struct latte_trainer {
   half_t *dyD = nullptr, *dhH = nullptr, *dxnH = nullptr, *dqkvH = nullptr, *xnh = nullptr, *at = nullptr, *bt = nullptr;
   int64_t wg_ws_floats = 0, ng_ws_floats = 0, loss_ws_floats = 0;
   bool weights_synced = false;
+  int cur_batch = 0, next_stage = 1 << 30;   // step in flight: batch, labels (caller keeps them alive), next backward stage
+  const int64_t* cur_y = nullptr;
   std::vector<void*> allocs;
 };
 
@@ -271,9 +273,10 @@ int latte_trainer_sync_weights(latte_trainer_t* e, void* stream) {
   return LATTE_OK;
 }
 
+// Forward with saved activations + loss terms + d loss / d model_output; the backward follows in stages (below).
 // terms_out: device float [3][batch] = loss, mse, vb;  model_out_copy: optional device copy of the model output
-int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
-                                   const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream) {
+int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
+                        const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream) {
   if (!e || !s || !x_start || !noise || !t || !terms_out) return fail(LATTE_ERR_INVALID, "train step: null argument");
   if (!e->Pm) return fail(LATTE_ERR_STATE, "train step: bind the parameter buffers first");
   if (batch <= 0 || batch > e->max_batch) return fail(LATTE_ERR_STATE, "train step: batch exceeds max_batch");
@@ -360,7 +363,62 @@ int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s
   if ((rc = launch_loss_grad(tab, s->num_timesteps, s->mean_type, s->var_type, x_start, e->x_t, noise, e->model_out, t, B, F, e->Cin, hw,
                              vb_scale, e->dmodel_out, st))) return rc;
 
-  // ================================================================ backward
+  LATTE_HIP(hipMemsetAsync(e->dc, 0, sizeof(float) * (size_t)B * D, st));   // d SiLU(c), summed over the adaLN linears by the stages
+  e->cur_batch = B;
+  e->cur_y = y;
+  e->next_stage = 0;
+  return LATTE_OK;
+}
+
+// adaLN linear of block i (i == depth: the final layer's): bias / weight gradients from the finished dmod rows, and its
+// contribution to d SiLU(c)
+static int adaln_bwd(latte_trainer_t* e, int i, hipStream_t st) {
+  const auto& c = e->cfg;
+  const int D = e->D, B = e->cur_batch, nmod = e->nmod;
+  const bool fin = i == c.depth;
+  const std::string p = fin ? "final_layer.adaLN_modulation.1." : "blocks." + std::to_string(i) + ".adaLN_modulation.1.";
+  const int N = fin ? 2 * D : 6 * D;
+  const float* dm = e->dmod + (size_t)i * 6 * D;
+  int rc;
+  if ((rc = launch_rows_sum(dm, B, nmod, N, G_(e, p + "bias"), 0, st))) return rc;
+  if ((rc = launch_naive_gemm(dm, 1, nmod, e->csilu, D, 1, G_(e, p + "weight"), D, 1, N, D, B, 1.0f, 0, st))) return rc;          // dW[n, k]
+  if ((rc = launch_naive_gemm(dm, nmod, 1, P_(e, p + "weight"), D, 1, e->dtmp, D, 1, B, D, N, 1.0f, 0, st, 48, e->ng_ws))) return rc;  // d csilu
+  return launch_add_rows(e->dc, e->dtmp, (size_t)B * D, st);
+}
+
+int latte_trainer_num_stages(const latte_trainer_t* e) { return e ? e->cfg.depth + 2 : 0; }
+
+// the slice of the flat gradient buffer that stage `stage` finalises: 0 = final layer, 1 .. depth = blocks depth-1 .. 0,
+// depth + 1 = patch embed + t / y embedders (the head of the buffer)
+int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offset, int64_t* numel) {
+  if (!e || !offset || !numel || stage < 0 || stage > e->cfg.depth + 1) return fail(LATTE_ERR_INVALID, "stage_range: bad stage");
+  auto off = [&](const std::string& k) { return e->params[e->index.at(k)].offset; };
+  const int depth = e->cfg.depth;
+  if (stage == 0) { *offset = off("final_layer.linear.weight"); *numel = e->total - *offset; }
+  else if (stage <= depth) {
+    const int i = depth - stage;
+    *offset = off("blocks." + std::to_string(i) + ".attn.qkv.weight");
+    const int64_t end = i + 1 < depth ? off("blocks." + std::to_string(i + 1) + ".attn.qkv.weight") : off("final_layer.linear.weight");
+    *numel = end - *offset;
+  } else { *offset = 0; *numel = off("blocks.0.attn.qkv.weight"); }
+  return LATTE_OK;
+}
+
+// Backward of one stage (in order 0, 1, ..., depth + 1 after latte_trainer_begin).  After stage k the gradient slice
+// latte_trainer_stage_range(k) is final: the data-parallel driver starts its all-reduce while the next stages run.
+int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream) {
+  if (!e || !e->Pm) return fail(LATTE_ERR_STATE, "backward_stage: no step in flight");
+  if (stage != e->next_stage || stage > e->cfg.depth + 1) return fail(LATTE_ERR_STATE, "backward_stage: stages run in order after latte_trainer_begin");
+  e->next_stage = stage + 1;
+  const auto& c = e->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  const int D = e->D, T = e->T, F = e->F, Hm = e->Hm, B = e->cur_batch, dt = e->dt, nmod = e->nmod;
+  const int M = B * F * T, rps = F * T;
+  const int64_t* y = e->cur_y;
+  if (stage == 0) {
+  float* xl = e->xs[2 * c.depth];
+  const float* fm = e->mod + (size_t)c.depth * 6 * D;
   // final layer: out = unpatchify(Linear(LN-mod(x)))
   if ((rc = launch_unpatchify_bwd(e->dmodel_out, e->dtok, B * F, e->G, c.patch_size, e->Cout, st))) return rc;
   if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dtok, e->P, 1, G_(e, "final_layer.linear.bias"), e->P, 1, 1, e->P, M, 1.0f, 0, st, 64, e->ng_ws)))
@@ -375,7 +433,10 @@ int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s
     float* dm = e->dmod + (size_t)c.depth * 6 * D;
     if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->part_rows, dm, dm + D, nmod, M, D, rps, dt, st))) return rc;
   }
-  for (int i = c.depth - 1; i >= 0; --i) {
+  return adaln_bwd(e, c.depth, st);
+  }
+  if (stage <= c.depth) {
+    const int i = c.depth - stage;
     const bool spatial = (i % 2) == 0;
     const std::string p = "blocks." + std::to_string(i) + ".";
     BlockBuf& b = e->blk[i];
@@ -404,26 +465,14 @@ int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s
     if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st))) return rc;
     if ((rc = gemm_half(e, e->dqkvH, b.qkv_wt, e->zeros, e->dxnH, M, D, 3 * D, st))) return rc;
     if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->part_rows, dm, dm + D, nmod, M, D, rps, dt, st))) return rc;
+    return adaln_bwd(e, i, st);
   }
   // ---- patch embed (latte.py:233,330-331): tokens = pix W^T + b + pos
   if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dx, D, 1, G_(e, "x_embedder.proj.bias"), D, 1, 1, D, M, 1.0f, 0, st, 64, e->ng_ws))) return rc;
   if ((rc = launch_im2col_patch(e->x_t, e->pix, B * F, e->G, c.patch_size, e->Cin, st))) return rc;
   if ((rc = launch_naive_gemm(e->dx, 1, D, e->pix, e->KPE, 1, G_(e, "x_embedder.proj.weight"), e->KPE, 1, D, e->KPE, M, 1.0f, 0, st, 64,
                               e->ng_ws))) return rc;
-  // ---- conditioning: mod rows -> adaLN linears -> SiLU -> c = temb (+ y_emb) -> t_embedder MLP
-  LATTE_HIP(hipMemsetAsync(e->dc, 0, sizeof(float) * (size_t)B * D, st));   // d SiLU(c), summed over the adaLN linears
-  for (int i = 0; i <= c.depth; ++i) {
-    const bool fin = i == c.depth;
-    const std::string p = fin ? "final_layer.adaLN_modulation.1." : "blocks." + std::to_string(i) + ".adaLN_modulation.1.";
-    const int N = fin ? 2 * D : 6 * D;
-    const float* dm = e->dmod + (size_t)i * 6 * D;
-    if ((rc = launch_rows_sum(dm, B, nmod, N, G_(e, p + "bias"), 0, st))) return rc;
-    // dW[n, k] = sum_b dmod[b, n] csilu[b, k]
-    if ((rc = launch_naive_gemm(dm, 1, nmod, e->csilu, D, 1, G_(e, p + "weight"), D, 1, N, D, B, 1.0f, 0, st))) return rc;
-    // d csilu[b, k] += sum_n dmod[b, n] W[n, k]
-    if ((rc = launch_naive_gemm(dm, nmod, 1, P_(e, p + "weight"), D, 1, e->dtmp, D, 1, B, D, N, 1.0f, 0, st, 48, e->ng_ws))) return rc;
-    if ((rc = launch_add_rows(e->dc, e->dtmp, (size_t)B * D, st))) return rc;
-  }
+  // ---- conditioning tail: d SiLU(c) (summed by the stages) -> c = temb (+ y_emb) -> t_embedder MLP
   if ((rc = launch_silu_bwd(e->dc, e->cvec, e->dtmp, (size_t)B * D, 0, st))) return rc;     // dtmp = dc (gradient of c = temb + y_emb)
   if (c.extras == 2) {
     if ((rc = launch_embedding_bwd(e->dtmp, y, G_(e, "y_embedder.embedding_table.weight"), B, D, st))) return rc;
@@ -437,6 +486,14 @@ int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s
   if ((rc = launch_rows_sum(e->dtmp2, B, D, D, G_(e, "t_embedder.mlp.0.bias"), 0, st))) return rc;
   if ((rc = launch_naive_gemm(e->dtmp2, 1, D, e->tfreq, 256, 1, G_(e, "t_embedder.mlp.0.weight"), 256, 1, D, 256, B, 1.0f, 0, st))) return rc;
   return LATTE_OK;
+}
+
+// begin + every stage: one micro-batch, gradients of terms["loss"].mean() in the bound gradient buffer
+int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s, int loss_type, const float* x_start, const float* noise,
+                                   const int64_t* t, const int64_t* y, int batch, float* terms_out, float* model_out_copy, void* stream) {
+  int rc = latte_trainer_begin(e, s, loss_type, x_start, noise, t, y, batch, terms_out, model_out_copy, stream);
+  for (int k = 0; !rc && k < latte_trainer_num_stages(e); ++k) rc = latte_trainer_backward_stage(e, k, stream);
+  return rc;
 }
 
 // clip_grad_norm_ (utils.py:72-117) + AdamW (train.py:127) + update_ema (utils.py:191-200) on the bound flat buffers, then the

@@ -21,15 +21,23 @@ from .models import Latte
 FROZEN = ("pos_embed", "temp_embed")   # nn.Parameter(requires_grad=False), latte.py:246-247
 
 
-def average_gradients(flat_grads, group=None):
-    """DistributedDataParallel's gradient averaging (train.py:125) as ONE all-reduce over a flat gradient buffer: RCCL over
-    xGMI when the process group's backend is nccl, gloo in the CPU tests.  No-op without an initialised process group."""
+def _world(group=None):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        world = dist.get_world_size(group)
-        if world > 1:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-            flat_grads.div_(world)
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def average_gradients(flat_grads, group=None, async_op=False):
+    """DistributedDataParallel's gradient averaging (train.py:125) as one all-reduce over a (slice of a) flat gradient buffer:
+    RCCL over xGMI when the process group's backend is nccl, gloo in the CPU tests.  No-op without an initialised process group.
+    async_op: returns the work handle (None when there is nothing to do); the caller divides by the world size after wait()."""
+    import torch.distributed as dist
+    world = _world(group)
+    if world <= 1:
+        return None if async_op else flat_grads
+    if async_op:
+        return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    flat_grads.div_(world)
     return flat_grads
 
 
@@ -61,6 +69,7 @@ class LatteTrainer:
         self.clip_max_norm, self.start_clip_iter, self.ema_decay = float(clip_max_norm), int(start_clip_iter), float(ema_decay)
         self.class_dropout_prob = float(class_dropout_prob)
         self.process_group = process_group
+        self.always_staged = False     # test hook: take the staged (bucketed) backward path without a process group
         self.train_steps = 0
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -129,9 +138,11 @@ class LatteTrainer:
             check(load_library().latte_trainer_sync_weights(self._h, stream_ptr()))
 
     # ------------------------------------------------------------------ one iteration of train.py:197-236
-    def forward_backward(self, x_start, t, noise, y=None, drop_mask=None, return_model_out=False):
-        """q_sample + forward + training_losses + backward; gradients of ``terms['loss'].mean()`` land in ``self.grads``.
+    def forward_backward(self, x_start, t, noise, y=None, drop_mask=None, return_model_out=False, overlap_all_reduce=False):
+        """q_sample + forward + training_losses + backward; gradients of ``terms['loss'].mean()`` land in ``self.grads``
+        (overlap_all_reduce: already averaged over the process group, bucket by bucket under the backward).
         -> dict(loss, mse, vb [, model_out])."""
+        self._reduced = False
         d = self.diffusion
         x0 = x_start.to(device=self.device, dtype=torch.float32).contiguous()
         B = x0.shape[0]
@@ -153,10 +164,29 @@ class LatteTrainer:
             yy = yy.contiguous()
         terms = torch.empty(3, B, device=self.device)
         mo = torch.empty(B, x0.shape[1], self.model.out_channels, x0.shape[3], x0.shape[4], device=self.device) if return_model_out else None
+        lib = load_library()
+        args = (self._h, d._h, _LOSS[d.loss_type], ptr(x0), ptr(nz), ptr(t64), ptr(yy) if yy is not None else None, B, ptr(terms),
+                ptr(mo) if mo is not None else None, stream_ptr())
         with torch.cuda.device(self.device):
-            check(load_library().latte_trainer_forward_backward(self._h, d._h, _LOSS[d.loss_type], ptr(x0), ptr(nz), ptr(t64),
-                                                                ptr(yy) if yy is not None else None, B, ptr(terms),
-                                                                ptr(mo) if mo is not None else None, stream_ptr()))
+            if not overlap_all_reduce:
+                check(lib.latte_trainer_forward_backward(*args))
+            else:
+                # bucketed data parallelism: as soon as a stage's gradient slice is final its all-reduce is enqueued (RCCL runs it
+                # on its own stream behind the kernels already launched) while the next stages' kernels follow on this stream
+                check(lib.latte_trainer_begin(*args))
+                handles = []
+                for k in range(lib.latte_trainer_num_stages(self._h)):
+                    check(lib.latte_trainer_backward_stage(self._h, k, stream_ptr()))
+                    off, n = _lib.c_i64(), _lib.c_i64()
+                    check(lib.latte_trainer_stage_range(self._h, k, off, n))
+                    h = average_gradients(self.grads[off.value:off.value + n.value], self.process_group, async_op=True)
+                    if h is not None:
+                        handles.append(h)
+                for h in handles:
+                    h.wait()
+                if handles:
+                    self.grads.div_(_world(self.process_group))
+                self._reduced = True
         out = {"loss": terms[0], "mse": terms[1]}
         if d.learn_sigma:
             out["vb"] = terms[2]
@@ -167,7 +197,9 @@ class LatteTrainer:
     def all_reduce_gradients(self):
         """DDP's gradient averaging (train.py:125) as ONE collective over the flat gradient buffer: RCCL over xGMI when the
         process group's backend is nccl, gloo in the CPU tests."""
-        average_gradients(self.grads, self.process_group)
+        if not getattr(self, "_reduced", False):
+            average_gradients(self.grads, self.process_group)
+            self._reduced = True
 
     def optimizer_step(self):
         """clip_grad_norm_ + AdamW + update_ema; -> gradient norm (0-d tensor, device)."""
@@ -190,7 +222,7 @@ class LatteTrainer:
             noise = torch.randn_like(x_start, dtype=torch.float32, device=self.device)          # gd:733-734
         if drop_mask is None and self.model.extras == 2 and self.class_dropout_prob > 0:
             drop_mask = torch.rand(B, device=self.device) < self.class_dropout_prob              # latte.py:142-143
-        out = self.forward_backward(x_start, t, noise, y, drop_mask)
+        out = self.forward_backward(x_start, t, noise, y, drop_mask, overlap_all_reduce=_world(self.process_group) > 1 or self.always_staged)
         self.all_reduce_gradients()
         out["grad_norm"] = self.optimizer_step()
         return out
