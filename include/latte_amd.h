@@ -246,6 +246,13 @@ typedef struct latte_vae latte_vae_t;
 /* latent_size: H = W of the latent (multiple of 16); max_frames: largest N of one decode call; compute_dtype: LATTE_DTYPE_F16
  * only (MFMA operands f16 as in the reference's fp16 decode, residual stream fp32) */
 int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out);
+/* diffusers.AutoencoderKLTemporalDecoder (sample/sample_t2x.py:31-32, pipeline_latte.py:779-798: vae.decode(z[i : i + 14],
+ * num_frames=n).sample): the same handle type and entry points; every resnet is a SpatioTemporalResBlock (keys
+ * "...resnets.N.spatial_res_block.*", "...temporal_res_block.*" with Conv3d weights [C, C, 3, 1, 1], "...time_mixer.mix_factor"),
+ * there is no post_quant_conv, and "decoder.time_conv_out.*" follows conv_out.  ONE latte_vae_decode call decodes ONE chunk:
+ * its n_frames frames are the temporal extent (max_frames >= the chunk length).  Restated from memory of diffusers 0.24.0:
+ * parity unpinned (oracle/vae_temporal_oracle.py). */
+int latte_vae_create_temporal(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out);
 void latte_vae_destroy(latte_vae_t* v);
 /* load_state_dict for ONE tensor named by its diffusers key ("decoder.up_blocks.2.resnets.0.conv1.weight",
  * "post_quant_conv.bias", ...); fp32, reference shape; encoder.* / quant_conv.* keys are not accepted. */

@@ -12,7 +12,7 @@ from .models import Latte, Latte_models, find_model, get_models  # noqa: F401
 from .pipeline import LattePipeline  # noqa: F401
 from .t2v import LatteT2V  # noqa: F401
 from .training import LatteTrainer  # noqa: F401
-from .vae import AutoencoderKL  # noqa: F401
+from .vae import AutoencoderKL, AutoencoderKLTemporalDecoder  # noqa: F401
 from .video_io import read_avi, write_avi  # noqa: F401
 from . import parallel  # noqa: F401
 

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "latte_t2v_guided_ddim_loop": (c_int, [c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_f32, c_int, c_void]),
     "latte_bench_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_f32), c_void]),
     "latte_vae_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void)]),
+    "latte_vae_create_temporal": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void)]),
     "latte_vae_destroy": (None, [c_void]),
     "latte_vae_num_keys": (c_int, [c_void]),
     "latte_vae_key": (c_char, [c_void, c_int]),

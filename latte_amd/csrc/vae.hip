@@ -41,6 +41,8 @@ struct ConvArgs {
   float* out32;         // fp32 output: out32 = acc + bias (+ res32), nothing is rounded to half
   const half_t* zeros;  // >= 16 bytes of zeros (padded taps)
   int N, Hin, Win, Cin, Cout, ups;   // Hout = Hin << ups
+  int taps3;   // 1: a 3-tap convolution along the image ROWS (w = [Cout, 3 * Cin], k = ky * Cin + ci; the temporal Conv3d (3,1,1) of
+               // AutoencoderKLTemporalDecoder on the "image" [frames][h * w] of one video)
 };
 
 // 128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators.
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int Hout = g.Hin << g.ups, Wout = g.Win << g.ups;
   const int M = g.N * Hout * Wout;
-  const int K = 9 * g.Cin;
+  const int K = (g.taps3 ? 3 : 9) * g.Cin;
   int tm, tn;
   tile_coords((M + BM - 1) / BM, g.Cout / BN, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
     char* sA = smem + buf * STAGE + wave * 1024;
     char* sB = sA + A_BYTES;
     const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int dy = g.taps3 ? tap - 1 : tap / 3 - 1, dx = g.taps3 ? 0 : tap - (tap / 3) * 3 - 1;
 #pragma unroll
     for (int j = 0; j < INSTR; ++j) {
       const int yy = py[j] + dy, xx = px[j] + dx;
@@ -243,7 +245,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
 template <int DT, bool SILU, bool IN32>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const void* __restrict__ x, half_t* __restrict__ y,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int HW, int C, size_t total_oct) {
+                                                       const float* __restrict__ beta, int HW, int C, size_t total_oct,
+                                                       half_t* __restrict__ y_lo) {
   const int cpg = C >> 5, oct_per_px = C >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_oct; i += (size_t)gridDim.x * blockDim.x) {
     const int oct = (int)(i % oct_per_px);
@@ -267,6 +270,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const void* __restrict__ 
     }
     const u32x4 w = {pack2<DT>(o[0], o[1]), pack2<DT>(o[2], o[3]), pack2<DT>(o[4], o[5]), pack2<DT>(o[6], o[7])};
     *(u32x4*)(y + i * 8) = w;
+    if (y_lo != nullptr) {   // the rounding residual as a second half tensor (split-operand convolutions)
+      float h[8];
+      unpack2<DT>(w[0], h[0], h[1]); unpack2<DT>(w[1], h[2], h[3]);
+      unpack2<DT>(w[2], h[4], h[5]); unpack2<DT>(w[3], h[6], h[7]);
+      const u32x4 l = {pack2<DT>(o[0] - h[0], o[1] - h[1]), pack2<DT>(o[2] - h[2], o[3] - h[3]),
+                       pack2<DT>(o[4] - h[4], o[5] - h[5]), pack2<DT>(o[6] - h[6], o[7] - h[7])};
+      *(u32x4*)(y_lo + i * 8) = l;
+    }
   }
 }
 
@@ -429,6 +440,67 @@ __global__ void pack_small_w_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// Conv3d weight [Cout, Cin, 3, 1, 1] -> half [Cout][3 * Cin] (k = tap * Cin + ci), scaled by sigmoid(*mix) when mix != nullptr
+// (AlphaBlender with switch_spatial_to_temporal_mix: out = x_spatial + sigmoid(mix_factor) * temporal branch)
+template <int DT>
+__global__ void pack_conv_t_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin, const float* __restrict__ mix,
+                                   half_t* __restrict__ out_lo) {
+  const float sc = mix ? 1.0f / (1.0f + __expf(-mix[0])) : 1.0f;
+  const size_t total = (size_t)Cout * Cin * 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / ((size_t)Cin * 3));
+    const int r = (int)(i - (size_t)co * Cin * 3);
+    const int tap = r / Cin, ci = r - tap * Cin;
+    const float v = w[((size_t)co * Cin + ci) * 3 + tap] * sc;
+    if constexpr (DT == LATTE_DTYPE_BF16) {
+      const __bf16 h = (__bf16)v;
+      out[i] = __builtin_bit_cast(half_t, h);
+      if (out_lo) out_lo[i] = __builtin_bit_cast(half_t, (__bf16)(v - (float)h));
+    } else {
+      const _Float16 h = (_Float16)v;
+      out[i] = __builtin_bit_cast(half_t, h);
+      if (out_lo) out_lo[i] = __builtin_bit_cast(half_t, (_Float16)(v - (float)h));
+    }
+  }
+}
+__global__ void scale_by_sigmoid_kernel(const float* __restrict__ in, float* __restrict__ out, int n, const float* __restrict__ mix) {
+  const float sc = 1.0f / (1.0f + __expf(-mix[0]));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * sc;
+}
+// time_conv_out: Conv3d(3, 3, (3, 1, 1), padding (1, 0, 0)) over the T frames of one video, fp32 NCHW in;
+// out_mode 0: fp32 [T, 3, H, W];  1: uint8 [T, H, W, 3] = ((v * 0.5 + 0.5) * 255 + 0.5).clamp(0, 255)  (sample.py:122)
+__global__ void time_conv_out_kernel(const float* __restrict__ in, const float* __restrict__ w /* [3][3][3] = co, ci, tap */,
+                                     const float* __restrict__ bias, void* __restrict__ out, int T, int HW, int out_mode) {
+  const size_t total = (size_t)T * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i / HW);
+    const size_t p = i - (size_t)f * HW;
+    float o[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int ff = f + tap - 1;
+      if (ff < 0 || ff >= T) continue;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = in[((size_t)ff * 3 + ci) * HW + p];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) o[co] += w[(co * 3 + ci) * 3 + tap] * v;
+      }
+    }
+    if (out_mode == 0) {
+#pragma unroll
+      for (int co = 0; co < 3; ++co) ((float*)out)[((size_t)f * 3 + co) * HW + p] = o[co];
+    } else {
+#pragma unroll
+      for (int co = 0; co < 3; ++co) {
+        const float q = fminf(fmaxf((o[co] * 0.5f + 0.5f) * 255.0f + 0.5f, 0.0f), 255.0f);
+        ((unsigned char*)out)[i * 3 + co] = (unsigned char)q;
+      }
+    }
+  }
+}
+
 inline int grid_for(size_t n, int block) {
   size_t g = (n + block - 1) / block;
   return (int)(g > 8192 ? 8192 : (g == 0 ? 1 : g));
@@ -438,10 +510,11 @@ inline int grid_for(size_t n, int block) {
 
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
                    const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
-                   const float* res32, float* out32) {
+                   const float* res32, float* out32, int taps3) {
   if (Cin % 64 != 0 || Cout % 128 != 0) return fail(LATTE_ERR_INVALID, "conv3x3: need Cin % 64 == 0 and Cout % 128 == 0");
   if (!out && !out32) return fail(LATTE_ERR_INVALID, "conv3x3: no output");
-  ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups};
+  if (taps3 && ups) return fail(LATTE_ERR_INVALID, "conv3x3: the 3-tap form has no upsampling");
+  ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups, taps3};
   const int M = N * (Hin << ups) * (Win << ups);
   const int tiles = ((M + 127) / 128) * (Cout / 128);
   constexpr int LDS = 2 * 256 * 128;
@@ -454,18 +527,18 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
 }
 
 int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
-                     int N, int HW, int C, int silu, int dtype, hipStream_t st) {
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps, int max_slabs, half_t* y_lo) {
   if (C != 128 && C != 256 && C != 512) return fail(LATTE_ERR_INVALID, "groupnorm: C must be 128, 256 or 512");
   int slabs = HW / 1024;
   if (slabs < 1) slabs = 1;
-  if (slabs > 64) slabs = 64;
+  if (slabs > max_slabs) slabs = max_slabs;
   const size_t total_oct = (size_t)N * HW * C / 8;
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "groupnorm: the VAE kernels are built for f16 operands only");
   if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), 1e-6f);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), eps);
   const dim3 grid(grid_for(total_oct, 256));
-#define GN_APPLY(S, I) hipLaunchKernelGGL((gn_apply_kernel<LATTE_DTYPE_F16, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct)
+#define GN_APPLY(S, I) hipLaunchKernelGGL((gn_apply_kernel<LATTE_DTYPE_F16, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct, y_lo)
   if (silu) { if (x_is_f32) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else      { if (x_is_f32) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY
@@ -507,6 +580,24 @@ int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype
   const size_t n = (size_t)Cout * Cin * 9;
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "pack_conv_w: the VAE kernels are built for f16 operands only");
   hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_pack_conv_t(const float* w, half_t* out, int Cout, int Cin, const float* mix, int dtype, hipStream_t st, half_t* out_lo) {
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "pack_conv_t: the VAE kernels are built for f16 operands only");
+  hipLaunchKernelGGL(pack_conv_t_kernel<LATTE_DTYPE_F16>, dim3(grid_for((size_t)Cout * Cin * 3, 256)), dim3(256), 0, st, w, out, Cout, Cin, mix,
+                     out_lo);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_scale_by_sigmoid(const float* in, float* out, int n, const float* mix, hipStream_t st) {
+  hipLaunchKernelGGL(scale_by_sigmoid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n, mix);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+int launch_time_conv_out(const float* in, const float* w, const float* bias, void* out, int T, int HW, int out_mode, hipStream_t st) {
+  hipLaunchKernelGGL(time_conv_out_kernel, dim3(grid_for((size_t)T * HW, 256)), dim3(256), 0, st, in, w, bias, out, T, HW, out_mode);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

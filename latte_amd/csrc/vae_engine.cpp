@@ -21,7 +21,7 @@ using namespace latte;
 
 namespace {
 
-enum VPack { VP_F32, VP_CONV3, VP_LINEAR_H16, VP_SMALL_T, VP_SMALL };
+enum VPack { VP_F32, VP_CONV3, VP_LINEAR_H16, VP_SMALL_T, VP_SMALL, VP_CONVT };
 struct VSlot {
   std::string key;
   int64_t numel;
@@ -34,6 +34,13 @@ struct Resnet {
   int cin, cout;
   float *n1w, *n1b, *n2w, *n2b, *c1b, *c2b, *scb = nullptr;
   half_t *c1w, *c2w, *scw = nullptr;
+};
+// TemporalResnetBlock + AlphaBlender of a SpatioTemporalResBlock (AutoencoderKLTemporalDecoder): Conv3d (3,1,1) weights as
+// [C][3 C] half; conv2 and its bias are kept in fp32 too and folded with sigmoid(mix_factor) before the first decode
+struct TResnet {
+  int c = 0;
+  float *n1w, *n1b, *n2w, *n2b, *c1b, *c2b, *c2b_eff, *c2w_f32, *mix;
+  half_t *c1w, *c2w, *c1w_lo, *c2w_lo;   // _lo: the f16 rounding residual of the weights (split-operand convolution)
 };
 
 }  // namespace
@@ -60,6 +67,11 @@ struct latte_vae {
   float *pq_out, *scores, *gn_partial, *gn_stats, *stage;
   int64_t stage_numel = 0;
   bool bias_folded = false;
+  // AutoencoderKLTemporalDecoder mode (latte_vae_create_temporal): every resnet is a SpatioTemporalResBlock, no
+  // post_quant_conv, time_conv_out after conv_out; one decode call = ONE video chunk of n_frames frames
+  bool temporal = false;
+  TResnet tmid[2], tup[4][3];
+  float *tco_w = nullptr, *tco_b = nullptr;
 };
 
 namespace {
@@ -106,6 +118,28 @@ int make_resnet(latte_vae* v, Resnet& r, const std::string& p, int cin, int cout
   return LATTE_OK;
 }
 
+int make_tresnet(latte_vae* v, TResnet& t, const std::string& p, int c) {
+  t.c = c;
+  int rc;
+  if ((rc = valloc(v, &t.n1w, c)) || (rc = valloc(v, &t.n1b, c)) || (rc = valloc(v, &t.n2w, c)) || (rc = valloc(v, &t.n2b, c)) ||
+      (rc = valloc(v, &t.c1b, c)) || (rc = valloc(v, &t.c2b, c)) || (rc = valloc(v, &t.c2b_eff, c)) ||
+      (rc = valloc(v, &t.c2w_f32, (size_t)c * c * 3)) || (rc = valloc(v, &t.mix, 4)) || (rc = valloc(v, &t.c1w, (size_t)c * c * 3)) ||
+      (rc = valloc(v, &t.c2w, (size_t)c * c * 3)) || (rc = valloc(v, &t.c1w_lo, (size_t)c * c * 3)) ||
+      (rc = valloc(v, &t.c2w_lo, (size_t)c * c * 3)))
+    return rc;
+  const std::string q = p + "temporal_res_block.";
+  vslot(v, q + "norm1.weight", c, VP_F32, t.n1w);
+  vslot(v, q + "norm1.bias", c, VP_F32, t.n1b);
+  vslot(v, q + "conv1.weight", (int64_t)c * c * 3, VP_CONVT, &t, c, c);
+  vslot(v, q + "conv1.bias", c, VP_F32, t.c1b);
+  vslot(v, q + "norm2.weight", c, VP_F32, t.n2w);
+  vslot(v, q + "norm2.bias", c, VP_F32, t.n2b);
+  vslot(v, q + "conv2.weight", (int64_t)c * c * 3, VP_F32, t.c2w_f32);
+  vslot(v, q + "conv2.bias", c, VP_F32, t.c2b);
+  vslot(v, p + "time_mixer.mix_factor", 1, VP_F32, t.mix);
+  return LATTE_OK;
+}
+
 int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, const half_t* res, int M, int N, int K, int epi,
              int dtype, hipStream_t st) {
   GemmArgs g{};
@@ -120,25 +154,64 @@ int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, 
   int rc;
   const int HW = H * W, dt = v->dtype;
   float* x = *s;
-  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st))) return rc;
+  // temporal-decoder mode: the activation operand of both 3x3 convolutions is split hi + lo (b = the f16 rounding residual of the
+  // GroupNorm output) and a second pass adds conv(lo): the decoder with twice as many blocks per stage stays under the 1e-3 bar
+  half_t* lo = v->temporal ? b : nullptr;
+  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st, 1e-6f, 64, lo))) return rc;
   if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, nullptr, v->tbuf))) return rc;
-  if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st))) return rc;
+  if (lo && (rc = launch_conv3x3(lo, r.c1w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, v->tbuf, v->tbuf))) return rc;
+  if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st, 1e-6f, 64, lo))) return rc;
   if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
     float* y = *s2;
     if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
     if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
     if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
+    if (lo && (rc = launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     std::swap(*s, *s2);
     return LATTE_OK;
   }
-  return launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
+  if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x))) return rc;
+  if (lo) return launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
+  return LATTE_OK;
 }
+
+// TemporalResnetBlock + AlphaBlender on the fp32 stream of ONE video [T, H, W, C]: the frames are the rows of an "image"
+// [T][H W], so the Conv3d (3,1,1) is the implicit-GEMM conv kernel with 3 taps along the rows and GroupNorm sees T H W pixels
+int run_tresnet(latte_vae* v, const TResnet& t, float* x, half_t* c, half_t* clo, int T, int H, int W, hipStream_t st) {
+  // The two Conv3d run as SPLIT-OPERAND convolutions: activation = hi + lo and weight = hi + lo in f16 (lo = the rounding
+  // residual), three MFMA passes hi*hi + lo*hi + hi*lo accumulated in the fp32 output -- the temporal branch then adds ~1e-6 of
+  // error instead of one more f16 roundoff per block (with single-pass convolutions the decode measured 1.04e-3 against the
+  // fp32 restatement, above the 1e-3 bar; a 3-tap convolution costs a third of a 3x3 one, so three passes cost one)
+  int rc;
+  const int HW = H * W, dt = v->dtype, C = t.c;
+  if ((rc = launch_groupnorm(x, 1, c, t.n1w, t.n1b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, 64 * T, clo))) return rc;
+  if ((rc = launch_conv3x3(c, t.c1w, t.c1b, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, nullptr, v->tbuf, 1))) return rc;
+  if ((rc = launch_conv3x3(clo, t.c1w, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, v->tbuf, v->tbuf, 1))) return rc;
+  if ((rc = launch_conv3x3(c, t.c1w_lo, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, v->tbuf, v->tbuf, 1))) return rc;
+  if ((rc = launch_groupnorm(v->tbuf, 1, c, t.n2w, t.n2b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, 64 * T, clo))) return rc;
+  // out = x_spatial + sigmoid(mix) * (conv2 + bias): weights and bias were folded with the blend factor
+  if ((rc = launch_conv3x3(c, t.c2w, t.c2b_eff, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1))) return rc;
+  if ((rc = launch_conv3x3(clo, t.c2w, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1))) return rc;
+  return launch_conv3x3(c, t.c2w_lo, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1);
+}
+
+int vae_create_impl(int latent_size, int max_frames, int compute_dtype, bool temporal, latte_vae_t** out);
 
 }  // namespace
 
 extern "C" {
 
 int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out) {
+  return vae_create_impl(latent_size, max_frames, compute_dtype, false, out);
+}
+int latte_vae_create_temporal(int latent_size, int max_frames, int compute_dtype, latte_vae_t** out) {
+  return vae_create_impl(latent_size, max_frames, compute_dtype, true, out);
+}
+
+}  // extern "C"
+
+namespace {
+int vae_create_impl(int latent_size, int max_frames, int compute_dtype, bool temporal, latte_vae_t** out) {
   if (!out || latent_size <= 0 || max_frames <= 0) return fail(LATTE_ERR_INVALID, "vae_create: bad arguments");
   if (compute_dtype != LATTE_DTYPE_F16)
     return fail(LATTE_ERR_INVALID, "vae_create: the decoder runs f16 MFMA operands only (the reference decodes in fp16, sample.py:74; "
@@ -146,19 +219,26 @@ int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_v
   if (latent_size % 16 != 0 || latent_size > 64)
     return fail(LATTE_ERR_INVALID, "vae_create: latent_size must be a multiple of 16, at most 64");
   auto* v = new latte_vae();
-  v->h = latent_size; v->max_frames = max_frames; v->dtype = compute_dtype;
+  v->h = latent_size; v->max_frames = max_frames; v->dtype = compute_dtype; v->temporal = temporal;
   const int top = v->ch[3];
+  const std::string sp = temporal ? "spatial_res_block." : "";
   int rc = LATTE_OK;
 #define TRY(x) do { if ((rc = (x))) { latte_vae_destroy(v); return rc; } } while (0)
   TRY(valloc(v, &v->pq_w, 16)); TRY(valloc(v, &v->pq_b, 4));
   TRY(valloc(v, &v->ci_wt, (size_t)36 * top)); TRY(valloc(v, &v->ci_b, top));
   TRY(valloc(v, &v->co_w, (size_t)27 * v->ch[0])); TRY(valloc(v, &v->co_b, 4));
   TRY(valloc(v, &v->no_w, v->ch[0])); TRY(valloc(v, &v->no_b, v->ch[0]));
-  vslot(v, "post_quant_conv.weight", 16, VP_F32, v->pq_w);
-  vslot(v, "post_quant_conv.bias", 4, VP_F32, v->pq_b);
+  if (!temporal) {
+    vslot(v, "post_quant_conv.weight", 16, VP_F32, v->pq_w);
+    vslot(v, "post_quant_conv.bias", 4, VP_F32, v->pq_b);
+  } else {   // AutoencoderKLTemporalDecoder has no post_quant_conv: the 1x1 kernel runs with the identity
+    const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    LATTE_HIP(hipMemcpy(v->pq_w, eye, sizeof(eye), hipMemcpyHostToDevice));
+  }
   vslot(v, "decoder.conv_in.weight", (int64_t)top * 36, VP_SMALL_T, v->ci_wt, top, 4);
   vslot(v, "decoder.conv_in.bias", top, VP_F32, v->ci_b);
-  TRY(make_resnet(v, v->mid[0], "decoder.mid_block.resnets.0.", top, top));
+  TRY(make_resnet(v, v->mid[0], "decoder.mid_block.resnets.0." + sp, top, top));
+  if (temporal) TRY(make_tresnet(v, v->tmid[0], "decoder.mid_block.resnets.0.", top));
   {
     const std::string a = "decoder.mid_block.attentions.0.";
     TRY(valloc(v, &v->agn_w, top)); TRY(valloc(v, &v->agn_b, top));
@@ -178,13 +258,16 @@ int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_v
     vslot(v, a + "to_out.0.weight", (int64_t)top * top, VP_LINEAR_H16, v->ao_w);
     vslot(v, a + "to_out.0.bias", top, VP_F32, v->ao_b);
   }
-  TRY(make_resnet(v, v->mid[1], "decoder.mid_block.resnets.1.", top, top));
+  TRY(make_resnet(v, v->mid[1], "decoder.mid_block.resnets.1." + sp, top, top));
+  if (temporal) TRY(make_tresnet(v, v->tmid[1], "decoder.mid_block.resnets.1.", top));
   int prev = top;
   for (int i = 0; i < 4; ++i) {
     const int cout = v->ch[3 - i];
-    for (int r = 0; r < 3; ++r)
-      TRY(make_resnet(v, v->up[i][r], "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(r) + ".",
-                      r == 0 ? prev : cout, cout));
+    for (int r = 0; r < 3; ++r) {
+      const std::string rp = "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(r) + ".";
+      TRY(make_resnet(v, v->up[i][r], rp + sp, r == 0 ? prev : cout, cout));
+      if (temporal) TRY(make_tresnet(v, v->tup[i][r], rp, cout));
+    }
     prev = cout;
     if (i < 3) {
       TRY(valloc(v, &v->upc_w[i], (size_t)cout * cout * 9));
@@ -198,6 +281,11 @@ int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_v
   vslot(v, "decoder.conv_norm_out.bias", v->ch[0], VP_F32, v->no_b);
   vslot(v, "decoder.conv_out.weight", (int64_t)27 * v->ch[0], VP_SMALL, v->co_w, 3, v->ch[0]);
   vslot(v, "decoder.conv_out.bias", 3, VP_F32, v->co_b);
+  if (temporal) {
+    TRY(valloc(v, &v->tco_w, 27)); TRY(valloc(v, &v->tco_b, 4));
+    vslot(v, "decoder.time_conv_out.weight", 27, VP_F32, v->tco_w);      // [3, 3, 3, 1, 1] = (co, ci, tap)
+    vslot(v, "decoder.time_conv_out.bias", 3, VP_F32, v->tco_b);
+  }
 
   // workspace: the largest NHWC map is [N, 8h, 8w, 256] (output of up_blocks.2's upsampler)
   const size_t big = (size_t)max_frames * (8 * latent_size) * (8 * latent_size) * 256;
@@ -220,6 +308,9 @@ int latte_vae_create(int latent_size, int max_frames, int compute_dtype, latte_v
   *out = v;
   return LATTE_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void latte_vae_destroy(latte_vae_t* v) {
   if (!v) return;
@@ -254,6 +345,11 @@ int latte_vae_load_tensor(latte_vae_t* v, const char* key, const float* data, in
     case VP_LINEAR_H16: rc = launch_convert_f32_to_h16(src, (half_t*)s.dst, numel, v->dtype, st); break;
     case VP_SMALL_T: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 1, st); break;
     case VP_SMALL: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 0, st); break;
+    case VP_CONVT: {
+      TResnet* t = (TResnet*)s.dst;
+      rc = launch_pack_conv_t(src, t->c1w, s.cout, s.cin, nullptr, v->dtype, st, t->c1w_lo);
+      break;
+    }
   }
   if (rc) return rc;
   if (s.key == "decoder.mid_block.attentions.0.to_out.0.weight")
@@ -300,6 +396,14 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     // softmax rows sum to 1, so  to_out(P (V0 + 1 bv^T)) = to_out(P V0) + (Wo bv + bo): the value bias is folded into
     // the output bias and V^T is produced directly by a GEMM (no transpose kernel)
     if ((rc = launch_small_linear(IN_PLAIN, v->av_b, nullptr, v->ao_w_f32, v->ao_b, nullptr, nullptr, v->ao_b_eff, 1, top, top, top, st))) return rc;
+    if (v->temporal) {   // AlphaBlender folded into conv2 of every temporal resnet: out = x_spatial + sigmoid(mix) (conv2 + b)
+      auto fold = [&](TResnet& t) -> int {
+        int r2 = launch_pack_conv_t(t.c2w_f32, t.c2w, t.c, t.c, t.mix, dt, st, t.c2w_lo);
+        return r2 ? r2 : launch_scale_by_sigmoid(t.c2b, t.c2b_eff, t.c, t.mix, st);
+      };
+      for (int k = 0; k < 2; ++k) if ((rc = fold(v->tmid[k]))) return rc;
+      for (int i = 0; i < 4; ++i) for (int r = 0; r < 3; ++r) if ((rc = fold(v->tup[i][r]))) return rc;
+    }
     v->bias_folded = true;
   }
   half_t *b = v->buf[0], *c = v->buf[1], *d = v->buf[2];
@@ -320,6 +424,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   if ((rc = launch_conv_in(v->pq_out, v->ci_wt, v->ci_b, a, N, H, W, top, st))) return rc;
   if (traced(rc)) return rc;
   if ((rc = run_resnet(v, v->mid[0], &a, &a2, b, c, d, N, H, W, st))) return rc;
+  if (v->temporal && (rc = run_tresnet(v, v->tmid[0], a, c, d, N, H, W, st))) return rc;
   if (traced(rc)) return rc;
   {  // mid-block attention: 1 head, dim 512, tokens = H*W per frame
     const int L = H * W;
@@ -348,10 +453,12 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   }
   if (traced(rc)) return rc;
   if ((rc = run_resnet(v, v->mid[1], &a, &a2, b, c, d, N, H, W, st))) return rc;
+  if (v->temporal && (rc = run_tresnet(v, v->tmid[1], a, c, d, N, H, W, st))) return rc;
   if (traced(rc)) return rc;
   for (int i = 0; i < 4; ++i) {
     for (int r = 0; r < 3; ++r) {
       if ((rc = run_resnet(v, v->up[i][r], &a, &a2, b, c, d, N, H, W, st))) return rc;
+      if (v->temporal && (rc = run_tresnet(v, v->tup[i][r], a, c, d, N, H, W, st))) return rc;
       cur_c = v->up[i][r].cout;
       if (traced(rc)) return rc;
     }
@@ -367,7 +474,10 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   }
   if (stop_after >= 0) return fail(LATTE_ERR_INVALID, "vae_trace: stage index beyond the last traced stage");
   if ((rc = launch_groupnorm(a, 1, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
-  return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
+  if (!v->temporal) return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
+  // conv_out to fp32 NCHW frames, then time_conv_out over the frames of the chunk
+  if ((rc = launch_conv_out(c, v->co_w, v->co_b, v->tbuf, N, H, W, v->ch[0], 0, dt, st))) return rc;
+  return launch_time_conv_out(v->tbuf, v->tco_w, v->tco_b, out, N, H * W, out_mode, st);
 }
 
 }  // extern "C"

@@ -8,8 +8,8 @@ any object with the diffusers interface (``latte_amd.schedulers.DDIMScheduler`` 
 scheduler at eta = 0 the whole guided loop (:700-760) runs inside the engine (``latte_t2v_guided_ddim_loop``: text context
 computed once, guidance combine + learned-sigma drop + DDIM update fused into one kernel per step); with any other
 scheduler object the guidance combine, the learned-sigma drop and the scheduler update are the reference's own few
-elementwise lines (:747-758) on device tensors around the engine denoiser.  ``enable_vae_temporal_decoder=True`` needs diffusers' ``AutoencoderKLTemporalDecoder`` and
-is not available; the per-frame decode of :773-785 is.
+elementwise lines (:747-758) on device tensors around the engine denoiser.  ``enable_vae_temporal_decoder=True`` decodes through
+``latte_amd.AutoencoderKLTemporalDecoder`` in chunks of 14 frames (:779-798), else per frame (:765-777).
 """
 import inspect
 
@@ -142,6 +142,21 @@ class LattePipeline:
         video = video.reshape(b, f, *video.shape[1:]).permute(0, 1, 3, 4, 2)                    # '(b f) c h w -> b f h w c'
         return ((video / 2.0 + 0.5).clamp(0, 1) * 255).to(dtype=torch.uint8).cpu().contiguous()
 
+    def decode_latents_with_temporal_decoder(self, latents):
+        """pipeline_latte.py:779-798: chunks of 14 frames through ``vae.decode(chunk, num_frames=len(chunk))``."""
+        if not getattr(self.vae, "_TEMPORAL", False):
+            raise LatteError("decode_latents_with_temporal_decoder needs a latte_amd.AutoencoderKLTemporalDecoder")
+        b, c, f, h, w = latents.shape
+        z = (1.0 / self.vae.config.scaling_factor) * latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+        video = []
+        decode_chunk_size = 14
+        for i in range(0, z.shape[0], decode_chunk_size):
+            chunk = z[i:i + decode_chunk_size].contiguous()
+            video.append(self.vae.decode(chunk, num_frames=chunk.shape[0]).sample)
+        video = torch.cat(video)
+        video = video.reshape(b, f, *video.shape[1:]).permute(0, 1, 3, 4, 2)
+        return ((video / 2.0 + 0.5).clamp(0, 1) * 255).to(dtype=torch.uint8).cpu().contiguous()
+
     # ------------------------------------------------------------------ pipeline_latte.py:516-771
     @torch.no_grad()
     def __call__(self, prompt=None, negative_prompt="", num_inference_steps=20, timesteps=None, guidance_scale=4.5,
@@ -149,9 +164,9 @@ class LattePipeline:
                  prompt_embeds=None, negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None,
                  callback_steps=1, clean_caption=True, mask_feature=True, enable_temporal_attentions=True,
                  enable_vae_temporal_decoder=False):
-        if enable_vae_temporal_decoder:
-            raise LatteError("enable_vae_temporal_decoder=True needs diffusers' AutoencoderKLTemporalDecoder (not part of the "
-                             "MI355X engine); use the per-frame decode (False)")
+        if enable_vae_temporal_decoder and not getattr(self.vae, "_TEMPORAL", False):
+            raise LatteError("enable_vae_temporal_decoder=True needs a latte_amd.AutoencoderKLTemporalDecoder as the pipeline's vae "
+                             "(sample_t2x.py:31-32 loads it from subfolder 'vae_temporal_decoder')")
         cfg = self.transformer.config
         height = height or cfg.sample_size * self.vae_scale_factor
         width = width or cfg.sample_size * self.vae_scale_factor
@@ -207,5 +222,10 @@ class LattePipeline:
             latents = self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]
             if callback is not None and i % callback_steps == 0:
                 callback(i // getattr(self.scheduler, "order", 1), t, latents)
-        video = latents if output_type == "latents" else self.decode_latents(latents)
+        if output_type == "latents":
+            video = latents
+        elif enable_vae_temporal_decoder:                                                 # pipeline_latte.py:737-740
+            video = self.decode_latents_with_temporal_decoder(latents)
+        else:
+            video = self.decode_latents(latents)
         return VideoPipelineOutput(video=video) if return_dict else (video,)

@@ -71,6 +71,36 @@ def vae_decoder_state_dict(seed=0):
     return _fill(vae_decoder_keys(), seed)
 
 
+def vae_temporal_decoder_keys():
+    """diffusers AutoencoderKLTemporalDecoder decoder keys: the SD-VAE decoder's with every resnet split into
+    ``spatial_res_block`` / ``temporal_res_block`` (Conv3d (3,1,1)) / ``time_mixer.mix_factor``, no post_quant_conv, plus
+    ``decoder.time_conv_out``."""
+    ks = {}
+    base = vae_decoder_keys()
+    for k, shp in base.items():
+        if k.startswith("post_quant_conv"):
+            continue
+        if ".resnets." in k:
+            head, tail = k.rsplit(".", 2)[0], ".".join(k.rsplit(".", 2)[1:])      # "...resnets.N", "conv1.weight"
+            ks[f"{head}.spatial_res_block.{tail}"] = shp
+            if not tail.startswith("conv_shortcut"):
+                c = base[f"{head}.norm2.weight"][0]                               # the temporal block works on out_channels
+                ks[f"{head}.temporal_res_block.{tail}"] = (c, c, 3, 1, 1) if tail.endswith("weight") and tail.startswith("conv") else (c,)
+            ks[f"{head}.time_mixer.mix_factor"] = (1,)
+        else:
+            ks[k] = shp
+    ks["decoder.time_conv_out.weight"], ks["decoder.time_conv_out.bias"] = (3, 3, 3, 1, 1), (3,)
+    return ks
+
+
+def vae_temporal_decoder_state_dict(seed=0):
+    sd = _fill(vae_temporal_decoder_keys(), seed)
+    for k in sd:
+        if k.endswith("mix_factor"):
+            sd[k] = torch.zeros(1)            # AlphaBlender(alpha = 0.0): sigmoid(0) = 0.5
+    return sd
+
+
 def t2v_keys(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28, patch_size=2,
              cross_attention_dim=1152, caption_channels=4096, **unused):
     """State-dict keys of LatteT2V (models/latte_t2v.py) in the Latte-1 configuration."""

@@ -33,6 +33,7 @@ class AutoencoderKL:
     residual stream is fp32: 1e-3 relative L2 against the fp32 restatement at the full 32x32 -> 256x256 size.  bf16
     operands (same MFMA rate, 2^-9 instead of 2^-11 unit roundoff in every conv operand) measured 7.3e-3 on the same
     decode and are not offered: ``compute_dtype`` other than f16 and ``.to(torch.bfloat16)`` raise."""
+    _TEMPORAL = False
 
     def __init__(self, latent_size=32, max_frames=16, compute_dtype="f16", scaling_factor=0.18215,
                  block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, norm_num_groups=32):
@@ -137,7 +138,8 @@ class AutoencoderKL:
                 self._h = None
             h = _lib.c_void()
             with torch.cuda.device(self._device):
-                check(lib.latte_vae_create(latent_size, want, _lib.DTYPES[self.compute_dtype], h))
+                create = lib.latte_vae_create_temporal if self._TEMPORAL else lib.latte_vae_create
+                check(create(latent_size, want, _lib.DTYPES[self.compute_dtype], h))
             self._h, self._key, self._synced = h, key, False
             self.max_frames, self.latent_size = want, latent_size
         if not self._synced:
@@ -183,3 +185,39 @@ class AutoencoderKL:
 
     def encode(self, x):
         raise LatteError("AutoencoderKL.encode is the training path (train.py:210) and is outside the MI355X sampling engine")
+
+
+class AutoencoderKLTemporalDecoder(AutoencoderKL):
+    """``diffusers.AutoencoderKLTemporalDecoder`` (stable-video-diffusion's VAE) for the call sites of the reference's text-to-video
+    path (sample_t2x.py:31-32 ``from_pretrained(path, subfolder="vae_temporal_decoder")``; pipeline_latte.py:779-798
+    ``vae.decode(latents[i : i + 14], num_frames=n).sample``): the SD-VAE decoder with a temporal resnet (GroupNorm over the
+    frames, Conv3d (3,1,1)) blended into every block by a learned factor, and a temporal convolution on the RGB output.
+    Decoder only, on the same HIP kernels as ``AutoencoderKL`` (the Conv3d is the implicit-GEMM conv kernel with three taps along
+    an "image" whose rows are the frames).  Restated from memory of diffusers 0.24.0: parity unpinned."""
+    _TEMPORAL = True
+
+    def load_state_dict(self, state_dict, strict=True):
+        super().load_state_dict(state_dict, strict)
+        self._sd.pop("post_quant_conv.weight", None)          # this class has none (only the encoder-side quant_conv)
+        self._sd.pop("post_quant_conv.bias", None)
+        return self
+
+    def decode(self, z, num_frames=1, return_dict=True, image_only_indicator=None):
+        """z [B * num_frames, 4, h, w] (already divided by scaling_factor) -> ``.sample`` fp32 [B * num_frames, 3, 8h, 8w];
+        every run of ``num_frames`` frames is one video chunk (temporal mixing stays inside it)."""
+        n = z.shape[0]
+        if num_frames <= 0 or n % num_frames:
+            raise LatteError("z.shape[0] must be a multiple of num_frames")
+        self.max_frames = max(self.max_frames, num_frames)
+        z32 = z.to(device=self._device, dtype=torch.float32).contiguous()
+        h = z.shape[2]
+        eng = self._engine(num_frames, h)
+        out = torch.empty(n, 3, 8 * h, 8 * h, device=self._device, dtype=torch.float32)
+        lib = load_library()
+        with torch.cuda.device(self._device):
+            for s in range(0, n, num_frames):
+                check(lib.latte_vae_decode(eng, ptr(z32[s:s + num_frames]), num_frames, 1.0, 0, ptr(out[s:s + num_frames]), stream_ptr()))
+        return DecoderOutput(out) if return_dict else (out,)
+
+    def decode_video_uint8(self, latents):
+        raise LatteError("use decode(z, num_frames=...) (the text-to-video pipeline converts to uint8 itself, pipeline_latte.py:796)")

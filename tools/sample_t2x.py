@@ -46,14 +46,23 @@ def main():
         from latte_amd.random_init import t2v_state_dict, vae_decoder_state_dict
         transformer = latte_amd.LatteT2V(num_layers=a.layers, sample_size=latent, video_length=args.video_length,
                                          compute_dtype=cdt, max_batch=2).load_state_dict(t2v_state_dict(0, num_layers=a.layers))
-        vae = latte_amd.AutoencoderKL(latent_size=latent, max_frames=args.video_length, compute_dtype="f16")
-        vae.load_state_dict(vae_decoder_state_dict(0))
+        if args.enable_vae_temporal_decoder:                       # sample_t2x.py:31-32
+            from latte_amd.random_init import vae_temporal_decoder_state_dict
+            vae = latte_amd.AutoencoderKLTemporalDecoder(latent_size=latent, max_frames=14, compute_dtype="f16")
+            vae.load_state_dict(vae_temporal_decoder_state_dict(0))
+        else:
+            vae = latte_amd.AutoencoderKL(latent_size=latent, max_frames=args.video_length, compute_dtype="f16")
+            vae.load_state_dict(vae_decoder_state_dict(0))
     else:
         from transformers import T5EncoderModel, T5Tokenizer
         p = args.pretrained_model_path
         transformer = latte_amd.LatteT2V.from_pretrained_2d(p, subfolder="transformer", video_length=args.video_length,
                                                             compute_dtype=cdt, max_batch=2)
-        vae = latte_amd.AutoencoderKL.from_pretrained(p, subfolder="vae", latent_size=latent, max_frames=args.video_length)
+        if args.enable_vae_temporal_decoder:                       # sample_t2x.py:31-32
+            vae = latte_amd.AutoencoderKLTemporalDecoder.from_pretrained(p, subfolder="vae_temporal_decoder", latent_size=latent,
+                                                                         max_frames=14)
+        else:
+            vae = latte_amd.AutoencoderKL.from_pretrained(p, subfolder="vae", latent_size=latent, max_frames=args.video_length)
         tokenizer = T5Tokenizer.from_pretrained(p, subfolder="tokenizer")
         text_encoder = T5EncoderModel.from_pretrained(p, subfolder="text_encoder", torch_dtype=torch.float16).to(device).eval()
     pipe = latte_amd.LattePipeline(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, scheduler=scheduler,
