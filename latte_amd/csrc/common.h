@@ -201,7 +201,6 @@ int launch_gelu_bwd(const half_t* u, const half_t* dh, half_t* du, size_t n, int
 int colsum_chunks(int M);
 int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* out, int accumulate, int dtype, hipStream_t st);
 int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st);
-int launch_transpose_half(const half_t* in, half_t* out, int M, int C, int ldo, hipStream_t st);
 int launch_pack_weight(const float* w, half_t* wn, half_t* wt, int N, int K, int dtype, hipStream_t st);
 int launch_naive_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, int M, int N,
                       int K, float alpha, int accumulate, hipStream_t st, int splits = 1, float* ws = nullptr);
@@ -220,6 +219,8 @@ int sumsq_blocks();
 int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, hipStream_t st);
 int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
                      int step, float ema_decay, const float* stats, hipStream_t st);
+// dW[N, K] = dY[M, N]^T X[M, K] without transposed copies (gemm_tn.hip); partial: float [ceil(M / m_chunk)][N][K]
+int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout, half_t* dqkv, float* stats, int num_seq, int L, int heads,
                          int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, hipStream_t st);
 

@@ -7,7 +7,6 @@
 //   LN + modulate bwd  dx, dshift[s], dscale[s]                                    latte.py:28-29,166,168
 //   GELU(tanh)         h = gelu(u);  du = dh * gelu'(u)                            latte.py:170
 //   column sums        bias gradients  db[n] += sum_m dy[m, n]
-//   transposes         half [M, C] -> [C, M]: operands of the weight-gradient GEMMs (dW = dY^T X)
 //   split reduce       dW (+)= sum of the split-K partial products
 //   small GEMMs        strided fp32 (adaLN / embedder / final-layer linears with <= 64 rows or <= 32 columns)
 //   unpatchify^-1, im2col of the patch embed, label-table scatter, SiLU backward
@@ -329,40 +328,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ partial, int split
   }
 }
 
-// ---------------------------------------------------------------------------------------------- half transpose [M, C] -> [C, ldo]
-__global__ void __launch_bounds__(256) transpose_half_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int M, int C,
-                                                             int ldo) {
-  __shared__ unsigned short tile[64][66];
-  const int m0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  // load 64 rows x 64 columns (8 chunks of 16 B per row): 512 chunks, 2 per thread
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int id = threadIdx.x + 256 * k;
-    const int r = id >> 3, ch = id & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (m0 + r < M && c0 + ch * 8 < C) v = *(const uint4*)(in + (size_t)(m0 + r) * C + c0 + ch * 8);
-    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      tile[r][ch * 8 + 2 * e] = (unsigned short)(w[e] & 0xffffu);
-      tile[r][ch * 8 + 2 * e + 1] = (unsigned short)(w[e] >> 16);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int id = threadIdx.x + 256 * k;
-    const int c = id >> 3, ch = id & 7;          // output row c (a column of the input), 8 consecutive m
-    if (c0 + c < C && m0 + ch * 8 < M) {
-      unsigned int w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        w[e] = (unsigned int)tile[ch * 8 + 2 * e][c] | ((unsigned int)tile[ch * 8 + 2 * e + 1][c] << 16);
-      *(uint4*)(out + (size_t)(c0 + c) * ldo + m0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-  }
-}
-
+// ---------------------------------------------------------------------------------------------- weight packing
 // fp32 [N, K] master weight -> half [N, K] and half [K, N] (the operand of the input-gradient GEMM dX = dY W)
 template <int DT>
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, half_t* __restrict__ wn, half_t* __restrict__ wt,
@@ -690,13 +656,6 @@ int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* ou
 }
 int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, partial, splits, stride, n, out, accumulate);
-  LATTE_HIP(hipGetLastError());
-  return LATTE_OK;
-}
-
-int launch_transpose_half(const half_t* in, half_t* out, int M, int C, int ldo, hipStream_t st) {
-  if (C % 8 || M % 8 || ldo % 8) return fail(LATTE_ERR_INVALID, "transpose_half: dimensions must be multiples of 8");
-  hipLaunchKernelGGL(transpose_half_kernel, dim3((C + 63) / 64, (M + 63) / 64), dim3(256), 0, st, in, out, M, C, ldo);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

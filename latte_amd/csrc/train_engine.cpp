@@ -56,7 +56,7 @@ struct latte_trainer {
         *pix = nullptr, *ones = nullptr, *zeros = nullptr, *part_rows = nullptr, *part_cols = nullptr, *wg_ws = nullptr, *ng_ws = nullptr,
         *attn_stats = nullptr, *loss_ws = nullptr, *stats = nullptr;
   double* sumsq = nullptr;
-  half_t *dyD = nullptr, *dhH = nullptr, *dxnH = nullptr, *dqkvH = nullptr, *xnh = nullptr, *at = nullptr, *bt = nullptr;
+  half_t *dyD = nullptr, *dhH = nullptr, *dxnH = nullptr, *dqkvH = nullptr, *xnh = nullptr;
   int64_t wg_ws_floats = 0, ng_ws_floats = 0, loss_ws_floats = 0;
   bool weights_synced = false;
   int cur_batch = 0, next_stage = 1 << 30;   // step in flight: batch, labels (caller keeps them alive), next backward stage
@@ -93,28 +93,16 @@ int gemm_half(latte_trainer* e, const half_t* A, const half_t* W, const float* b
   return launch_gemm(g, EPI_BIAS_H16, e->dt, 0, st);
 }
 
-// dW[N, K] = dY[M, N]^T X[M, K] through two half transposes and the split-K tile GEMM; result ASSIGNED to dW (fp32)
+// dW[N, K] = dY[M, N]^T X[M, K] on the transposed-operand GEMM (gemm_tn.hip: no transposed copies), the contraction split so
+// that about four workgroups per CU are in flight; the partial products are reduced in a fixed order; result ASSIGNED to dW
 int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st) {
   int rc;
-  const int ld = M;   // M = batch * F * T is a multiple of 64: the transposed operands are dense [N, M] / [K, M]
-  if ((rc = launch_transpose_half(dY, e->at, M, N, ld, st))) return rc;
-  if ((rc = launch_transpose_half(X, e->bt, M, K, ld, st))) return rc;
-  // 256 x 128 ping-pong tiles (variant 4), contraction split so that about two workgroups per CU are in flight
-  const int tiles = ((N + 255) / 256) * (K / 128);
-  int splits = std::max(1, std::min(ld / 128, (512 + tiles - 1) / tiles));
-  int chunk = ((ld + splits - 1) / splits + 63) / 64 * 64;
-  if (chunk < 128) chunk = 128;                       // the ping-pong kernel needs >= 2 K tiles
-  splits = (ld + chunk - 1) / chunk;
-  if (ld - (splits - 1) * chunk < 128 && splits > 1) {   // a short last split: fold it into fewer, longer ones
-    --splits;
-    chunk = ((ld + splits - 1) / splits + 63) / 64 * 64;
-    splits = (ld + chunk - 1) / chunk;
-  }
+  const int tiles = ((N + 127) / 128) * (K / 128);
+  int splits = std::max(1, std::min(M / 64, (1024 + tiles - 1) / tiles));
+  int chunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (M + chunk - 1) / chunk;
   if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
-  GemmArgs g{};
-  g.A = e->at; g.W = e->bt; g.bias = e->zeros; g.out = e->wg_ws; g.M = N; g.N = K; g.K = ld; g.rows_per_sample = N;
-  g.k_chunk = chunk; g.split_stride = (long)N * K;
-  if ((rc = launch_gemm(g, EPI_BIAS_F32, e->dt, 4, st))) return rc;
+  if ((rc = launch_gemm_tn(dY, X, e->wg_ws, M, N, K, chunk, e->dt, st))) return rc;
   return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
 }
 
@@ -196,12 +184,12 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   A(&e->part_rows, (size_t)(e->rows_max / Rr + 4) * 2 * D);
   A(&e->part_cols, (size_t)(colsum_chunks((int)e->rows_max) + 1) * std::max(Hm, 3 * D));
   {
-    // split-K partial products: splits * N * K with splits <= ceil(512 / tiles) (+1), tiles = ceil(N / 256) (K / 128)
+    // split-K partial products: splits * N * K with splits <= ceil(1024 / tiles) (+1), tiles = ceil(N / 128) (K / 128)
     int64_t worst = 0;
     const int shapes[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
     for (auto& s : shapes) {
-      const int tiles = ((s[0] + 255) / 256) * (s[1] / 128);
-      const int64_t splits = std::min<int64_t>(e->ld / 128 + 1, (512 + tiles - 1) / tiles) + 1;
+      const int tiles = ((s[0] + 127) / 128) * (s[1] / 128);
+      const int64_t splits = std::min<int64_t>(e->ld / 64 + 1, (1024 + tiles - 1) / tiles) + 1;
       worst = std::max<int64_t>(worst, splits * s[0] * s[1]);
     }
     e->wg_ws_floats = worst;
@@ -215,8 +203,6 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   A(&e->stats, 4);
   A(&e->sumsq, (size_t)sumsq_blocks());
   A(&e->dyD, R * D); A(&e->dhH, R * Hm); A(&e->dxnH, R * D); A(&e->dqkvH, R * 3 * D); A(&e->xnh, R * D);
-  const size_t maxn = (size_t)(std::max(Hm, 3 * D) + 127) / 128 * 128;
-  A(&e->at, maxn * e->ld); A(&e->bt, maxn * e->ld);
   if (!rc) rc = launch_fill_f32(e->ones, 1.0f, R, nullptr);
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(LATTE_ERR_HIP, "trainer_create: device error");
   if (rc) { latte_trainer_destroy(e); return rc; }
