@@ -871,14 +871,16 @@ int gemm_auto_variant(int M, int N, int epi) {
   // full-line LDS-transposed epilogue for half-precision outputs (qkv: 220 us vs 250-266 us at 192), for the fp32
   // read-modify-write epilogue the two are within 3 %
   const bool half_out = epi == EPI_BIAS_H16 || epi == EPI_BIAS_GELU_H16;
-  const Cand cands[] = {{9, 256, 256, 256, 1.00f}, {8, 256, 192, 256, half_out ? 0.86f : 0.97f}, {7, 256, 128, 256, 0.80f},
-                        {1, 128, 128, 512, 0.78f}};
+  // (11 = the rolling 12-wave kernel with the LDS-patch epilogue: for half outputs it ties the 256-wide tile at M = 32768 and wins
+  //  wherever 192-wide tiles quantise better -- fc1 at B = 1, 2: 384 / 768 tiles; it needs whole 192-wide tile columns)
+  const Cand cands[] = {{9, 256, 256, 256, 1.00f}, {11, 256, 192, 256, half_out ? 0.96f : 0.0f}, {8, 256, 192, 256, half_out ? 0.86f : 0.97f},
+                        {7, 256, 128, 256, 0.80f}, {1, 128, 128, 512, 0.78f}};
   int best = 1;
   float best_score = -1.f;
   for (const Cand& c : cands) {
     // the persistent kernels take a partial last tile column as long as every wave's WTN = bn / 4 columns
     // are all inside or all outside N
-    if (c.variant >= 7 ? (N % (c.bn / 4)) != 0 : (N % c.bn) != 0) continue;
+    if (c.variant == 11 ? (N % 192) != 0 : c.variant >= 7 ? (N % (c.bn / 4)) != 0 : (N % c.bn) != 0) continue;
     const long tiles_n = (N + c.bn - 1) / c.bn;
     const long tiles = (long)((M + c.bm - 1) / c.bm) * tiles_n;
     const long rounds = (tiles + c.slots - 1) / c.slots;
@@ -911,9 +913,10 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     variant = gemm_auto_variant(a.M, a.N, epi);
     // the gated read-modify-write GEMMs on 192-wide tiles run on the 12-wave producer / consumer kernel (gemm_pw.hip, rolling
     // schedule): proj 127 -> 119 us, fc2 316 -> 289 us per launch in the XL/2 forward at B = 8 (same box, round-2 sweep)
-    if (variant == 8 && epi == EPI_GATE_RES_F32 && a.N % 192 == 0 && a.K >= 128 &&
-        (uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 < (1ull << 32) && (uint64_t)a.N * a.K * 2 < (1ull << 32))
-      variant = 11;
+    const bool pw_ok = a.N % 192 == 0 && a.K >= 128 && (uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 < (1ull << 32) &&
+                       (uint64_t)a.N * a.K * 2 < (1ull << 32);
+    if (variant == 8 && epi == EPI_GATE_RES_F32 && pw_ok) variant = 11;
+    if (variant == 11 && !pw_ok) variant = 8;
     // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
     //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
   }
