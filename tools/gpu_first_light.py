@@ -386,6 +386,8 @@ def attn_variants():
         qkv = torch.randn(rows, 3 * D, device=dev).bfloat16()
         out = torch.zeros(rows, D, dtype=torch.bfloat16, device=dev)
         args = (B * F, T, H, hd, F, F * T, T, 1) if mode == "spatial" else (B * T, F, H, hd, T, F * T, 1, T)
+        if mode == "temporal_adjacent":   # the 16 frames of a token as 16 ADJACENT rows (a (b, t, f) row order): layout probe
+            args = (B * T, F, H, hd, T, F * T, F, 1)
         if env is None:
             os.environ.pop("LATTE_ATTN_ABLATE", None)
         else:
@@ -412,6 +414,8 @@ def attn_variants():
         log(f"attn_variants {nm}: " + " | ".join(row))
     us, tf, _ = run(8, 16, 256, "temporal", None)
     log(f"attn_variants XL/2 temporal L=16 B=8: {us:.1f}us, {8*16*256*4*1152*2/us/1e6:.2f} TB/s algorithmic")
+    us, tf, _ = run(8, 16, 256, "temporal_adjacent", None)
+    log(f"attn_variants XL/2 temporal L=16 B=8, frames of a token in adjacent rows: {us:.1f}us, {8*16*256*4*1152*2/us/1e6:.2f} TB/s algorithmic")
 
 
 def group_m_sweep():
