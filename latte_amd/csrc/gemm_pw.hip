@@ -17,10 +17,10 @@
 // Barrier-delimited intervals (barrier b ends interval I(b); P = the barrier after the pipeline fill):
 //   group 0:   L(u) in I(2u),   C(u) in I(2u+1)          L(u): B(u) both halves + A(u) first half  -> registers
 //   group 1:   L(u) in I(2u+1), C(u) in I(2u+2)          C(u): 48 MFMAs, the 8 second-half A reads between them
-//   producers: I(2v)   issue B(v+1) and A rows 0-127 of K tile v+1  (stage (v+1)&1: last read in I(2v-1)),
-//                      then vmcnt(10): A rows 128-255 of K tile v have landed (group 1 reads them in I(2v+1));
-//              I(2v+1) issue A rows 128-255 of K tile v+1            (last read of that region: group 1's C(v-1) in I(2v)),
-//                      then vmcnt(4): B / A rows 0-127 of K tile v+1 have landed (group 0 reads them in I(2v+2)).
+//   producers (LDS rings: THREE A stages, two B stages -- with two A stages the producers of the K = 4608 GEMM waited 745 clocks
+//   per K tile for an A operand that comes from HBM / the Infinity Cache with one K tile of look-ahead):
+//              I(2v)   issue B(v+1) and A rows 0-127 of K tile v+2, then vmcnt(18): everything of K tile v has landed;
+//              I(2v+1) issue A rows 128-255 of K tile v+2, then vmcnt(8): B(v+1) (and the older A(v+1)) have landed.
 // The K-tile counter runs across tile boundaries, so the producers never drain; a consumer group runs its epilogue
 // around the barrier that ends its last compute segment (group 1 before, group 0 after it), as in gemm_pps_kernel.
 #include <type_traits>
@@ -55,7 +55,7 @@ template <int EPI, int DT, int TAG>
 __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int NA = 3, NB = 2;                 // LDS rings: 3 A stages (96 KB) at offset 0, 2 B stages (48 KB) behind them
+  constexpr int NA = 3;                         // LDS rings: 3 A stages (96 KB) at offset 0, 2 B stages (48 KB) behind them
   constexpr int B_BASE = NA * A_BYTES;
   constexpr int AH_INSTR = 4, BG_INSTR = 6;   // per producer wave: 128 A rows / (4 waves x 8 rows), 192 W rows / (4 x 8)
   constexpr int GROUP_M = 8;
