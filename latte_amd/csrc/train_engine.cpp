@@ -98,9 +98,9 @@ int gemm_half(latte_trainer* e, const half_t* A, const half_t* W, const float* b
 // that about four workgroups per CU are in flight; the partial products are reduced in a fixed order; result ASSIGNED to dW
 int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st) {
   int rc;
-  const bool wide = K % 256 == 0 && getenv("LATTE_TN_KW") && atoi(getenv("LATTE_TN_KW")) == 2;   // measurement hook (gemm_tn.hip)
-  const int tiles = ((N + 127) / 128) * (K / (wide ? 256 : 128));
-  int splits = std::max(1, std::min(M / 64, (768 + tiles - 1) / tiles));
+  const int tn = gemm_tn_tile_n();
+  const int tiles = ((N + tn - 1) / tn) * (K / 128);
+  int splits = std::max(1, std::min(M / 64, ((tn == 256 ? 512 : 768) + tiles - 1) / tiles));
   int chunk = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + chunk - 1) / chunk;
   if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
@@ -190,7 +190,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
     int64_t worst = 0;
     const int shapes[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
     for (auto& s : shapes) {
-      const int tiles = ((s[0] + 127) / 128) * (s[1] / 256 > 0 ? s[1] / 256 : 1);   // (the wider measurement tile needs the most splits)
+      const int tiles = ((s[0] + 255) / 256) * (s[1] / 128);
       const int64_t splits = std::min<int64_t>(e->ld / 64 + 1, (768 + tiles - 1) / tiles) + 1;
       worst = std::max<int64_t>(worst, splits * s[0] * s[1]);
     }
