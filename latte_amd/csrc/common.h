@@ -146,6 +146,10 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
 // text_embedding_projection of the extras == 78 variant (latte.py:238-242): out[B,N] = Linear(SiLU(text[B,K]))
 int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K, hipStream_t st);
 int launch_iota(int64_t* p, int n, hipStream_t st);
+// x[M, N] += gate[m / rows_per_sample, :] * (sum of `splits` fp32 partial products (slab stride `stride`) + bias): the reduction
+// of a split-K gated GEMM (engine.cpp: gated_gemm)
+int launch_gated_split_reduce(float* x, const float* ws, int splits, size_t stride, const float* bias, const float* gate,
+                              int gate_stride, int rows_per_sample, int M, int N, hipStream_t st);
 int launch_silu_rows(const float* in, float* out, size_t n, hipStream_t st);   // out = SiLU(in), may alias
 // adaLN-single (latte_t2v.py:301-304,913-915): mod[b, j, :] = table[j, :] + t6[b, (j % 6) * D ...] for the 6 * nblk block
 // rows, then the 2 head rows = head_table[r, :] + temb[b, :]; mod is [B, (6 * nblk + 2) * D].

@@ -59,6 +59,8 @@ struct latte_engine {
   int64_t rows_max = 0, rows_pad = 0;
   int gemm_variant = 0;  // 0 = per-shape choice (gemm_auto_variant)
   int gemm_variant_of[4] = {0, 0, 0, 0};   // per-GEMM override (qkv, proj, fc1, fc2); 0 = gemm_variant
+  int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
+  float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
         *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr, *ytab = nullptr, *fin_wt = nullptr,
@@ -129,6 +131,40 @@ struct Timer {  // optional per-launch HIP events (latte_profile_forward)
   }
 };
 enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATCH, C_FINAL, C_NONE = -1 };
+
+// Gated read-modify-write GEMM x += gate * (A W^T + bias) (attention out-projection, fc2; latte.py:179-180).  At small batches
+// its 256 x 192 output tiles fill a fraction of the 256 CUs (B = 1 at XL/2: 96 tiles, fc2 78 us per launch against 33 us at the
+// B = 8 rate): when at least two splits of a DEEP contraction fit on the chip, the GEMM runs as `s` partial products (tile
+// variant 5, grid.y = s, fp32 slabs in split_ws) and gated_split_reduce adds them to the residual stream in slab order.
+// Measured inside the XL/2 forward at B = 1 (same box): fc2 (K = 4608) 77.6 -> 68.2 us including the reduction, the out-projection
+// (K = 1152) 30.6 -> 39.0 us -- the reduction pass costs more than half of a 18-K-tile GEMM, hence the >= 32 K tiles per split.
+// (A stream-K decomposition of the 12-wave kernel with in-launch hand-over of the partial products was built and measured
+// slower than this at every small-batch shape: DESIGN.md section 8.)
+constexpr int64_t SPLIT_WS_FLOATS = 256ll * 256 * 192;   // s * tiles <= 256 tiles of 256 x 192
+int gated_split_choice(const latte_engine* e, int M, int N, int K, int variant) {
+  if (variant != 0 || e->gated_split_k == 1 || N % 192 || K % 64) return 1;
+  const int tiles = ((M + 255) / 256) * (N / 192), nk = K / 64;
+  if (e->gated_split_k >= 2) {
+    const int s = e->gated_split_k;
+    return (nk % s == 0 && (int64_t)s * M * N <= SPLIT_WS_FLOATS) ? s : 1;
+  }
+  for (int s = 4; s >= 2; --s)
+    if (tiles * s <= 256 && nk % s == 0 && nk / s >= 32 && (int64_t)s * M * N <= SPLIT_WS_FLOATS) return s;
+  return 1;
+}
+int gated_gemm(latte_engine* e, const GemmArgs& g, int dt, int variant, hipStream_t st) {
+  const int s = gated_split_choice(e, g.M, g.N, g.K, variant);
+  if (s == 1) return launch_gemm(g, EPI_GATE_RES_F32, dt, variant, st);
+  GemmArgs p = g;
+  p.bias = e->zero_bias;
+  p.gate = nullptr;
+  p.out = e->split_ws;
+  p.k_chunk = g.K / s;
+  p.split_stride = (long)g.M * g.N;
+  if (int rc = launch_gemm(p, EPI_BIAS_F32, dt, 5, st)) return rc;
+  return launch_gated_split_reduce((float*)g.out, e->split_ws, s, (size_t)g.M * g.N, g.bias, g.gate, g.gate_stride,
+                                   g.rows_per_sample, g.M, g.N, st);
+}
 
 // mod_override != nullptr: the adaLN outputs of this step were precomputed ([B or 1 rows, nmod], row stride mod_stride;
 // stride 0 = one row shared by every sample) and the conditioning launches are skipped.
@@ -202,7 +238,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     if ((rc = launch_attention(a, dt, st))) return rc;
     tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
-    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
+    if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
     tm.mark(C_LN);
@@ -210,7 +246,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC1);
     g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
-    if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, e->gemm_variant_of[3] ? e->gemm_variant_of[3] : e->gemm_variant, st))) return rc;
+    if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[3] ? e->gemm_variant_of[3] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC2);
   }
   // --- final layer (latte.py:197-201) + unpatchify (:297-310)
@@ -394,6 +430,8 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
 
   TRY(dev_alloc(e, &e->stage, (size_t)e->stage_numel, false));
   TRY(dev_alloc(e, &e->xres, (size_t)e->rows_pad * D));
+  TRY(dev_alloc(e, &e->split_ws, (size_t)SPLIT_WS_FLOATS, false));
+  TRY(dev_alloc(e, &e->zero_bias, (size_t)std::max(D, e->Hm)));
   TRY(dev_alloc(e, &e->xn, (size_t)e->rows_pad * D));
   TRY(dev_alloc(e, &e->qkv, (size_t)e->rows_pad * 3 * D));
   TRY(dev_alloc(e, &e->hbuf, (size_t)e->rows_pad * e->Hm));
@@ -437,6 +475,11 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }
+  }
+  if (k == "gated_split_k") {
+    if (value < 0 || value > 4) return fail(LATTE_ERR_INVALID, "gated_split_k: 0 (rule), 1 (off) or 2..4 splits");
+    e->gated_split_k = (int)value;
+    return LATTE_OK;
   }
   if (k == "seed") {
     e->seed = (uint64_t)value;

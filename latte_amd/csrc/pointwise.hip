@@ -375,6 +375,31 @@ __global__ void __launch_bounds__(256) text_proj_kernel(const float* __restrict_
   }
 }
 
+// Second half of the split-K gated GEMM of small batches (engine.cpp: gated_gemm): the GEMM wrote `splits` fp32 partial products
+// [M, N] (slab stride `stride`); x += gate * ((p0 + p1 + ...) + bias), the partials summed in slab order (deterministic), the
+// expression of the gated read-modify-write epilogue (latte.py:179-180).  16 bytes per lane, N % 4 == 0.
+__global__ void __launch_bounds__(256) gated_split_reduce_kernel(float* __restrict__ x, const float* __restrict__ ws, int splits,
+                                                                 size_t stride, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gate, int gate_stride, int rps, int M,
+                                                                 int N) {
+  const int n4 = N >> 2;
+  const size_t total = (size_t)M * n4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+    const size_t o = (size_t)m * N + n;
+    float4 a = *(const float4*)(ws + o);
+    for (int k = 1; k < splits; ++k) {
+      const float4 b = *(const float4*)(ws + (size_t)k * stride + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float4 b4 = *(const float4*)(bias + n);
+    const float4 g4 = *(const float4*)(gate + (size_t)(m / rps) * gate_stride + n);
+    float4 r = *(const float4*)(x + o);
+    r.x += g4.x * (a.x + b4.x); r.y += g4.y * (a.y + b4.y); r.z += g4.z * (a.z + b4.z); r.w += g4.w * (a.w + b4.w);
+    *(float4*)(x + o) = r;
+  }
+}
+
 __global__ void silu_rows_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = silu(in[i]);
 }
@@ -847,6 +872,16 @@ int launch_text_proj(const float* text, const float* W, const float* bias, float
                      hipStream_t st) {
   if (K % 128) return fail(LATTE_ERR_INVALID, "text_proj: K must be a multiple of 128");
   hipLaunchKernelGGL(text_proj_kernel, dim3((N + 3) / 4), dim3(256), 0, st, text, W, bias, out, B, N, K);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_gated_split_reduce(float* x, const float* ws, int splits, size_t stride, const float* bias, const float* gate,
+                              int gate_stride, int rows_per_sample, int M, int N, hipStream_t st) {
+  if (N % 4 || splits < 1) return fail(LATTE_ERR_INVALID, "gated_split_reduce: need N % 4 == 0, splits >= 1");
+  const size_t n = (size_t)M * (N / 4);
+  hipLaunchKernelGGL(gated_split_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, x, ws, splits, stride, bias, gate,
+                     gate_stride, rows_per_sample, M, N);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -327,6 +327,42 @@ def test_xl_chain_is_bitwise_reproducible():
     assert not torch.equal(a, c)
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_small_batch_split_k_gated_gemms(B):
+    """B = 1 at XL/2: fc2 (96 tiles of 256 x 192 for 256 CUs, K = 4608) runs as two partial products over halves of the
+    contraction + a reduction into the residual stream (engine.cpp: gated_gemm).  The forward must agree with the unsplit path
+    up to the re-association (the contraction is summed in two parts instead of one), with the split forced on both gated GEMMs
+    likewise, be bit-identical run to run, and at B = 2 (192 tiles: no split) the rule must change nothing."""
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=32, num_frames=16, extras=1)
+    cfg = lo.preset_config("Latte-XL/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=7)
+    m = latte_amd.Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 16, 4, 32, 32, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    outs = {}
+    for mode in (0, 1, 2, 0):
+        m.set_engine_option("gated_split_k", mode, B)
+        o = m.forward(x, t)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        if mode in outs:
+            assert torch.equal(o, outs[mode]), "split-K path is not deterministic"
+        outs[mode] = o.clone()
+    m.set_engine_option("gated_split_k", 0, B)
+    if B == 1:
+        assert not torch.equal(outs[0], outs[1]), "the rule did not split at B = 1"
+        assert rel_l2(outs[0], outs[1]) < 6e-4      # fp32 re-association, amplified by the half-precision operand rounding downstream
+    else:
+        assert torch.equal(outs[0], outs[1])
+    if B == 1:
+        assert not torch.equal(outs[2], outs[1]), "the forced split did not split"
+    assert rel_l2(outs[2], outs[1]) < 6e-4
+
+
 @pytest.mark.parametrize("cd", [None, "f16"])
 def test_text_conditioned_variant_matches_reference_golden(cd):
     """extras == 78 (latte.py:238-242,340-363): text_embedding_projection inside the engine, blocks conditioned on

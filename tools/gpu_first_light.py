@@ -492,6 +492,43 @@ def xl_profile():
         torch.cuda.empty_cache()
 
 
+def small_batch():
+    """B = 1, 2 at XL/2: split-K gated GEMMs (engine option gated_split_k: 1 = off, 0 = rule, 2..4 forced) -- per-kernel times
+    inside the forward and the 10-step DDIM loop."""
+    import latte_amd
+    from latte_amd.models import Latte_models
+    for B in [int(v) for v in os.environ.get("LATTE_FL_B", "1,2").split(",")]:
+        m = Latte_models["Latte-XL/2"](compute_dtype="bf16", max_batch=B, input_size=32, num_frames=16, extras=1)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if float(p_.abs().max()) == 0.0:
+                    p_.normal_(0, 0.02)
+        m = m.to(dev)
+        x = torch.randn(B, 16, 4, 32, 32, device=dev)
+        t = torch.full((B,), 500, device=dev, dtype=torch.int64)
+        d = latte_amd.create_diffusion("250")
+        eng = m.engine(B)
+        for mode in (1, 0, 2, 1, 0):
+            m.set_engine_option("gated_split_k", mode, B)
+            m.profile_forward(x, t)
+            pr = [m.profile_forward(x, t) for _ in range(3)]
+            row = " ".join(f"{k[5:] if k.startswith('gemm_') else k}: {min(p[k][0] for p in pr) / max(pr[0][k][1], 1) * 1e3:5.1f}" for k in
+                           ("gemm_proj", "gemm_fc2", "gemm_qkv", "gemm_fc1", "ln_modulate", "attn_spatial", "attn_temporal"))
+            xx = x.clone()
+            check(lib.latte_sample_loop(eng, d._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 249, 249 - 2, None, None, None, stream_ptr()))
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.time()
+                check(lib.latte_sample_loop(eng, d._h, 1, 0.0, 0, 1.0, ptr(xx), None, B, 246, 246 - 20 + 1, None, None, None, stream_ptr()))
+                torch.cuda.synchronize()
+                best = min(best, time.time() - t0)
+            log(f"small_batch B={B} gated_split_k={mode} (us/launch): {row} | 20 DDIM steps {best*1e3:.1f} ms -> {B*20/best:.2f} sample-steps/s")
+        m.set_engine_option("gated_split_k", 0, B)
+        del m
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["env", "tr16_probe", "gemm_checks", "attention_checks", "ln_checks", "normal_check",
                              "gemm_bench", "xl_profile"]
