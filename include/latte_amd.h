@@ -81,8 +81,11 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
 void latte_engine_destroy(latte_engine_t* e);
 
 /* Engine options: "gemm_variant" (0 auto; 1-3 simple kernel 128x128 / 256x128 / 256x256; 4-6 ping-pong kernel
- * 256x128 / 256x192 / 256x256 tiles; 7-9 the persistent ping-pong kernel, same tiles),
+ * 256x128 / 256x192 / 256x256 tiles; 7-9 the persistent ping-pong kernel, same tiles; 10 / 11 the 12-wave
+ * producer / consumer kernel, 256x192, two-segment / rolling schedule),
  * "gemm_variant_qkv" / "_proj" / "_fc1" / "_fc2" (the same, for one of the four GEMMs of the block only; tuning hook),
+ * "gated_split_k" (small batches: 0 = the rule -- a gated GEMM with >= 64 K tiles whose tiles fill at most half of the
+ * CUs runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);
