@@ -362,15 +362,21 @@ __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float nm = -mx * c;
-      float ls = 0.f;
+      // two scores per VALU instruction where the ISA has packed fp32 forms (v_pk_fma_f32, v_pk_add_f32); the exp2 is scalar
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 c2 = {c, c}, nm2 = {nm, nm};
+      f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[gq][kt][r], c, nm));
-          st[gq][kt][r] = p;
-          ls += p;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 e = __builtin_elementwise_fma((f32x2){st[gq][kt][r], st[gq][kt][r + 1]}, c2, nm2);
+          const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          st[gq][kt][r] = p.x;
+          st[gq][kt][r + 1] = p.y;
+          ls2 += p;
         }
+      float ls = ls2.x + ls2.y;
       ls += __shfl_xor(ls, 16, 64);
       ls += __shfl_xor(ls, 32, 64);
       inv[gq] = 1.0f / ls;
