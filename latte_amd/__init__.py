@@ -13,7 +13,7 @@ from .pipeline import LattePipeline  # noqa: F401
 from .t2v import LatteT2V  # noqa: F401
 from .training import LatteTrainer  # noqa: F401
 from .vae import AutoencoderKL, AutoencoderKLTemporalDecoder  # noqa: F401
-from .video_io import read_avi, write_avi  # noqa: F401
+from .video_io import read_avi, read_mp4, write_avi, write_mp4  # noqa: F401
 from . import parallel  # noqa: F401
 
 __version__ = "0.1.0"

@@ -126,6 +126,38 @@ def test_avi_round_trip(tmp_path):
         write_avi(str(tmp_path / "bad.avi"), np.zeros((2, 4, 4), dtype=np.uint8))
 
 
+def test_mp4_round_trip(tmp_path):
+    """The reference's hand-off is an .mp4 (sample.py:123-126, sample_ddp.py:174-176).  write_mp4 puts Motion-JPEG samples into an
+    ISO base-media file: box structure (ftyp first, one mdat, one moov with a single video track whose sample table addresses
+    every frame), frame count / size / rate, and the decoded frames within JPEG tolerance of the uint8 input."""
+    import struct
+    import numpy as np
+    from latte_amd import read_mp4, write_mp4
+    f, h, w = 16, 64, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    v = np.stack([np.stack([127 + 100 * np.sin(xx / 9 + i / 3), 127 + 100 * np.cos(yy / 7 - i / 5), (xx + yy + 4 * i) % 256], -1)
+                  for i in range(f)]).astype(np.uint8)
+    path = str(tmp_path / "v.mp4")
+    write_mp4(path, torch.from_numpy(v), fps=8)
+    raw = open(path, "rb").read()
+    boxes, p = [], 0
+    while p < len(raw):
+        n, kind = struct.unpack_from(">I4s", raw, p)
+        boxes.append((kind, p, n))
+        p += n
+    assert p == len(raw) and [b[0] for b in boxes] == [b"ftyp", b"mdat", b"moov"]
+    assert raw[8:12] == b"isom" and b"mp4v" in raw and b"esds" in raw and raw.count(b"trak") == 1
+    stco = raw.index(b"stco")
+    assert struct.unpack_from(">I", raw, stco + 12)[0] == boxes[1][1] + 8        # the chunk offset points at the first JPEG
+    assert raw[boxes[1][1] + 8: boxes[1][1] + 10] == b"\xff\xd8"                 # ... which starts with SOI
+    back, fps = read_mp4(path)
+    assert fps == 8.0 and back.shape == v.shape and back.dtype == np.uint8
+    rms = float(np.sqrt(((back.astype(np.float64) - v) ** 2).mean()))
+    assert rms < 2.5, rms
+    with pytest.raises(ValueError):
+        write_mp4(str(tmp_path / "bad.mp4"), np.zeros((2, 4, 4), dtype=np.uint8))
+
+
 def test_oracle_is_only_imported_by_the_checkers():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
     The package, the tools and the rest of bench.py must not (random weights for plumbing runs come from

@@ -128,7 +128,7 @@ def test_sample_single_video_tool(tmp_path):
                         os.path.join(ROOT, "configs", "tiny_sample.yaml"), "--save_video_path", str(tmp_path), "--steps", "4"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    frames, fps = latte_amd.read_avi(os.path.join(str(tmp_path), "sample.avi"))
+    frames, fps = latte_amd.read_mp4(os.path.join(str(tmp_path), "sample.mp4"))   # the reference's file name (sample.py:123)
     assert tuple(frames.shape) == (4, 128, 128, 3) and fps == 8 and float(np.asarray(frames, dtype=np.float64).std()) > 0
 
 

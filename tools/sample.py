@@ -7,7 +7,8 @@ latte_amd: config -> get_models -> find_model / load_
 AutoencoderKL -> z (doubled with the null class under guidance, :86-98) -> p_sample_loop / ddim_sample_loop (:100-107) ->
 vae.decode(z / 0.18215) (:113-115) -> uint8 video (:122) -> file.  Offline there are no checkpoints: without --ckpt the
 zero-initialised adaLN / final layers are re-drawn so the run exercises the whole path (plumbing, not picture quality), and
-the video is written as uncompressed .avi (the reference writes .mp4 through imageio, :124-126)."""
+the video is written as sample.mp4 like the reference's (:124-126; Motion-JPEG samples instead of imageio's H.264, see
+latte_amd/video_io.py)."""
 import argparse
 import os
 import sys
@@ -77,8 +78,8 @@ def main(args, cli):
         .to(dtype=torch.uint8).cpu().permute(0, 1, 3, 4, 2).contiguous()   # :122
     out_dir = args.get("save_video_path") or "./sample_videos"
     os.makedirs(out_dir, exist_ok=True)                                    # :118-120
-    path = os.path.join(out_dir, "sample.avi")
-    latte_amd.write_avi(path, video[0], fps=8)                             # :124-126 (fps 8)
+    path = os.path.join(out_dir, "sample.mp4")                             # :123
+    latte_amd.write_mp4(path, video[0], fps=8)                             # :124-126 (fps 8)
     print("saved", path, tuple(video.shape))
     return video
 

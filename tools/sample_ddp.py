@@ -6,8 +6,9 @@
 One process per GPU, weights replicated, samples sharded by global index (latte_amd.parallel.plan_shards =
 sample_ddp.py:116-176); collectives: start / end barrier and ONE RCCL broadcast of the timestep-embedding table.
 Without --ckpt / a VAE directory the weights are random (there are no checkpoints offline): the script then
-measures and checks plumbing, not picture quality.  Videos are written as uncompressed .avi (latte_amd.video_io; the
-reference writes .mp4 through imageio, sample_ddp.py:176, which is not available offline) or uint8 .npy [F, H, W, 3].
+measures and checks plumbing, not picture quality.  Videos are written as {index:04d}.mp4 like the reference's
+(sample_ddp.py:174-176; Motion-JPEG samples, latte_amd.video_io -- imageio / H.264 do not exist offline), as lossless
+uncompressed .avi, or as uint8 .npy [F, H, W, 3].
 """
 import argparse
 import os
@@ -41,7 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="override num_sampling_steps")
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--format", choices=["avi", "npy"], default="avi")
+    ap.add_argument("--format", choices=["mp4", "avi", "npy"], default="mp4")   # mp4: the reference's {index:04d}.mp4 (:174-176)
     a = ap.parse_args()
     args = latte_amd.load_config(a.config)
     torch.set_grad_enabled(False)
@@ -107,8 +108,10 @@ def main():
         if vae is not None:
             video = vae.decode_video_uint8(samples)                # decode(z / 0.18215) + uint8, sample_ddp.py:165-172
             for j, i in enumerate(idx):
-                if a.format == "avi":
-                    latte_amd.write_avi(os.path.join(out_dir, f"{i:04d}.avi"), video[j], fps=8)   # fps as sample_ddp.py:176
+                if a.format == "mp4":
+                    latte_amd.write_mp4(os.path.join(out_dir, f"{i:04d}.mp4"), video[j], fps=8)   # sample_ddp.py:174-176
+                elif a.format == "avi":
+                    latte_amd.write_avi(os.path.join(out_dir, f"{i:04d}.avi"), video[j], fps=8)   # lossless alternative
                 else:
                     np.save(os.path.join(out_dir, f"{i:04d}.npy"), video[j].cpu().numpy())
         else:

@@ -6,8 +6,8 @@ With a real checkpoint directory (`pretrained_model_path` holding transformer/, 
 the reference's (sample_t2x.py:21-140): T5 tokenizer + encoder from `transformers`, `LatteT2V.from_pretrained_2d`,
 `AutoencoderKL.from_pretrained`, a DDIM scheduler, `LattePipeline(...)`, one video per prompt.  Offline there are no
 weights: `--random` builds randomly initialised models and random prompt embeddings of the right shape, which exercises the
-whole device path (denoiser, guidance loop, VAE decode, video hand-off) and times it.  Videos are written as uncompressed
-.avi (latte_amd.video_io).  Only the DDIM scheduler has a self-contained stand-in (latte_amd/schedulers.py); any diffusers
+whole device path (denoiser, guidance loop, VAE decode, video hand-off) and times it.  Videos are written as .mp4
+(Motion-JPEG samples, latte_amd.video_io).  Only the DDIM scheduler has a self-contained stand-in (latte_amd/schedulers.py); any diffusers
 scheduler object can be passed to LattePipeline instead.
 """
 import argparse
@@ -87,8 +87,8 @@ def main():
                      enable_vae_temporal_decoder=bool(args.enable_vae_temporal_decoder), generator=g, **kw).video
         torch.cuda.synchronize()
         dt = time.time() - t0
-        path = os.path.join(out_dir, f"{n:03d}.avi")
-        latte_amd.write_avi(path, video[0], fps=8)                    # sample_t2x.py:137 imageio.mimwrite(..., fps=8)
+        path = os.path.join(out_dir, f"{n:03d}.mp4")
+        latte_amd.write_mp4(path, video[0], fps=8)                    # sample_t2x.py:137 imageio.mimwrite(..., fps=8)
         print(f"  {steps} steps + decode in {dt:.2f} s ({steps / dt:.2f} steps/s incl. decode) -> {path} {tuple(video.shape)}")
 
 
