@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/prof_kernel.sh <outdir under gpurun_out> <cmd...>   -- kernel trace + separate PMC passes (never combined)
+# ALWAYS pass --output-format csv: without it rocprofv3 7.x writes a rocpd database and derives the statistics from it after
+# the run, which took > 5 minutes of box time for a 3-forward LatteT2V trace (round 2b: one such call ate the GPU budget).
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
