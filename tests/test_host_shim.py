@@ -154,6 +154,11 @@ def test_mp4_round_trip(tmp_path):
     assert fps == 8.0 and back.shape == v.shape and back.dtype == np.uint8
     rms = float(np.sqrt(((back.astype(np.float64) - v) ** 2).mean()))
     assert rms < 2.5, rms
+    for shape, rate in [((1, 5, 7, 3), 8), ((3, 33, 17, 3), 23.976), ((2, 256, 256, 3), 30)]:   # one frame, odd sizes, fractional rate
+        u = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
+        write_mp4(path, u, fps=rate)
+        back, fps = read_mp4(path)
+        assert back.shape == u.shape and abs(fps - rate) < 1e-9
     with pytest.raises(ValueError):
         write_mp4(str(tmp_path / "bad.mp4"), np.zeros((2, 4, 4), dtype=np.uint8))
 
