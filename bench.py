@@ -1,6 +1,12 @@
 """bench.py — denoising steps/sec of the Latte-XL/2 16x256x256 sampling loop on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE / RANK / LOCAL_RANK in the environment, the
+driver's launch line) the process is one rank and asserts WORLD_SIZE == --gpus; started plainly (`python bench.py --gpus N`)
+it re-executes itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free port> bench.py <same flags>` -- the reference's sample_ddp.py is launched the same way
+(sample/sample_ddp.py:60-66: one rank per device, torchrun environment).
 
 One "step" = one pass of the hot path (denoiser forward + sampler update) over the rank's batch of
 latents, inputs resident in HBM.  Workload (every N) = BASELINE.json configs[1]: Latte-XL/2, FaceForensics
@@ -23,8 +29,10 @@ Beside the headline, in the same JSON line:
     latents, local batch 5 (configs/ffs/ffs_train.yaml), forward + loss + backward + gradient all-reduce (N > 1: one RCCL
     all-reduce of the 130 M-parameter fp32 gradient buffer) + clip + AdamW + EMA; samples/s over all ranks and the
     algorithmic TFLOP/s (3 x forward FLOPs);
-  * `cpu_baseline` (N = 1): the oracle's forward on the host cores, a forward-only proxy of the reference's
-    p_sample_loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
+  * `config4` (N = 1): BASELINE config 4 -- Latte-1 text-to-video 512x512x16: one guided DDIM step of LatteT2V inside the
+    engine and the 16-frame AutoencoderKLTemporalDecoder decode, random weights of the real shapes;
+  * `cpu_baseline` (N = 1): the oracle's sampling-loop body (forward + ddim_sample) on the host cores, standing in for the reference's
+    loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
     than it because it skips the reference's repeated adaLN rows: oracle/VALIDATION.md).
 """
 import argparse
@@ -53,10 +61,15 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--method", default="ddim", choices=["ddim", "ddpm"])
     p.add_argument("--gemm-variant", type=int, default=0)
+    p.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                   help="latte_engine_set_option on the headline engine before the timed region (A/B measurements, e.g. fuse_qkv_attn=0)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode rate report")
     p.add_argument("--no-side", action="store_true", help="skip the f16 / config-3 side measurements")
-    p.add_argument("--cpu-forwards", type=int, default=2)
+    p.add_argument("--launch-check", action="store_true",
+                   help="launch N ranks, rendezvous, one all-reduce, print {launch_check, n_gpus, collective_ranks} and exit: "
+                        "exercises the --gpus contract without measuring anything (runs without a GPU on the gloo backend)")
+    p.add_argument("--cpu-steps", type=int, default=3, help="timed DDIM steps of the CPU baseline (about 5 s each)")
     return p.parse_args()
 
 
@@ -97,41 +110,67 @@ def timed_steps(lib, model, diffusion, x, steps, method, batch, **kw):
     return (time.perf_counter() - t0) / steps
 
 
-def cpu_baseline(n_forwards):
-    """The oracle (a CPU port of the reference forward, bit-identical to it: oracle/VALIDATION.md) timed
-    on this box's host cores — reported beside the GPU number, never the thing measured."""
+def cpu_baseline(n_steps):
+    """The oracle (a CPU port of the reference, bit-identical to it: oracle/VALIDATION.md) running the reference's sampling
+    loop body -- denoiser forward + `ddim_sample` (gaussian_diffusion.py:604-684) on the "250" respacing -- on this box's
+    host cores; reported beside the GPU number, never the thing measured.  Thread count: one untimed-for-the-result forward
+    at 32, 64 and 128 threads (those the box has), the fastest count runs the timed steps (MKL / OpenMP GEMMs of this size
+    stop scaling, and can collapse, well below the 256 hardware threads of the GPU box)."""
+    from oracle import diffusion_oracle as do
     from oracle import latte_oracle as lo
     cfg = lo.preset_config("Latte-XL/2", input_size=32, num_frames=16, extras=1)
     sd = lo.init_state_dict(cfg, seed=0)
     x = torch.randn(1, 16, 4, 32, 32)
-    t = torch.tensor([500])
-    # MKL/OpenMP GEMMs stop scaling (and can collapse) far below the 256 hardware threads of the GPU box
-    cores = min(len(os.sched_getaffinity(0)), 32)
-    torch.set_num_threads(cores)
+    s = do.Schedule("250")
+    visible = len(os.sched_getaffinity(0))
+    sweep = {}
     with torch.no_grad():
-        lo.latte_forward(sd, cfg, x, t)                       # warm-up
+        torch.set_num_threads(min(visible, 32))
+        lo.latte_forward(sd, cfg, x, torch.tensor([500]))                       # warm-up (page-in, MKL init)
+        for n in sorted({min(visible, c) for c in (32, 64, 128)}):
+            torch.set_num_threads(n)
+            t0 = time.time()
+            lo.latte_forward(sd, cfg, x, torch.tensor([500]))
+            sweep[n] = round(time.time() - t0, 3)
+        cores = min(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
         t0 = time.time()
-        for _ in range(n_forwards):
-            lo.latte_forward(sd, cfg, x, t)
-        dt = (time.time() - t0) / n_forwards
-    return {"value": round(1.0 / dt, 4), "unit": "denoising sample-steps/s", "cores": torch.get_num_threads(),
-            "host_cores_visible": len(os.sched_getaffinity(0)), "kind": "port",
-            "sample": f"forward-only proxy of the reference's p_sample_loop: {n_forwards} timed fp32 forwards of the oracle's "
-                      "Latte-XL/2 (B=1, 16x32x32 latents) after 1 warm-up; the sampler update is negligible on CPU "
-                      "(<0.1%); the oracle is bit-identical to the reference forward and ~6 % faster than it "
-                      "(oracle/VALIDATION.md: 6.61 s vs 7.06 s)"}
+        for k in range(n_steps):                                                 # the loop body of gd:637-684
+            i = s.num_timesteps - 1 - k
+            out = lo.latte_forward(sd, cfg, x, torch.full((1,), s.timestep_map[i], dtype=torch.int64))
+            x = do.ddim_sample(s, out, x, i, None, 0.0, False)["sample"]
+        dt = (time.time() - t0) / n_steps
+    return {"value": round(1.0 / dt, 4), "unit": "denoising sample-steps/s", "cores": cores,
+            "host_cores_visible": visible, "kind": "port", "seconds_per_forward_by_threads": sweep,
+            "sample": f"{n_steps} timed DDIM steps (oracle forward + ddim_sample, fp32, B=1, Latte-XL/2 16x32x32 latents, '250' "
+                      "respacing) after 1 warm-up forward and a 32/64/128-thread sweep; the oracle is bit-identical to the "
+                      "reference loop and ~6 % faster than it (it skips the repeated adaLN rows; oracle/VALIDATION.md: "
+                      "6.61 s vs 7.06 s per forward)"}
 
 
 def pmc_table():
     """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_collect.py:
-    FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE); {} when nothing was profiled."""
-    tab = {}
-    for name in ("r1_gemm_pmc.json", "r2_pmc.json"):      # later files override earlier ones
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as f:
-                tab.update(json.load(f))
-    return tab
+    FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE) -- a committed constant per kernel class and shape,
+    NOT a per-run measurement: rocprofv3 cannot run inside this process.  Files are merged oldest round first, so every
+    (class, shape) key carries the NEWEST pass that measured it; -> ({key: record}, {key: source file})."""
+    import glob
+    import re
+
+    def order(path):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    tab, src = {}, {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), key=order):
+        with open(path) as f:
+            try:
+                rec = json.load(f)
+            except ValueError:
+                continue
+        for k, v in rec.items():
+            if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                tab[k] = v
+                src[k] = "profiles/" + os.path.basename(path)
+    return tab, src
 
 
 def roofline_table(prof, B, dtype):
@@ -143,12 +182,18 @@ def roofline_table(prof, B, dtype):
     mfma = {"gemm_qkv": (2.0 * M * 3 * D * D, "gemm_pps_kernel<256, EPI_BIAS_H16>: qkv projection M=%d N=3456 K=1152" % M),
             "gemm_proj": (2.0 * M * D * D, "gemm_pwr_kernel<EPI_GATE_RES_F32, tag 0> (12-wave producer/consumer, 256x192): attention out-projection M=%d N=1152 K=1152, gated fp32 residual RMW" % M),
             "gemm_fc1": (2.0 * M * Hm * D, "gemm_pps_kernel<256, EPI_BIAS_GELU_H16>: fc1 M=%d N=4608 K=1152, bias+GELU" % M),
-            "gemm_fc2": (2.0 * M * D * Hm, "gemm_pwr_kernel<EPI_GATE_RES_F32, tag 1> (12-wave producer/consumer, 256x192): fc2 M=%d N=1152 K=4608, gated fp32 residual RMW" % M)}
+            "gemm_fc2": (2.0 * M * D * Hm, "gemm_pwr_kernel<EPI_GATE_RES_F32, tag 1> (12-wave producer/consumer, 256x192): fc2 M=%d N=1152 K=4608, gated fp32 residual RMW" % M),
+            # the fused QKV projection + attention kernel (csrc/qkv_attn.hip): algorithmic FLOPs = the projection (2 M 3D D) + the
+            # two attention products (4 S L^2 D); q / k / v never reach HBM
+            "qkv_attn_spatial": (2.0 * M * 3 * D * D + 4.0 * B * F * T * T * D,
+                                 "qkv_attn_kernel<72, MODE 0>: QKV projection + spatial attention fused, %d sequences x 16 heads x 256 tokens, q/k/v in LDS" % (B * F)),
+            "qkv_attn_temporal": (2.0 * M * 3 * D * D + 4.0 * B * T * F * F * D,
+                                  "qkv_attn_kernel<72, MODE 1>: QKV projection + temporal attention fused, %d sequences x 16 heads x 16 frames, q/k/v in LDS" % (B * T))}
     qkv_bytes = M * 3 * D * 2 + M * D * 2      # reads q, k, v once, writes the head outputs
     hbm = {"attn_spatial": (qkv_bytes, 4.0 * B * F * T * T * D, "attn_full_kernel<72>: spatial attention, %d sequences x 16 heads x 256 tokens" % (B * F)),
            "attn_temporal": (qkv_bytes, 4.0 * B * T * F * F * D, "attn_small_kernel<72>: temporal attention, %d sequences x 16 heads x 16 frames" % (B * T)),
            "ln_modulate": (M * D * (4 + 2), 0.0, "ln_modulate_kernel: LayerNorm + adaLN modulate, fp32 in, half out")}
-    pmc = pmc_table()
+    pmc, pmc_src = pmc_table()
     total_ms = sum(v[0] for v in prof.values())
     rows = []
     for k, (ms, n) in prof.items():
@@ -170,6 +215,7 @@ def roofline_table(prof, B, dtype):
                 row["mfma_frac_of_peak"] = round(fl / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
         rec = pmc.get(f"{k}:M={M}")
         row["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
+        row["traffic_source"] = (pmc_src[f"{k}:M={M}"] + " (committed rocprofv3 PMC pass, not measured in this run)") if rec else None
         rows.append(row)
     rows.sort(key=lambda r: -r["share_of_forward"])
     return rows, total_ms
@@ -222,16 +268,123 @@ def vae_decode_rate(device):
             "finite_and_nonconstant": bool(out.float().std() > 0)}
 
 
+def config4_rate(device, n_steps=4):
+    """BASELINE config 4 (configs/t2x/t2v_sample.yaml:24-26, sample/sample_t2x.py): Latte-1 text-to-video, 16 frames of 64x64
+    latents (512 px), the classifier-free-guidance pair through LatteT2V inside the engine's guided DDIM loop
+    (pipeline_latte.py:735-758), then the 16-frame AutoencoderKLTemporalDecoder decode in chunks of 14 + 2 frames
+    (pipeline_latte.py:779-798).  Random weights of the real shapes, 120 T5 tokens (40 unmasked); f16 operands (the reference
+    runs this model in fp16: sample_t2x.py:29).  Side measurement outside the timed region."""
+    import latte_amd
+    from latte_amd.random_init import t2v_state_dict, vae_temporal_decoder_state_dict
+    from latte_amd.schedulers import DDIMScheduler
+    m = latte_amd.LatteT2V(num_layers=28, compute_dtype="f16", max_batch=2).load_state_dict(t2v_state_dict(0, num_layers=28)).to(device)
+    g = torch.Generator("cpu").manual_seed(4000)
+    enc = torch.randn(2, 120, 4096, generator=g).to(device)
+    mask = torch.ones(2, 120, device=device)
+    mask[:, 40:] = 0
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    ts = [int(v) for v in sch.timesteps[:n_steps]]
+    ratio = sch.num_train_timesteps // sch.num_inference_steps
+    at = [float(sch.alphas_cumprod[v]) for v in ts]
+    ap = [float(sch.alphas_cumprod[v - ratio]) if v >= ratio else 1.0 for v in ts]
+    lat = torch.randn(1, 4, 16, 64, 64, generator=g).to(device)
+    m.set_text(enc, mask)
+    m.guided_ddim_loop(lat, ts[:2], at[:2], ap[:2], 7.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = m.guided_ddim_loop(lat, ts, at, ap, 7.5)
+    torch.cuda.synchronize()
+    dstep = (time.perf_counter() - t0) / n_steps
+    D, T, F, L = 1152, 1024, 16, 28
+    M = 2 * F * T
+    lin = 2.0 * M * D * (3 * D + D + 4 * D + 4 * D) * 2 * L + 2.0 * M * D * (D + D) * L      # self blocks (x2) + cross q / out
+    attn = L * (4.0 * 2 * F * T * T * D + 4.0 * 2 * T * F * F * D + 4.0 * 2 * F * T * 120 * D)
+    res = {"workload": "Latte-1 T2V 512x512x16 (16 x 4 x 64x64 latents, 28 + 28 blocks, guidance pair, 120 T5 tokens), guided DDIM "
+                       "step inside the engine + AutoencoderKLTemporalDecoder decode (14 + 2 frame chunks), random weights, f16 operands",
+           "guided_step_ms": round(dstep * 1e3, 2), "steps": n_steps, "value": round(1.0 / dstep, 3), "unit": "guided steps/s",
+           "seconds_for_50_steps": round(50 * dstep, 2),
+           "algorithmic_tflops_per_s": round((lin + attn) / dstep / 1e12, 1),
+           "model_mfma_frac": round((lin + attn) / dstep / 1e12 / MFMA_PEAK_TFLOPS, 4),
+           "finite": bool(torch.isfinite(out).all())}
+    del m
+    torch.cuda.empty_cache()
+    vae = latte_amd.AutoencoderKLTemporalDecoder(latent_size=64, max_frames=14)
+    vae.load_state_dict(vae_temporal_decoder_state_dict(0))
+    vae.to(device)
+    z = torch.randn(16, 4, 64, 64, generator=g).to(device)     # latents / scaling_factor (pipeline_latte.py:786)
+
+    def decode():
+        return [vae.decode(z[i:i + 14].contiguous(), num_frames=min(14, 16 - i)).sample for i in range(0, 16, 14)]
+    decode()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vid = decode()
+    torch.cuda.synchronize()
+    dd = time.perf_counter() - t0
+    res["temporal_decoder"] = {"ms_per_16_frame_video": round(dd * 1e3, 2), "frames_per_sec": round(16 / dd, 1),
+                               "finite": bool(all(torch.isfinite(v).all() for v in vid))}
+    res["seconds_per_video_50_steps_plus_decode"] = round(50 * dstep + dd, 2)
+    del vae
+    torch.cuda.empty_cache()
+    return res
+
+
 def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"--gpus {n} without a launcher: re-executing as {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd)
+
+
+def launch_check(args, world, rank, backend):
+    """--launch-check: the rendezvous + collective of the N-rank launch and nothing else (no `value` is printed)."""
+    ranks, total = 1, rank
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        cuda = backend == "nccl"
+        if cuda:
+            assert torch.cuda.is_available() and world <= torch.cuda.device_count(), "RCCL: one rank per GPU"
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+        v = torch.tensor([float(rank)], device="cuda" if cuda else "cpu")
+        dist.all_reduce(v)
+        dist.barrier()
+        ranks, total = dist.get_world_size(), int(v.item())
+        dist.destroy_process_group()
+    assert total == world * (world - 1) // 2
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "collective_ranks": ranks,
+                          "collective_backend": "rccl" if backend == "nccl" else backend}))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LATTE_BENCH_BACKEND", "nccl")
+    if args.launch_check:
+        return launch_check(args, world, rank, backend)
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    # "nccl" is RCCL on ROCm: one rank per device.  LATTE_BENCH_BACKEND=gloo exists only to exercise the N > 1 code path on a
+    # box with fewer GPUs than ranks (RCCL refuses two ranks on one device); it is never used for reported numbers.
+    assert backend != "nccl" or world <= torch.cuda.device_count(), \
+        f"--gpus {world} needs {world} devices (RCCL: one rank per GPU), {torch.cuda.device_count()} visible"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -239,9 +392,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm.  LATTE_BENCH_BACKEND=gloo exists only to exercise the N > 1 code path on a box
-        # with fewer GPUs than ranks (RCCL refuses two ranks on one device); it is never used for reported numbers.
-        backend = os.environ.get("LATTE_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -255,6 +405,9 @@ def main():
     note('model on device')
     if args.gemm_variant:
         model.set_engine_option("gemm_variant", args.gemm_variant, args.batch)
+    for opt in args.engine_option:
+        k, v = opt.split("=")
+        model.set_engine_option(k, int(v), args.batch)
     diffusion = latte_amd.create_diffusion("250")
     B = args.batch
     if dist is not None:
@@ -362,7 +515,8 @@ def main():
         dom = table[0]                                   # the dominant kernel = largest share of the forward
         res = {
             "metric": "denoising steps/sec", "value": round(value, 3), "unit": "sample-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "collective_ranks": dist.get_world_size() if dist is not None else 1,
+            "collective_backend": (("rccl" if backend == "nccl" else backend) if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "Latte-XL/2 FaceForensics (uncond) 16x256x256 -> latents 16x4x32x32, "
@@ -373,7 +527,7 @@ def main():
             "model_mfma_frac": round(value / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "finite": finite,
             "roofline": {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
-                         "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"],
+                         "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": dom["traffic_source"],
                          "avg_launch_ms": dom["avg_launch_ms"], "share_of_forward": dom["share_of_forward"]},
             "roofline_table": table,
             "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
@@ -403,9 +557,12 @@ def main():
                     res[k]["per_gpu_batch"] = v["batch"]
         if world == 1 and not args.no_vae:
             res["vae_decode"] = vae_decode_rate(device)
+        if world == 1 and not args.no_side:
+            note('config 4 (Latte-1 T2V guided step + temporal decoder)')
+            res["config4"] = config4_rate(device)
         if world == 1 and not args.no_cpu_baseline:
             note('cpu baseline (oracle on host cores)')
-            res["cpu_baseline"] = cpu_baseline(args.cpu_forwards)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_steps)
             note('cpu baseline done')
         print(json.dumps(res))
     if dist is not None:

@@ -86,6 +86,9 @@ void latte_engine_destroy(latte_engine_t* e);
  * "gemm_variant_qkv" / "_proj" / "_fc1" / "_fc2" (the same, for one of the four GEMMs of the block only; tuning hook),
  * "gated_split_k" (small batches: 0 = the rule -- a gated GEMM with >= 64 K tiles whose tiles fill at most half of the
  * CUs runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
+ * "fuse_qkv_attn" (bit 0: spatial blocks, bit 1: temporal blocks run the QKV projection and the attention core of
+ * latte.py:48-70 as ONE kernel with q / k / v held in LDS -- csrc/qkv_attn.hip -- wherever the shape allows it: 256 tokens per
+ * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; both give the same bits),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);
@@ -321,9 +324,10 @@ int latte_t2v_guided_ddim_loop(latte_t2v_t* e, float* x, int samples, int n_step
  * Runs ONE denoiser forward eagerly with HIP events around every kernel launch on `stream`,
  * synchronises, and reports per-kernel-class totals.  classes (fixed order):
  *   0 gemm_qkv 1 gemm_proj 2 gemm_fc1 3 gemm_fc2 4 attn_spatial 5 attn_temporal 6 ln_modulate
- *   7 embed_cond 8 patch_embed 9 final_layer
- * ms_out / launches_out: arrays of n (>= 10). */
-#define LATTE_NUM_KERNEL_CLASSES 10
+ *   7 embed_cond 8 patch_embed 9 final_layer 10 qkv_attn_spatial 11 qkv_attn_temporal (the fused QKV projection +
+ *   attention kernel of csrc/qkv_attn.hip, which replaces classes 0 + 4 / 0 + 5 in the blocks whose shape allows it)
+ * ms_out / launches_out: arrays of n (>= 12). */
+#define LATTE_NUM_KERNEL_CLASSES 12
 int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,
                           float* out, float* ms_out, int* launches_out, int n, void* stream);
 /* Stand-alone timing of the dominant kernel: C[M,N] = A[M,K] * W[N,K]^T (+bias epilogue `epi`,

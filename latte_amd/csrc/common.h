@@ -125,6 +125,22 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t st);
 int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st);
 
+// ---- fused QKV projection + attention (qkv_attn.hip): out[rows, D] = attention(xn W_qkv^T + b) per (sequence, head), Q / K / V
+// of a head live only in LDS.  mode 0: spatial sequences (T == 256 tokens of one frame), mode 1: temporal sequences (F == 16
+// frames of one token); rows in the canonical [B, F, T] order.
+struct QkvAttnArgs {
+  const half_t* xn;    // [B F T, D]  LN-modulated activations (must not alias out)
+  const half_t* w;     // [3 D, D]    qkv weight, rows ordered [3][heads][hd]   (latte.py:50)
+  const float* bias;   // [3 D]
+  half_t* out;         // [B F T, D]  column = head * hd + d                    (latte.py:70)
+  half_t* dbg_qkv;     // test hook: when set, [B F T, 3 D] receives the half q | k | v the kernel holds in LDS
+  int B, F, T, D, heads, hd;
+  int mode;
+  float scale;         // hd^-0.5
+};
+bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
+int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
+
 // ---- pointwise / small kernels ------------------------------------------------------------------
 // y(half)[m, :] = LN(x[m, :]) * (1 + scale[s(m), :]) + shift[s(m), :], eps 1e-6, no affine.
 // If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).

@@ -59,6 +59,8 @@ struct latte_engine {
   int64_t rows_max = 0, rows_pad = 0;
   int gemm_variant = 0;  // 0 = per-shape choice (gemm_auto_variant)
   int gemm_variant_of[4] = {0, 0, 0, 0};   // per-GEMM override (qkv, proj, fc1, fc2); 0 = gemm_variant
+  int fuse_qkv_attn = 3;                   // bit 0: spatial blocks, bit 1: temporal blocks run qkv projection + attention as ONE kernel
+                                           // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair
   int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
@@ -130,7 +132,7 @@ struct Timer {  // optional per-launch HIP events (latte_profile_forward)
     p->cls.push_back(cls);
   }
 };
-enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATCH, C_FINAL, C_NONE = -1 };
+enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATCH, C_FINAL, C_QKVATTN_S, C_QKVATTN_T, C_NONE = -1 };
 
 // Gated read-modify-write GEMM x += gate * (A W^T + bias) (attention out-projection, fc2; latte.py:179-180).  At small batches
 // its 256 x 192 output tiles fill a fraction of the 256 CUs (B = 1 at XL/2: 96 tiles, fc2 78 us per launch against 33 us at the
@@ -227,17 +229,29 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     tm.mark(C_LN);
     GemmArgs g{};
     g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
-    g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
-    if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant_of[0] ? e->gemm_variant_of[0] : e->gemm_variant, st))) return rc;
-    tm.mark(C_QKV);
-    AttnArgs a{};
-    a.qkv = e->qkv; a.out = e->xn; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
-    a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
-    if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
-    else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
-    if ((rc = launch_attention(a, dt, st))) return rc;
-    tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
-    g.A = e->xn; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
+    const half_t* attn_out = e->xn;
+    if (((e->fuse_qkv_attn >> (spatial ? 0 : 1)) & 1) && qkv_attention_fusable(D, c.num_heads, e->hd, F, T, spatial ? 0 : 1, M)) {
+      // qkv projection + attention core in one kernel (q / k / v of a head only in LDS); the output goes to the (otherwise idle)
+      // qkv buffer viewed as [rows, D], because xn is still being read by other units of the same launch
+      QkvAttnArgs qa{};
+      qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
+      qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
+      if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
+      tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
+      attn_out = e->qkv;
+    } else {
+      g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
+      if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, e->gemm_variant_of[0] ? e->gemm_variant_of[0] : e->gemm_variant, st))) return rc;
+      tm.mark(C_QKV);
+      AttnArgs a{};
+      a.qkv = e->qkv; a.out = e->xn; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
+      a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
+      if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
+      else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
+      if ((rc = launch_attention(a, dt, st))) return rc;
+      tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
+    }
+    g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
@@ -479,6 +493,11 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (k == "gated_split_k") {
     if (value < 0 || value > 4) return fail(LATTE_ERR_INVALID, "gated_split_k: 0 (rule), 1 (off) or 2..4 splits");
     e->gated_split_k = (int)value;
+    return LATTE_OK;
+  }
+  if (k == "fuse_qkv_attn") {
+    if (value < 0 || value > 3) return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks (0..3)");
+    e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }
   if (k == "seed") {

@@ -1,0 +1,432 @@
+// Fused QKV projection + attention core of one Latte block on gfx950:  out = softmax(q k^T * hd^-0.5) v  with
+// [q | k | v] = xn W_qkv^T + b computed INSIDE the kernel, per (sequence, head).
+//
+// Replaces Attention.forward up to (not including) the output projection (latte.py:48-77: `qkv = self.qkv(x)` at :50, the
+// reshape / permute copy at :50-51, `attn = (q @ k.transpose(-2, -1)) * self.scale` :67, softmax :68, `attn @ v` :70) for the
+// two sequence shapes of every 256-pixel, 16-frame Latte config: spatial blocks (256 tokens of one frame) and temporal blocks
+// (16 frames of one token, latte.py:355-368).  Un-fused, the qkv tensor makes a round trip through HBM (226 MB written and
+// read again per block at XL/2, B = 8) and the stand-alone attention kernel is bound by exactly that traffic (arithmetic
+// intensity 128 FLOP/B); here Q, K and V of a head exist only in LDS.
+//
+// One work unit = (sequence group, head):
+//   spatial : the 256 tokens of one frame  -> rows  sg * 256 + r                       of the canonical [B, F, T, D] order
+//   temporal: 16 neighbouring tokens x 16 frames -> tile row r = p * 16 + f  <->  row  b F T + f T + 16 tq + p
+//             (16 sequences of 16 tokens; the rows of a sequence are the 16 consecutive tile rows 16 p .. 16 p + 15)
+// and runs three phases on one 8-wave workgroup (one workgroup per CU, persistent over its units):
+//   G  [256 x NPAD] = xn_tile[256 x D] W_h^T, NPAD = 3 hd rounded up to 32 (224 at hd = 72): the ping-pong MFMA schedule of
+//      gemm.hip (two groups of 4 waves one barrier apart, operands staged by LDS DMA with the bank swizzle on the source
+//      address, BK = 64, two stages), wave tile 64 x NPAD/2.  The W tile's rows are gathered from the three row blocks
+//      q | k | v of the head (8-row DMA groups never straddle a block: hd % 8 == 0); the pad rows lie beyond the buffer
+//      descriptor and read as zeros.
+//   E  accumulators + bias -> half -> three row-major LDS images Q, K, V [256][160 B] (they overlay the operand stages).
+//   A  spatial: every wave owns 32 queries against all 256 keys -- the register-resident exact softmax of attn_full_kernel
+//      (attention.hip), V^T through ds_read_b64_tr_b16; temporal: every wave owns two 16-token sequences (attn_small_kernel's
+//      arithmetic).  Outputs are written as in the un-fused kernels (row = token, column = head * hd + d).
+// The half values of Q / K / V and every later operation are the same as on the un-fused path (same K order, same rounding
+// points), so the two paths agree bit for bit (tests/test_gpu_kernels.py::test_fused_qkv_attention_*).
+#include "common.h"
+#include "mfma_util.h"
+
+namespace latte {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short i16v4_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr float NEG_BIG_F = -1.0e30f;
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma_k16h(u32x2 a, u32x2 b, f32x4 c) {
+  if constexpr (DT == LATTE_DTYPE_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+}
+// hardware transpose read (see attention.hip): lane i of a 16-lane group supplies the address of 4 d-values of key (i >> 2) of a
+// ROW-MAJOR image and receives the 4 keys of d-column i
+__device__ __forceinline__ u32x2 tr16(const char* p) {
+  i16v4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16v4_t*)p);
+  return __builtin_bit_cast(u32x2, v);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+constexpr int RP = 160;                 // row pitch of the Q / K / V images: conflict-free for the b128 and the transpose reads
+constexpr int IMG = 256 * RP;           // one image
+constexpr int FUSED_LDS = 3 * IMG;      // 122880 B = the two operand stages at hd = 72; the images overlay them
+
+template <int HD, int DT, int MODE>
+__global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
+  constexpr int NQ = 3 * HD;
+  constexpr int NPAD = (NQ + 31) / 32 * 32;      // 224 | 192
+  constexpr int FN = NPAD / 32;                  // 16-column fragments per wave: 7 | 6
+  constexpr int A_BYTES = 256 * 128, STAGE = A_BYTES + NPAD * 128;
+  constexpr int B_MAIN = NPAD / 8 / 4;           // W-tile DMA groups (8 rows) per wave of group 0: 7 | 6
+  constexpr int GPM = HD / 8;                    // DMA groups per q / k / v row block: 9 | 8
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
+  static_assert(2 * STAGE <= FUSED_LDS && HD % 8 == 0, "LDS plan");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+  const int D = a.D, T = a.T, F = a.F;
+  const unsigned row_bytes = (unsigned)D * 2u;
+  const int nk = D / 64;
+
+  // ---- this workgroup's units: the heads of a sequence group stay on ONE XCD (shared xn panel in that L2; the head slices of
+  // an output row share 128-byte lines)
+  const int S = MODE == 0 ? a.B * F : a.B * (T >> 4);
+  const bool xmap = (S & 7) == 0;
+  const int xcd = blockIdx.x & 7;
+  int it = xmap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int it_step = xmap ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int it_end = xmap ? (S >> 3) * a.heads : S * a.heads;
+
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.xn, 0, (unsigned)((size_t)a.B * F * T) * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)(3 * D) * row_bytes, 0x00020000);
+
+  // per-lane DMA offsets: lane = (row lrow of an 8-row group, 16-byte chunk cpos); the LDS image is lane-linear, so the bank
+  // swizzle chunk ^= (tile_row >> 1) & 7 is applied to the SOURCE chunk and mirrored by the fragment reads.  A wave's groups
+  // are gi = base + w4 + 4 j: (tile_row >> 1) & 7 = ((w4 & 1) * 4 + (lrow >> 1)) & 7 for every j.
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const unsigned swz16 = (unsigned)((cpos ^ ((((w4 & 1) << 2) + (lrow >> 1)) & 7)) << 4);
+  const unsigned voff_b = (unsigned)lrow * row_bytes + swz16;
+  const unsigned voff_a = MODE == 0 ? voff_b : (unsigned)lrow * (unsigned)T * row_bytes + swz16;   // temporal: a group's rows are 8 frames
+  const unsigned a_jstep = (MODE == 0 ? 32u : 2u) * row_bytes;
+
+  // fragment read offsets inside a stage (row = 16 f + (lane & 15), chunk = (lane >> 4) + 4 ks, swizzled)
+  const int fr = lane & 15, g = lane >> 4;
+  const int chunkb = (g ^ ((lane >> 1) & 7)) << 4;
+  const int a_off = (grp * 128 + wm * 64 + fr) * 128 + chunkb;
+  const int b_off = A_BYTES + (wn * (NPAD / 2) + fr) * 128 + chunkb;
+
+  for (; it < it_end; it += it_step) {
+    const int head = it % a.heads;
+    const int sg = xmap ? (it / a.heads) * 8 + xcd : it / a.heads;
+    // first global row of the unit and the A-row DMA offsets of this wave (groups grp * 16 + w4 + 4 j)
+    unsigned a_so0;
+    int row_base;           // spatial: first row; temporal: b F T + 16 tq
+    if constexpr (MODE == 0) {
+      row_base = sg * 256;
+      a_so0 = (unsigned)(row_base + (grp * 16 + w4) * 8) * row_bytes;
+    } else {
+      const int tqn = T >> 4;
+      row_base = (sg / tqn) * F * T + (sg % tqn) * 16;
+      // group gi = grp * 16 + w4 + 4 j: p = gi >> 1 = grp * 8 + (w4 >> 1) + 2 j, first frame (w4 & 1) * 8
+      a_so0 = (unsigned)(row_base + (w4 & 1) * 8 * T + grp * 8 + (w4 >> 1)) * row_bytes;
+    }
+    // W-tile DMA offsets of this wave (group 0 only): group gi = w4 + 4 j -> rows of block gi / GPM
+    unsigned b_so[B_MAIN];
+#pragma unroll
+    for (int j = 0; j < B_MAIN; ++j) {
+      const int gi = w4 + 4 * j, mat = gi / GPM, wi = gi - mat * GPM;
+      b_so[j] = (unsigned)(mat < 3 ? mat * D + head * HD + wi * 8 : 3 * D) * row_bytes;   // 3 D: beyond the descriptor -> zeros
+    }
+    auto dma_a_half = [&](int kt, int stg) {
+      char* sA = smem + stg * STAGE + (grp * 16 + w4) * 1024;
+      const unsigned so = a_so0 + (unsigned)kt * 128u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma16(rsA, sA + j * 4096, voff_a, so + (unsigned)j * a_jstep);
+    };
+    auto dma_b_all = [&](int kt, int stg) {
+      char* sB = smem + stg * STAGE + A_BYTES + w4 * 1024;
+#pragma unroll
+      for (int j = 0; j < B_MAIN; ++j) dma16(rsB, sB + j * 4096, voff_b, b_so[j] + (unsigned)kt * 128u);
+    };
+
+    // ================================================================ G: [256 x NPAD] = xn_tile W_h^T
+    f32x4 acc[4][FN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dma_a_half(0, 0);
+    if (grp == 0) dma_b_all(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // K tile 0 has landed for everybody
+    dma_a_half(1, 1);
+    if (grp == 0) dma_b_all(1, 1);
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // stagger the two groups by one segment
+    // Per K tile u (stage u & 1): L(u) fragment reads, barrier, C(u) MFMAs, own DMA of u + 1 confirmed, barrier, then the
+    // DMA of u + 2 into the stage just consumed (group 0 issues after the barrier that ends its C(u): by then group 1 has
+    // finished L(u); group 1 only overwrites its own A rows).  Hand-offs as in gemm_pp_kernel / gemm_pps_kernel.
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sbuf = smem + (kt & 1) * STAGE;
+      u32x4 bf[2][FN], af[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) {
+        dma_a_half(kt + 2, kt & 1);
+        if (grp == 0) dma_b_all(kt + 2, kt & 1);
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // balance group 1's extra barrier: all stage reads are done
+
+    // ================================================================ E: accumulators + bias -> half -> Q | K | V images
+    {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n0 = wn * (NPAD / 2) + j * 16 + g * 4;     // 4 consecutive columns, never straddling a block (hd % 4 == 0)
+        if (n0 < NQ) {
+          const int mat = n0 >= 2 * HD ? 2 : (n0 >= HD ? 1 : 0);
+          const int d = n0 - mat * HD;
+          const float4 b4 = *(const float4*)(a.bias + mat * D + head * HD + d);
+          char* dst = smem + mat * IMG + (grp * 128 + wm * 64 + fr) * RP + d * 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const u32x2 pk = {pack2<DT>(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y), pack2<DT>(acc[i][j][2] + b4.z, acc[i][j][3] + b4.w)};
+            *(u32x2*)(dst + i * 16 * RP) = pk;
+          }
+        }
+      }
+      if constexpr (HD % 32 != 0) {
+        // the QK^T contraction runs over hd padded to 32: the pad chunk of a K row (d hd .. hd + 7) meets zero Q chunks, but must
+        // be finite -- clear it (the chunks after it belong to the next row / image and hold real data)
+        if (threadIdx.x < 256) *(u32x4*)(smem + IMG + threadIdx.x * RP + HD * 2) = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();
+
+    if (a.dbg_qkv != nullptr) {   // test hook: the images as the [rows, 3 D] tensor the un-fused GEMM writes
+      for (int idx = threadIdx.x; idx < 256 * 3 * NCH; idx += 512) {
+        const int r = idx / (3 * NCH), rem = idx - r * (3 * NCH), mat = rem / NCH, ch = rem - mat * NCH;
+        const int grow = MODE == 0 ? row_base + r : row_base + (r & 15) * T + (r >> 4);
+        *(u32x4*)(a.dbg_qkv + (size_t)grow * (3 * D) + mat * D + head * HD + ch * 8) = *(const u32x4*)(smem + mat * IMG + r * RP + ch * 16);
+      }
+    }
+
+    // ================================================================ A: attention on the LDS images
+    const char* q_img = smem;
+    const char* k_img = smem + IMG;
+    const char* v_img = smem + 2 * IMG;
+    if constexpr (MODE == 0) {
+      // every wave: 32 queries (two 16-query MFMA column groups) x 256 keys; attn_full_kernel's pass (attention.hip)
+      constexpr int NKT = 16;
+      const float c = a.scale * 1.4426950408889634f;
+      const int q0 = wave * 32;
+      u32x4 qf[2][KS];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ch = g + 4 * ks;
+          qf[gq][ks] = *(const u32x4*)(q_img + (q0 + gq * 16 + fr) * RP + ch * 16);
+          if (ch >= NCH) qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
+        }
+      const char* kbase = k_img + fr * RP + g * 16;
+      const char* vbase = v_img + (4 * g + (fr >> 2)) * RP + (fr & 3) * 8;
+      f32x4 st[2][NKT];
+      u32x4 kf[4][KS];
+      auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+      };
+      load_k(0, kf[0]);
+      load_k(1, kf[1]);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          st[0][kt] = mfma16<DT>(kf[kt & 3][ks], qf[0][ks], st[0][kt]);
+          st[1][kt] = mfma16<DT>(kf[kt & 3][ks], qf[1][ks], st[1][kt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float inv[2];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        float mx = NEG_BIG_F;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nm = -mx * c;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 c2 = {c, c}, nm2 = {nm, nm};
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 e = __builtin_elementwise_fma((f32x2){st[gq][kt][r], st[gq][kt][r + 1]}, c2, nm2);
+            const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+            st[gq][kt][r] = p.x;
+            st[gq][kt][r + 1] = p.y;
+            ls2 += p;
+          }
+        float ls = ls2.x + ls2.y;
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        inv[gq] = 1.0f / ls;
+      }
+      // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
+      f32x4 o[2][DF];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 vfr[2][DF];
+      auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          const u32x2 lo = tr16(vbase + (32 * ks2) * RP + d * 32);
+          const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RP + d * 32);
+          dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+      };
+      load_v(0, vfr[0]);
+#pragma unroll
+      for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+        if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
+        u32x4 pb[2];
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+          pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
+                           pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
+                           pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          o[0][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[0], o[0][d]);
+          o[1][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[1], o[1][d]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          const int dd = 16 * d + 4 * g;
+          if (dd < HD) {
+            const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
+                              pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
+            *(u32x2*)(orow + dd) = pk;
+          }
+        }
+      }
+    } else {
+      // every wave: two sequences of 16 tokens (tile rows 16 p .. 16 p + 15); attn_small_kernel's arithmetic (attention.hip)
+      const float c = a.scale * 1.4426950408889634f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int p = wave * 2 + s2;
+        u32x4 qf[KS], kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ch = g + 4 * ks;
+          qf[ks] = *(const u32x4*)(q_img + (16 * p + fr) * RP + ch * 16);
+          kf[ks] = *(const u32x4*)(k_img + (16 * p + fr) * RP + ch * 16);
+          if (ch >= NCH) {
+            qf[ks] = (u32x4){0u, 0u, 0u, 0u};
+            kf[ks] = (u32x4){0u, 0u, 0u, 0u};
+          }
+        }
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) st = mfma16<DT>(kf[ks], qf[ks], st);   // S^T[key = 4g + r][q = fr]
+        float mx = NEG_BIG_F;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[r] = st[r] * c;
+          mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+          ls += st[r];
+        }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        const u32x2 pb = {pack2<DT>(st[0], st[1]), pack2<DT>(st[2], st[3])};   // P^T[key = 4g + i][q = fr]
+        const float inv = 1.0f / ls;
+        half_t* orow = a.out + (size_t)(row_base + fr * T + p) * D + head * HD;    // token fr (frame) of sequence p
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          const u32x2 vf = tr16(v_img + (16 * p + 4 * g + (fr >> 2)) * RP + (fr & 3) * 8 + d * 32);
+          f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+          oacc = mfma_k16h<DT>(vf, pb, oacc);                                  // O^T[d = 16 d + 4g + r][q = fr]
+          const int dd = 16 * d + 4 * g;
+          if (dd < HD) {
+            const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
+            *(u32x2*)(orow + dd) = pk;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done with the images: the next unit's DMA may overwrite them
+  }
+}
+
+template <int HD, int DT>
+int launch_mode(const QkvAttnArgs& a, hipStream_t st) {
+  const int S = a.mode == 0 ? a.B * a.F : a.B * (a.T >> 4);
+  const int units = S * a.heads;
+  const int nblk = units >= 256 ? 256 : (units + 7) / 8 * 8;
+  dim3 grid(nblk), block(512);
+  if (a.mode == 0) {
+    auto kern = qkv_attn_kernel<HD, DT, 0>;
+    static std::atomic<uint64_t> done{0};
+    if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, FUSED_LDS, st, a);
+  } else {
+    auto kern = qkv_attn_kernel<HD, DT, 1>;
+    static std::atomic<uint64_t> done{0};
+    if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, FUSED_LDS, st, a);
+  }
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+}  // namespace
+
+bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows) {
+  if (heads * hd != D || (hd != 64 && hd != 72) || D % 64 != 0 || D < 128) return false;
+  if ((uint64_t)rows * D * 2 >= (1ull << 32) || (uint64_t)3 * D * D * 2 >= (1ull << 32)) return false;   // 32-bit buffer offsets
+  if (mode == 0) return T == 256;                 // one frame = one 256-row tile
+  return F == 16 && T % 16 == 0;                  // 16 tokens x 16 frames = one 256-row tile
+}
+
+int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st) {
+  if (!qkv_attention_fusable(a.D, a.heads, a.hd, a.F, a.T, a.mode, (int64_t)a.B * a.F * a.T))
+    return fail(LATTE_ERR_INVALID, "fused qkv + attention: shape not supported (need T == 256 spatial / F == 16 temporal, hd 64 | 72)");
+  if (dtype == LATTE_DTYPE_BF16) return a.hd == 64 ? launch_mode<64, LATTE_DTYPE_BF16>(a, st) : launch_mode<72, LATTE_DTYPE_BF16>(a, st);
+  if (dtype == LATTE_DTYPE_F16) return a.hd == 64 ? launch_mode<64, LATTE_DTYPE_F16>(a, st) : launch_mode<72, LATTE_DTYPE_F16>(a, st);
+  return fail(LATTE_ERR_INVALID, "fused qkv + attention: unknown dtype");
+}
+
+}  // namespace latte

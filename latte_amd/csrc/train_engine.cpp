@@ -463,7 +463,11 @@ int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream) {
   // ---- conditioning tail: d SiLU(c) (summed by the stages) -> c = temb (+ y_emb) -> t_embedder MLP
   if ((rc = launch_silu_bwd(e->dc, e->cvec, e->dtmp, (size_t)B * D, 0, st))) return rc;     // dtmp = dc (gradient of c = temb + y_emb)
   if (c.extras == 2) {
-    if ((rc = launch_embedding_bwd(e->dtmp, y, G_(e, "y_embedder.embedding_table.weight"), B, D, st))) return rc;
+    // the scatter accumulates (a label may repeat inside the batch): clear the slice first, so that forward_backward ASSIGNS this
+    // gradient like every other one (two calls without an optimiser step in between must not double it)
+    float* gy = G_(e, "y_embedder.embedding_table.weight");
+    LATTE_HIP(hipMemsetAsync(gy, 0, (size_t)(c.num_classes + 1) * D * sizeof(float), st));
+    if ((rc = launch_embedding_bwd(e->dtmp, y, gy, B, D, st))) return rc;
   }
   // temb = W2 SiLU(temb_pre) + b2
   if ((rc = launch_rows_sum(e->dtmp, B, D, D, G_(e, "t_embedder.mlp.2.bias"), 0, st))) return rc;

@@ -328,7 +328,7 @@ class Latte(nn.Module):
     def profile_forward(self, x, t, y=None):
         """One eager forward with HIP events around every launch -> {class: (ms, launches)} (bench.py)."""
         names = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial", "attn_temporal", "ln_modulate",
-                 "embed_cond", "patch_embed", "final_layer"]
+                 "embed_cond", "patch_embed", "final_layer", "qkv_attn_spatial", "qkv_attn_temporal"]
         x32, t64, y64 = self._prep(x, t, y)
         B = x32.shape[0]
         eng = self.engine(B)

@@ -77,12 +77,14 @@ def broadcast_tensor(t, src=0):
     return t
 
 
-def broadcast_temb_table(model, diffusion, batch=1, src=0):
+def broadcast_temb_table(model, diffusion, batch=1, src=0, guided=False):
     """Rank `src` computes the timestep-embedding table of `diffusion` on its engine, everyone receives it over
-    RCCL and installs it.  Returns the table (device tensor [num_timesteps, hidden])."""
+    RCCL and installs it.  Returns the table (device tensor [num_timesteps, hidden]).  `guided`: install it on the engine
+    guided calls use (forward_with_cfg / the fused loop with cfg: a separate engine when the operand types differ, latte_amd.Latte
+    docstring) -- the table lands on the engine the sampling loop will actually run."""
     from ._lib import check, load_library, ptr, stream_ptr
     lib = load_library()
-    eng = model.engine(batch)
+    eng = model.engine(batch, guided=guided)
     dev = model.pos_embed.device
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     table = torch.zeros(diffusion.num_timesteps, model.hidden_size, device=dev, dtype=torch.float32)

@@ -122,6 +122,21 @@ class LatteTrainer:
         named = dict(self.model.named_parameters())
         return {k: self.grads[off:off + numel].view(named[k].shape) for k, off, numel in self.layout}
 
+    def model_state_dict(self):
+        """The ``"model"`` entry of train.py's checkpoints (:257-262), built from the flat fp32 master buffer through the layout --
+        not through the module's parameter views: a later ``model.cuda()`` / ``.to()`` / ``.float()`` re-materialises the
+        ``nn.Parameter``s and silently ends the aliasing, after which ``model.state_dict()`` would be stale."""
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        for k, off, numel in self.layout:
+            sd[k] = self.params[off:off + numel].view(sd[k].shape).clone()
+        return sd
+
+    def check_aliasing(self):
+        """True while every trained ``nn.Parameter`` of the module still is a view of the flat master buffer."""
+        named = dict(self.model.named_parameters())
+        base = self.params.data_ptr()
+        return all(named[k].data_ptr() == base + 4 * off for k, off, _ in self.layout)
+
     def ema_state_dict(self):
         """The ``"ema"`` entry of train.py's checkpoints (:257-262): every key of model.state_dict()."""
         sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}

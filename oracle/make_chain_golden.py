@@ -1,0 +1,121 @@
+"""Generate ``tests/golden/chain250.npz``: 250-step sampling chains run by the REAL reference (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage:  python -m oracle.make_chain_golden [--skip-xl]
+
+The benchmarked chain is DDIM on the "250" respacing (sample/sample.py:67 ``create_diffusion("250")`` driving
+gaussian_diffusion.py:604-684, DDPM: :423-515).  Every case here runs the reference's own loop -- its ``Latte`` module
+(models/latte.py, unmodified, timm stand-in) under its ``SpacedDiffusion.{ddim,p}_sample_loop`` -- for all 250 steps and
+stores the sample after every 50th executed step plus the final latents.  The noise the loops draw
+(``th.randn_like(x)`` at gaussian_diffusion.py:413,555) comes from ``torch.manual_seed(noise_seed)``; the k-th draw equals the
+k-th ``torch.randn(x.shape)`` under the same seed (asserted below), which is how the parity test regenerates it.  Weights are
+``oracle.latte_oracle.init_state_dict(cfg, seed)`` (regenerable from the seed, nothing large is stored).  The oracle's
+``sample_loop`` is run beside the reference on the small cases and must agree to 1e-6 (it is bit-identical on the short
+chains of oracle/validate_oracle.py; over 250 steps fp32 non-associativity between the two forward implementations may
+show in the last bits).
+
+Cases (name -> model, latent, conditioning, steps):
+  s2_uncond   Latte-S/2  4 x 8x8    unconditional                  250 (ddim, ddpm)
+  s2_guided   Latte-S/2  4 x 8x8    class-cond, CFG 7.0 (2 rows)    250 (ddim, ddpm)
+  b2_uncond   Latte-B/2  16 x 16x16 unconditional                  250 (ddim, ddpm)
+  b2_guided   Latte-B/2  16 x 16x16 class-cond, CFG 7.0            250 (ddim, ddpm)
+  xl_segment  Latte-XL/2 16 x 32x32 unconditional, B = 2            the first 24 steps of the "250" respacing (ddim)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from oracle import diffusion_oracle as do
+from oracle import latte_oracle as lo
+from oracle.reference_loader import load_reference_diffusion, load_reference_latte
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "chain250.npz")
+
+CFG_SCALE = 7.0
+EVERY = 50
+# name -> (preset, kwargs, weight seed, latent seed, noise seed, batch, guided label rows or None, steps, methods)
+CASES = {
+    "s2_uncond": ("Latte-S/2", dict(input_size=8, num_frames=4, extras=1), 11, 12, 13, 1, None, 250, ("ddim", "ddpm")),
+    "s2_guided": ("Latte-S/2", dict(input_size=8, num_frames=4, num_classes=101, extras=2), 21, 22, 23, 1, [17], 250,
+                  ("ddim", "ddpm")),
+    "b2_uncond": ("Latte-B/2", dict(input_size=16, num_frames=16, extras=1), 31, 32, 33, 1, None, 250, ("ddim", "ddpm")),
+    "b2_guided": ("Latte-B/2", dict(input_size=16, num_frames=16, num_classes=101, extras=2), 41, 42, 43, 1, [5], 250,
+                  ("ddim", "ddpm")),
+    "xl_segment": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 51, 52, 53, 2, None, 24, ("ddim",)),
+}
+
+
+def case_inputs(name):
+    """-> (preset, kw, state_dict, x0 [rows, F, 4, S, S], y or None, steps, methods, noise_seed).  Guided cases: rows = 2 x batch,
+    x0 = cat([z, z]), y = [labels..., null class...] (sample/sample.py:92-99)."""
+    preset, kw, wseed, xseed, nseed, B, labels, steps, methods = CASES[name]
+    cfg = lo.preset_config(preset, **kw)
+    sd = lo.init_state_dict(cfg, seed=wseed)
+    g = torch.Generator("cpu").manual_seed(xseed)
+    z = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
+    if labels is None:
+        return preset, kw, cfg, sd, z, None, steps, methods, nseed
+    y = torch.tensor(list(labels) + [kw["num_classes"]] * B, dtype=torch.int64)
+    return preset, kw, cfg, sd, torch.cat([z, z]), y, steps, methods, nseed
+
+
+def chain_noises(seed, shape, n):
+    """The n noise tensors a reference loop draws after torch.manual_seed(seed) (one th.randn_like(x) per step)."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    return [torch.randn(shape, generator=g) for _ in range(n)]
+
+
+def main():
+    rl, rd = load_reference_latte(), load_reference_diffusion()
+    # the k-th randn_like under the global seed == the k-th generator draw of the same shape (what the test regenerates)
+    torch.manual_seed(99)
+    a = [torch.randn_like(torch.empty(2, 3, 5)) for _ in range(3)]
+    b = chain_noises(99, (2, 3, 5), 3)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    arrays = {}
+    for name in CASES:
+        if name == "xl_segment" and "--skip-xl" in sys.argv:
+            continue
+        preset, kw, cfg, sd, x0, y, steps, methods, nseed = case_inputs(name)
+        model = rl.Latte_models[preset](**kw).eval()
+        model.load_state_dict(sd, strict=True)
+        d = rd.create_diffusion("250")
+        s = do.Schedule("250")
+        for method in methods:
+            t0 = time.time()
+            loop = d.ddim_sample_loop_progressive if method == "ddim" else d.p_sample_loop_progressive
+            if y is None:
+                fn, mk = model.forward, dict(y=None)
+            else:
+                fn, mk = model.forward_with_cfg, dict(y=y, cfg_scale=CFG_SCALE)
+            keep = []
+            torch.manual_seed(nseed)
+            with torch.no_grad():
+                for k, r in enumerate(loop(fn, x0.shape, noise=x0.clone(), clip_denoised=False, model_kwargs=mk, device="cpu")):
+                    if (k + 1) % EVERY == 0 or k + 1 == steps:
+                        keep.append((k, r["sample"].clone()))
+                    if k + 1 == steps:
+                        break
+            arrays[f"{name}::{method}::steps"] = np.asarray([k for k, _ in keep], dtype=np.int64)
+            arrays[f"{name}::{method}::samples"] = torch.stack([v for _, v in keep]).numpy()
+            msg = f"{name} {method}: {steps} reference steps in {time.time() - t0:.1f}s, |x_final| rms {float(keep[-1][1].pow(2).mean().sqrt()):.3f}"
+            if not name.startswith("xl"):   # the oracle beside the reference (pin over the full chain length)
+                nz = chain_noises(nseed, x0.shape, steps)
+                if y is None:
+                    mfn = lambda xx, tt: lo.latte_forward(sd, cfg, xx, tt)
+                else:
+                    mfn = lambda xx, tt: lo.latte_forward_with_cfg(sd, cfg, xx, tt, y, CFG_SCALE)
+                with torch.no_grad():
+                    want = do.sample_loop(s, mfn, x0.clone(), method=method, noises=nz)
+                err = float((want - keep[-1][1]).norm() / keep[-1][1].norm())
+                msg += f"; oracle loop vs reference loop rel-L2 {err:.2e}"
+                assert err < 1e-6, err
+            print(msg, flush=True)
+    np.savez_compressed(OUT, **arrays)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

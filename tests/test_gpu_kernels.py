@@ -225,3 +225,61 @@ def test_gemm_bias_residual_half_epilogue(lib, dev, dt):
     check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(out), M, N, K, 0, M, 5, dt, 1, stream_ptr()))
     torch.cuda.synchronize()
     assert float((out.float() - want).norm() / want.norm()) < OUT_TOL[dt]
+
+
+# (B, F, T, heads, hd): spatial needs T == 256, temporal F == 16; more than 256 units (persistent walk), fewer than 256, a
+# sequence-group count that is not a multiple of 8 (plain unit order), hd 64 (192 columns per head) and 72 (216 -> padded 224)
+FUSED_CASES = [(2, 16, 256, 16, 72), (1, 3, 256, 6, 64), (1, 16, 256, 8, 72), (3, 16, 64, 4, 64), (1, 16, 16, 8, 72)]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", FUSED_CASES)
+@pytest.mark.parametrize("mode", [0, 1], ids=["spatial", "temporal"])
+def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
+    """csrc/qkv_attn.hip (QKV projection + attention in one kernel, q / k / v only in LDS) against the two kernels it replaces:
+    the in-LDS q | k | v must be the qkv GEMM's output bit for bit (same K order, same rounding), the attention output must be the
+    stand-alone attention kernel's bit for bit, and both must match the fp32 torch reference of latte.py:50-70."""
+    B, F, T, H, hd = case
+    if (mode == 0 and T != 256) or (mode == 1 and F != 16):
+        pytest.skip("shape belongs to the other mode")
+    D, rows = H * hd, B * F * T
+    rows_pad = (rows + 255) // 256 * 256
+    g = torch.Generator("cpu").manual_seed(rows + hd + mode)
+    xn = torch.zeros(rows_pad, D, dtype=TD[dt], device=dev)
+    xn[:rows] = torch.randn(rows, D, generator=g).to(dev).to(TD[dt])
+    W = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev).to(TD[dt])
+    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
+    qkv = torch.zeros(rows_pad, 3 * D, dtype=TD[dt], device=dev)
+    check(lib.latte_debug_gemm(ptr(xn), ptr(W), ptr(bias), ptr(qkv), None, rows, 3 * D, D, 0, F * T, 0, dt, 0, stream_ptr()))
+    want = torch.zeros(rows, D, dtype=TD[dt], device=dev)
+    args = (B * F, T, H, hd, F, F * T, T, 1) if mode == 0 else (B * T, F, H, hd, T, F * T, 1, T)
+    check(lib.latte_debug_attention(ptr(qkv), ptr(want), *args, dt, stream_ptr()))
+    out = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
+    dbg = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
+    for rep in range(2):          # second launch: same result with warm LDS / caches (stale-image screen)
+        check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), ptr(dbg), B, F, T, D, H, mode, dt, stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(dbg.view(torch.int16), qkv[:rows].view(torch.int16)), "in-LDS q | k | v != qkv GEMM output"
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16)), "fused attention != stand-alone attention kernel"
+        out.fill_(float("nan"))
+    check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), None, B, F, T, D, H, mode, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    # fp32 reference of latte.py:50-70 on the half q | k | v
+    q5 = (xn[:rows].float() @ W.float().t() + bias).to(TD[dt]).float().view(B, F, T, 3, H, hd)
+    if mode == 0:
+        q, k, v = [q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3)]
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(rows, D)
+    else:
+        q, k, v = [q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3)]
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(rows, D)
+    rel = float((out.float() - ref).norm() / ref.norm())
+    assert rel < (8e-3 if dt == 0 else 1.5e-3), rel
+
+
+def test_fused_qkv_attention_rejects_other_shapes(lib, dev):
+    x = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(384, 128, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros(384, device=dev)
+    o = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 0, 0, stream_ptr()) != 0   # T != 256
+    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 1, 0, stream_ptr()) != 0   # F != 16

@@ -106,6 +106,7 @@ ORACLE_CASES = [
     ("Latte-S/4", dict(input_size=32, num_frames=4, extras=1), 1),
     ("Latte-S/8", dict(input_size=32, num_frames=2, extras=1), 2),
     ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 1),    # headline size
+    ("Latte-S/2", dict(input_size=32, num_frames=16, extras=1), 2),     # 256 tokens x 16 frames at hd = 64: the fused qkv + attention kernel
 ]
 
 
@@ -500,3 +501,32 @@ def test_fused_loop_with_fixed_variance_model():
     with pytest.raises(latte_amd.LatteError, match="learn_sigma"):
         check(load_library().latte_sample_loop(m.engine(2), d2._h, 0, 0.0, 0, 1.0, ptr(xx), None, 2, steps - 1, 0, ptr(nz),
                                                None, None, stream_ptr()))
+
+
+@pytest.mark.parametrize("name", ["Latte-S/2", "Latte-XL/2"])
+def test_fused_qkv_attention_path_is_bit_identical_to_the_unfused(name):
+    """16 frames of 256 tokens: every block's QKV projection + attention core runs as ONE kernel (csrc/qkv_attn.hip, engine option
+    fuse_qkv_attn, default on).  The forward must be bit-identical with the option off (separate qkv GEMM + attention kernels), the
+    launch classes must show which path ran, and partial fusion (spatial only / temporal only) must agree as well."""
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=32, num_frames=16, extras=1)
+    cfg = lo.preset_config(name, **kw)
+    sd = lo.init_state_dict(cfg, seed=8)
+    B = 2
+    m = latte_amd.Latte_models[name](compute_dtype="bf16", max_batch=B, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = torch.randn(B, 16, 4, 32, 32, generator=torch.Generator("cpu").manual_seed(2)).cuda()
+    t = torch.tensor([900, 41]).cuda()
+    outs = {}
+    for opt in (3, 0, 1, 2):
+        m.set_engine_option("fuse_qkv_attn", opt, B)
+        outs[opt] = m(x, t).clone()
+        prof = m.profile_forward(x, t)
+        half = cfg.depth // 2
+        assert prof["qkv_attn_spatial"][1] == (half if opt & 1 else 0) and prof["attn_spatial"][1] == (0 if opt & 1 else half)
+        assert prof["qkv_attn_temporal"][1] == (half if opt & 2 else 0) and prof["attn_temporal"][1] == (0 if opt & 2 else half)
+        assert prof["gemm_qkv"][1] == (0 if opt & 1 else half) + (0 if opt & 2 else half)
+    assert torch.isfinite(outs[3]).all()
+    for opt in (0, 1, 2):
+        assert torch.equal(outs[opt], outs[3]), opt

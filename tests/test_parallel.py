@@ -163,3 +163,38 @@ def test_broadcast_temb_table_rccl_two_gpus(tmp_path):
     port = _free_port()
     mp.spawn(_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))["ok"] for r in range(2))
+
+
+def _run_bench(extra, timeout):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LATTE_BENCH_BACKEND"] = "gloo"      # two ranks on fewer than two GPUs: RCCL wants one device per rank
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + extra, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's N > 1 contract allows both forms) must start two
+    ranks, rendezvous on 127.0.0.1 and report n_gpus = 2; --launch-check stops after the collective (no GPU here)."""
+    res = _run_bench(["--launch-check"], 240)
+    assert res == {"launch_check": True, "n_gpus": 2, "collective_ranks": 2, "collective_backend": "gloo"}
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_full_path_on_the_gpu():
+    """The whole N = 2 code path of bench.py (temb-table broadcast, barriers, max-over-ranks reduction, one JSON line) with
+    both ranks on the lease's GPU over gloo: `--gpus 2` alone starts them.  Numbers are not asserted, the contract fields are."""
+    res = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "1", "--no-side", "--no-vae", "--no-cpu-baseline"], 900)
+    assert res["n_gpus"] == 2 and res["collective_ranks"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["config"]["global_batch"] == 2 and res["scaling"] == "weak" and res["finite"]
+    assert res["value"] > 0 and res["roofline"]["frac"] > 0

@@ -83,7 +83,7 @@ def main():
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     parallel.barrier()                                             # sample_ddp.py:113
-    parallel.broadcast_temb_table(model, diffusion, batch=args.max_batch)   # the one payload collective
+    parallel.broadcast_temb_table(model, diffusion, batch=args.max_batch, guided=using_cfg)   # the one payload collective
 
     num = a.num_samples or int(args.get("num_fvd_samples") or n * world)
     total, iterations, lists = parallel.plan_shards(num, n, rank, world)

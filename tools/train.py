@@ -83,6 +83,21 @@ def main():
     diffusion = latte_amd.create_diffusion(timestep_respacing="")                                # train.py:92
     trainer = latte_amd.LatteTrainer(model, diffusion, max_batch=nb, lr=float(args.learning_rate), clip_max_norm=float(args.clip_max_norm),
                                      start_clip_iter=int(args.start_clip_iter))
+    # Replicas were initialised from the shared seed; from here every rank draws its own timesteps, noise and label-dropout
+    # masks, as the reference does (train.py:62 `seed = args.global_seed + rank`): a global batch covers world * nb independent
+    # draws, not nb draws replicated world times.
+    torch.manual_seed(seed + rank)
+    if args.get("resume_from_checkpoint"):
+        raise SystemExit("resume_from_checkpoint (the reference's accelerate-style state resume, train.py:176-192) is not supported: "
+                         "continue from a checkpoint with `pretrained: <results_dir>/checkpoints/<step>.pt`")
+    first_step = 0
+    if args.get("pretrained"):
+        # train.py:195-196: the step counter continues from the checkpoint's file name (0100000.pt -> 100000), so gradient clipping
+        # (start_clip_iter) and the checkpoint numbering carry on instead of restarting
+        stem = os.path.basename(str(args.pretrained)).split(".")[0]
+        if stem.isdigit():
+            first_step = int(stem)
+            trainer.train_steps = first_step
     data = LatentClips(args.get("data_path"), int(args.num_frames), args.latent_size, rank, world, seed, int(args.get("num_classes") or 0))
     out_dir = a.out or args.results_dir
     max_steps = a.max_steps or int(args.max_train_steps)
@@ -93,7 +108,7 @@ def main():
         print(f"Model Parameters: {sum(p.numel() for p in model.parameters()):,}; world {world}, local batch {nb}")
     parallel.barrier()
     running, t0, log_steps = 0.0, time.time(), 0
-    for step in range(1, max_steps + 1):
+    for step in range(first_step + 1, max_steps + 1):
         x, y = data.batch(step, nb)
         out = trainer.train_step(x.to(device), y=y.to(device) if int(args.extras) == 2 else None)
         running += float(out["loss"].mean())                  # (the reference's loss.item(), train.py:239)
@@ -112,7 +127,7 @@ def main():
         if step % ckpt_every == 0 or step == max_steps:
             if rank == 0:
                 path = os.path.join(out_dir, "checkpoints", f"{step:07d}.pt")
-                torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                torch.save({"model": {k: v.cpu() for k, v in trainer.model_state_dict().items()},
                             "ema": {k: v.cpu() for k, v in trainer.ema_state_dict().items()}}, path)
                 print(f"Saved checkpoint to {path}", flush=True)
             parallel.barrier()
