@@ -88,7 +88,8 @@ void latte_engine_destroy(latte_engine_t* e);
  * CUs runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
  * "fuse_qkv_attn" (bit 0: spatial blocks, bit 1: temporal blocks run the QKV projection and the attention core of
  * latte.py:48-70 as ONE kernel with q / k / v held in LDS -- csrc/qkv_attn.hip -- wherever the shape allows it: 256 tokens per
- * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; both give the same bits),
+ * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; bits 2-3 select schedule
+ * variants of the fused kernel; every setting gives the same bits),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);

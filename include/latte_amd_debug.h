@@ -25,9 +25,11 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
  * out[B F T, D] = attention(xn[B F T, D] W[3D, D]^T + bias[3D]) per (sequence, head), rows in the canonical [B, F, T] order.
  * mode 0: spatial sequences (needs T == 256), mode 1: temporal sequences (needs F == 16, T % 16 == 0); head_dim D / heads
  * must be 64 or 72.  dbg_qkv (may be NULL): half [B F T, 3D] receives the q | k | v values the kernel holds in LDS (what the
- * un-fused qkv GEMM would have written).  xn must not alias out. */
+ * un-fused qkv GEMM would have written).  xn must not alias out.  flags: schedule variants with identical results (bit 0:
+ * the next unit's first operand tile is fetched under the attention phase; bit 1: a wave's two query groups run one after
+ * the other, spatial only). */
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T,
-                              int D, int heads, int mode, int dtype, void* stream);
+                              int D, int heads, int mode, int flags, int dtype, void* stream);
 /* half y = LN(x) * (1 + scale[sample]) + shift[sample]; optional x += temp_embed[frame] first
  * (latte.py:28-29,166,179; :357-358). */
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,

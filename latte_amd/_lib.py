@@ -109,7 +109,7 @@ PROTOTYPES = {
     "latte_debug_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int,
                                       c_void]),
     "latte_debug_qkv_attention": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                          c_void]),
+                                          c_int, c_void]),
     "latte_debug_ln_modulate": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_int,
                                         c_int, c_int, c_void]),
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),

@@ -137,6 +137,8 @@ struct QkvAttnArgs {
   int B, F, T, D, heads, hd;
   int mode;
   float scale;         // hd^-0.5
+  int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
+                       // attention phase, bit 1 = the two query groups of a wave one after the other (spatial)
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);

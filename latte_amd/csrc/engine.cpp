@@ -60,7 +60,8 @@ struct latte_engine {
   int gemm_variant = 0;  // 0 = per-shape choice (gemm_auto_variant)
   int gemm_variant_of[4] = {0, 0, 0, 0};   // per-GEMM override (qkv, proj, fc1, fc2); 0 = gemm_variant
   int fuse_qkv_attn = 3;                   // bit 0: spatial blocks, bit 1: temporal blocks run qkv projection + attention as ONE kernel
-                                           // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair
+                                           // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair;
+                                           // bits 2, 3: QkvAttnArgs::flags (schedule variants, same results)
   int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
@@ -236,6 +237,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       QkvAttnArgs qa{};
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
+      qa.flags = (e->fuse_qkv_attn >> 2) & 3;
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
       attn_out = e->qkv;
@@ -496,7 +498,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     return LATTE_OK;
   }
   if (k == "fuse_qkv_attn") {
-    if (value < 0 || value > 3) return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks (0..3)");
+    if (value < 0 || value > 15)
+      return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..15)");
     e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }

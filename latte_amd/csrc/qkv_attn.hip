@@ -16,14 +16,16 @@
 //   G  [256 x NPAD] = xn_tile[256 x D] W_h^T, NPAD = 3 hd rounded up to 32 (224 at hd = 72): the ping-pong MFMA schedule of
 //      gemm.hip (two groups of 4 waves one barrier apart, operands staged by LDS DMA with the bank swizzle on the source
 //      address, BK = 64, two stages), wave tile 64 x NPAD/2.  The W tile's rows are gathered from the three row blocks
-//      q | k | v of the head (8-row DMA groups never straddle a block: hd % 8 == 0); the pad rows lie beyond the buffer
-//      descriptor and read as zeros.
+//      q | k | v of the head (8-row DMA groups never straddle a block: hd % 8 == 0); the pad rows re-read rows of the q block
+//      and their output columns are dropped.
 //   E  accumulators + bias -> half -> three row-major LDS images Q, K, V [256][160 B] (they overlay the operand stages).
 //   A  spatial: every wave owns 32 queries against all 256 keys -- the register-resident exact softmax of attn_full_kernel
 //      (attention.hip), V^T through ds_read_b64_tr_b16; temporal: every wave owns two 16-token sequences (attn_small_kernel's
 //      arithmetic).  Outputs are written as in the un-fused kernels (row = token, column = head * hd + d).
 // The half values of Q / K / V and every later operation are the same as on the un-fused path (same K order, same rounding
 // points), so the two paths agree bit for bit (tests/test_gpu_kernels.py::test_fused_qkv_attention_*).
+#include <type_traits>
+
 #include "common.h"
 #include "mfma_util.h"
 
@@ -59,8 +61,15 @@ constexpr int RP = 160;                 // row pitch of the Q / K / V images: co
 constexpr int IMG = 256 * RP;           // one image
 constexpr int FUSED_LDS = 3 * IMG;      // 122880 B = the two operand stages at hd = 72; the images overlay them
 
-template <int HD, int DT, int MODE>
+// FLAGS bit 0 (EARLY): the next unit's K tile 0 is DMA'd into stage 0 as soon as every wave is done with the Q and K images
+//   (stage 0 = bytes [0, 61440) lies inside the Q + K images [0, 81920); softmax and PV only touch the V image), so the fill
+//   latency of the next unit's operand pipeline hides under the rest of the attention phase.
+// FLAGS bit 1 (SPLITQ, spatial): a wave takes its two 16-query groups through QK^T -> softmax -> PV one after the other (64
+//   live scores instead of 128): the two waves of a SIMD fall out of phase after the first MFMA segment, so one wave's softmax
+//   VALU work runs under the other's MFMAs (attn_blocks_kernel's order).
+template <int HD, int DT, int MODE, int FLAGS>
 __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
+  constexpr bool EARLY = (FLAGS & 1) != 0, SPLITQ = (FLAGS & 2) != 0;
   constexpr int NQ = 3 * HD;
   constexpr int NPAD = (NQ + 31) / 32 * 32;      // 224 | 192
   constexpr int FN = NPAD / 32;                  // 16-column fragments per wave: 7 | 6
@@ -106,52 +115,80 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   const int a_off = (grp * 128 + wm * 64 + fr) * 128 + chunkb;
   const int b_off = A_BYTES + (wn * (NPAD / 2) + fr) * 128 + chunkb;
 
-  for (; it < it_end; it += it_step) {
-    const int head = it % a.heads;
-    const int sg = xmap ? (it / a.heads) * 8 + xcd : it / a.heads;
-    // first global row of the unit and the A-row DMA offsets of this wave (groups grp * 16 + w4 + 4 j)
-    unsigned a_so0;
-    int row_base;           // spatial: first row; temporal: b F T + 16 tq
+  struct Unit {
+    unsigned a_so0;            // A-row DMA offset of this wave's first group
+    unsigned b_so[B_MAIN];     // W-row DMA offsets of this wave's groups (group 0's waves)
+    int row_base, head;        // spatial: first row; temporal: b F T + 16 tq
+  };
+  auto decode = [&](int it_) -> Unit {
+    Unit u;
+    u.head = it_ % a.heads;
+    const int sg = xmap ? (it_ / a.heads) * 8 + xcd : it_ / a.heads;
     if constexpr (MODE == 0) {
-      row_base = sg * 256;
-      a_so0 = (unsigned)(row_base + (grp * 16 + w4) * 8) * row_bytes;
+      u.row_base = sg * 256;
+      u.a_so0 = (unsigned)(u.row_base + (grp * 16 + w4) * 8) * row_bytes;          // groups grp * 16 + w4 + 4 j
     } else {
       const int tqn = T >> 4;
-      row_base = (sg / tqn) * F * T + (sg % tqn) * 16;
+      u.row_base = (sg / tqn) * F * T + (sg % tqn) * 16;
       // group gi = grp * 16 + w4 + 4 j: p = gi >> 1 = grp * 8 + (w4 >> 1) + 2 j, first frame (w4 & 1) * 8
-      a_so0 = (unsigned)(row_base + (w4 & 1) * 8 * T + grp * 8 + (w4 >> 1)) * row_bytes;
+      u.a_so0 = (unsigned)(u.row_base + (w4 & 1) * 8 * T + grp * 8 + (w4 >> 1)) * row_bytes;
     }
-    // W-tile DMA offsets of this wave (group 0 only): group gi = w4 + 4 j -> rows of block gi / GPM
-    unsigned b_so[B_MAIN];
 #pragma unroll
-    for (int j = 0; j < B_MAIN; ++j) {
+    for (int j = 0; j < B_MAIN; ++j) {   // group gi = w4 + 4 j -> rows of block gi / GPM
       const int gi = w4 + 4 * j, mat = gi / GPM, wi = gi - mat * GPM;
-      b_so[j] = (unsigned)(mat < 3 ? mat * D + head * HD + wi * 8 : 3 * D) * row_bytes;   // 3 D: beyond the descriptor -> zeros
+      // pad groups (columns >= 3 hd, hd = 72 only) re-read rows of the q block: their accumulator columns are never stored, so
+      // any finite-or-not data will do, but the address must be valid (an SGPR offset is not part of the buffer bounds check)
+      u.b_so[j] = (unsigned)((mat < 3 ? mat : 0) * D + u.head * HD + wi * 8) * row_bytes;
     }
-    auto dma_a_half = [&](int kt, int stg) {
-      char* sA = smem + stg * STAGE + (grp * 16 + w4) * 1024;
-      const unsigned so = a_so0 + (unsigned)kt * 128u;
+    return u;
+  };
+  auto dma_a_half = [&](const Unit& u, int kt, int stg) {
+    char* sA = smem + stg * STAGE + (grp * 16 + w4) * 1024;
+    const unsigned so = u.a_so0 + (unsigned)kt * 128u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dma16(rsA, sA + j * 4096, voff_a, so + (unsigned)j * a_jstep);
-    };
-    auto dma_b_all = [&](int kt, int stg) {
-      char* sB = smem + stg * STAGE + A_BYTES + w4 * 1024;
+    for (int j = 0; j < 4; ++j) dma16(rsA, sA + j * 4096, voff_a, so + (unsigned)j * a_jstep);
+  };
+  auto dma_b_all = [&](const Unit& u, int kt, int stg) {
+    char* sB = smem + stg * STAGE + A_BYTES + w4 * 1024;
 #pragma unroll
-      for (int j = 0; j < B_MAIN; ++j) dma16(rsB, sB + j * 4096, voff_b, b_so[j] + (unsigned)kt * 128u);
-    };
+    for (int j = 0; j < B_MAIN; ++j) dma16(rsB, sB + j * 4096, voff_b, u.b_so[j] + (unsigned)kt * 128u);
+  };
+  auto fill_first = [&](const Unit& u) {   // K tile 0 of a unit into stage 0
+    dma_a_half(u, 0, 0);
+    if (grp == 0) dma_b_all(u, 0, 0);
+  };
 
+  if (it >= it_end) return;
+  Unit cur = decode(it);
+  fill_first(cur);
+  for (;;) {
+    const int head = cur.head, row_base = cur.row_base;
+    const int it_next = it + it_step;
+    const bool has_next = it_next < it_end;
+    Unit nxt = cur;
+    if (has_next) nxt = decode(it_next);
+    bool filled_next = false;
+    // the mid-attention hook: every wave has finished its reads of the Q and K images
+    auto early_fill = [&]() {
+      if constexpr (EARLY) {
+        if (has_next) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          fill_first(nxt);
+          filled_next = true;
+        }
+      }
+    };
     // ================================================================ G: [256 x NPAD] = xn_tile W_h^T
     f32x4 acc[4][FN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dma_a_half(0, 0);
-    if (grp == 0) dma_b_all(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // K tile 0 has landed for everybody
-    dma_a_half(1, 1);
-    if (grp == 0) dma_b_all(1, 1);
+    dma_a_half(cur, 1, 1);
+    if (grp == 0) dma_b_all(cur, 1, 1);
     if (grp == 1) __builtin_amdgcn_s_barrier();         // stagger the two groups by one segment
     // Per K tile u (stage u & 1): L(u) fragment reads, barrier, C(u) MFMAs, own DMA of u + 1 confirmed, barrier, then the
     // DMA of u + 2 into the stage just consumed (group 0 issues after the barrier that ends its C(u): by then group 1 has
@@ -179,8 +216,8 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + 2 < nk) {
-        dma_a_half(kt + 2, kt & 1);
-        if (grp == 0) dma_b_all(kt + 2, kt & 1);
+        dma_a_half(cur, kt + 2, kt & 1);
+        if (grp == 0) dma_b_all(cur, kt + 2, kt & 1);
       }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // balance group 1's extra barrier: all stage reads are done
@@ -222,121 +259,133 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     const char* q_img = smem;
     const char* k_img = smem + IMG;
     const char* v_img = smem + 2 * IMG;
+    const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
     if constexpr (MODE == 0) {
-      // every wave: 32 queries (two 16-query MFMA column groups) x 256 keys; attn_full_kernel's pass (attention.hip)
+      // every wave: 32 queries (two 16-query MFMA column groups) x 256 keys; attn_full_kernel's pass (attention.hip) on NG = 2
+      // groups at once, or (SPLITQ) on one group after the other
       constexpr int NKT = 16;
-      const float c = a.scale * 1.4426950408889634f;
       const int q0 = wave * 32;
-      u32x4 qf[2][KS];
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int ch = g + 4 * ks;
-          qf[gq][ks] = *(const u32x4*)(q_img + (q0 + gq * 16 + fr) * RP + ch * 16);
-          if (ch >= NCH) qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
-        }
       const char* kbase = k_img + fr * RP + g * 16;
       const char* vbase = v_img + (4 * g + (fr >> 2)) * RP + (fr & 3) * 8;
-      f32x4 st[2][NKT];
-      u32x4 kf[4][KS];
-      auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
+      auto pass = [&](auto ng_tag, int gq0, bool last) {
+        constexpr int NG = decltype(ng_tag)::value;
+        u32x4 qf[NG][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
-      };
-      load_k(0, kf[0]);
-      load_k(1, kf[1]);
+        for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
-        __builtin_amdgcn_sched_barrier(0);
-        st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          st[0][kt] = mfma16<DT>(kf[kt & 3][ks], qf[0][ks], st[0][kt]);
-          st[1][kt] = mfma16<DT>(kf[kt & 3][ks], qf[1][ks], st[1][kt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float inv[2];
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq) {
-        float mx = NEG_BIG_F;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float nm = -mx * c;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 c2 = {c, c}, nm2 = {nm, nm};
-        f32x2 ls2 = {0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; r += 2) {
-            const f32x2 e = __builtin_elementwise_fma((f32x2){st[gq][kt][r], st[gq][kt][r + 1]}, c2, nm2);
-            const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-            st[gq][kt][r] = p.x;
-            st[gq][kt][r + 1] = p.y;
-            ls2 += p;
+          for (int ks = 0; ks < KS; ++ks) {
+            const int ch = g + 4 * ks;
+            qf[gq][ks] = *(const u32x4*)(q_img + (q0 + (gq0 + gq) * 16 + fr) * RP + ch * 16);
+            if (ch >= NCH) qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
           }
-        float ls = ls2.x + ls2.y;
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
-        inv[gq] = 1.0f / ls;
-      }
-      // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
-      f32x4 o[2][DF];
+        // S^T[key][q] for all 256 keys; K fragments software-pipelined two key tiles ahead through four rotating register sets
+        f32x4 st[NG][NKT];
+        u32x4 kf[4][KS];
+        auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
 #pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
+          for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+        };
+        load_k(0, kf[0]);
+        load_k(1, kf[1]);
 #pragma unroll
-        for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      u32x4 vfr[2][DF];
-      auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < DF; ++d) {
-          const u32x2 lo = tr16(vbase + (32 * ks2) * RP + d * 32);
-          const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RP + d * 32);
-          dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          for (int gq = 0; gq < NG; ++gq) st[gq][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) st[gq][kt] = mfma16<DT>(kf[kt & 3][ks], qf[gq][ks], st[gq][kt]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      };
-      load_v(0, vfr[0]);
+        if (last) early_fill();   // Q and K images are dead for this wave from here on
+        // exact softmax over the key axis: in-lane over 64 values, then the 4 lanes g = 0..3 of a query.
+        // max on the raw scores (c > 0), p = exp2(s * c - max * c): one max, one fma, one exp2, one add per element
+        float inv[NG];
 #pragma unroll
-      for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
-        if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
-        u32x4 pb[2];
+        for (int gq = 0; gq < NG; ++gq) {
+          float mx = NEG_BIG_F;
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
-          pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
-                           pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
-                           pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
-        __builtin_amdgcn_sched_barrier(0);
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int d = 0; d < DF; ++d) {
-          o[0][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[0], o[0][d]);
-          o[1][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[1], o[1][d]);
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float nm = -mx * c;
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 c2 = {c, c}, nm2 = {nm, nm};
+          f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const f32x2 e = __builtin_elementwise_fma((f32x2){st[gq][kt][r], st[gq][kt][r + 1]}, c2, nm2);
+              const f32x2 pp = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+              st[gq][kt][r] = pp.x;
+              st[gq][kt][r + 1] = pp.y;
+              ls2 += pp;
+            }
+          float ls = ls2.x + ls2.y;
+          ls += __shfl_xor(ls, 16, 64);
+          ls += __shfl_xor(ls, 32, 64);
+          inv[gq] = 1.0f / ls;
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
+        f32x4 o[NG][DF];
 #pragma unroll
-      for (int gq = 0; gq < 2; ++gq) {
-        half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD;
+        for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-        for (int d = 0; d < DF; ++d) {
-          const int dd = 16 * d + 4 * g;
-          if (dd < HD) {
-            const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
-                              pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
-            *(u32x2*)(orow + dd) = pk;
+          for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        u32x4 vfr[2][DF];
+        auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+#pragma unroll
+          for (int d = 0; d < DF; ++d) {
+            const u32x2 lo = tr16(vbase + (32 * ks2) * RP + d * 32);
+            const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RP + d * 32);
+            dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+        };
+        load_v(0, vfr[0]);
+#pragma unroll
+        for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+          if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
+          u32x4 pb[NG];
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq)
+            pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
+                             pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
+                             pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int d = 0; d < DF; ++d)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) o[gq][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[gq], o[gq][d]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+          half_t* orow = a.out + (size_t)(row_base + q0 + (gq0 + gq) * 16 + fr) * D + head * HD;
+#pragma unroll
+          for (int d = 0; d < DF; ++d) {
+            const int dd = 16 * d + 4 * g;
+            if (dd < HD) {
+              const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
+                                pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
+              *(u32x2*)(orow + dd) = pk;
+            }
           }
         }
+      };
+      if constexpr (SPLITQ) {
+        pass(std::integral_constant<int, 1>{}, 0, false);
+        pass(std::integral_constant<int, 1>{}, 1, true);
+      } else {
+        pass(std::integral_constant<int, 2>{}, 0, true);
       }
     } else {
       // every wave: two sequences of 16 tokens (tile rows 16 p .. 16 p + 15); attn_small_kernel's arithmetic (attention.hip)
-      const float c = a.scale * 1.4426950408889634f;
+      f32x4 st2[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int p = wave * 2 + s2;
@@ -351,9 +400,15 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
             kf[ks] = (u32x4){0u, 0u, 0u, 0u};
           }
         }
-        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        st2[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) st = mfma16<DT>(kf[ks], qf[ks], st);   // S^T[key = 4g + r][q = fr]
+        for (int ks = 0; ks < KS; ++ks) st2[s2] = mfma16<DT>(kf[ks], qf[ks], st2[s2]);   // S^T[key = 4g + r][q = fr]
+      }
+      early_fill();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int p = wave * 2 + s2;
+        f32x4 st = st2[s2];
         float mx = NEG_BIG_F;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -387,29 +442,38 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave is done with the images: the next unit's DMA may overwrite them
+    __builtin_amdgcn_s_barrier();   // every wave is done with the images: the next unit's DMA may overwrite all of them
+    if (!has_next) break;
+    if (!filled_next) fill_first(nxt);
+    cur = nxt;
+    it = it_next;
   }
+}
+
+template <int HD, int DT, int MODE, int FLAGS>
+int launch_one(const QkvAttnArgs& a, dim3 grid, hipStream_t st) {
+  auto kern = qkv_attn_kernel<HD, DT, MODE, FLAGS>;
+  static std::atomic<uint64_t> done{0};
+  if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
+  hipLaunchKernelGGL(kern, grid, dim3(512), FUSED_LDS, st, a);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
 }
 
 template <int HD, int DT>
 int launch_mode(const QkvAttnArgs& a, hipStream_t st) {
   const int S = a.mode == 0 ? a.B * a.F : a.B * (a.T >> 4);
   const int units = S * a.heads;
-  const int nblk = units >= 256 ? 256 : (units + 7) / 8 * 8;
-  dim3 grid(nblk), block(512);
+  const dim3 grid(units >= 256 ? 256 : (units + 7) / 8 * 8);   // one workgroup per CU, a multiple of the 8 XCDs
   if (a.mode == 0) {
-    auto kern = qkv_attn_kernel<HD, DT, 0>;
-    static std::atomic<uint64_t> done{0};
-    if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, FUSED_LDS, st, a);
-  } else {
-    auto kern = qkv_attn_kernel<HD, DT, 1>;
-    static std::atomic<uint64_t> done{0};
-    if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
-    hipLaunchKernelGGL(kern, grid, block, FUSED_LDS, st, a);
+    switch (a.flags & 3) {
+      case 0: return launch_one<HD, DT, 0, 0>(a, grid, st);
+      case 1: return launch_one<HD, DT, 0, 1>(a, grid, st);
+      case 2: return launch_one<HD, DT, 0, 2>(a, grid, st);
+      default: return launch_one<HD, DT, 0, 3>(a, grid, st);
+    }
   }
-  LATTE_HIP(hipGetLastError());
-  return LATTE_OK;
+  return (a.flags & 1) ? launch_one<HD, DT, 1, 1>(a, grid, st) : launch_one<HD, DT, 1, 0>(a, grid, st);
 }
 
 }  // namespace

@@ -256,13 +256,14 @@ def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
     check(lib.latte_debug_attention(ptr(qkv), ptr(want), *args, dt, stream_ptr()))
     out = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
     dbg = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
-    for rep in range(2):          # second launch: same result with warm LDS / caches (stale-image screen)
-        check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), ptr(dbg), B, F, T, D, H, mode, dt, stream_ptr()))
+    for flags in ((0, 0, 1, 2, 3) if mode == 0 else (0, 0, 1)):   # flags 0 twice: same result with warm LDS / caches (stale-image screen)
+        check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), ptr(dbg), B, F, T, D, H, mode, flags, dt, stream_ptr()))
         torch.cuda.synchronize()
-        assert torch.equal(dbg.view(torch.int16), qkv[:rows].view(torch.int16)), "in-LDS q | k | v != qkv GEMM output"
-        assert torch.equal(out.view(torch.int16), want.view(torch.int16)), "fused attention != stand-alone attention kernel"
+        assert torch.equal(dbg.view(torch.int16), qkv[:rows].view(torch.int16)), f"flags {flags}: in-LDS q | k | v != qkv GEMM output"
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16)), f"flags {flags}: fused attention != stand-alone attention kernel"
         out.fill_(float("nan"))
-    check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), None, B, F, T, D, H, mode, dt, stream_ptr()))
+        dbg.fill_(float("nan"))
+    check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), None, B, F, T, D, H, mode, 0, dt, stream_ptr()))
     torch.cuda.synchronize()
     # fp32 reference of latte.py:50-70 on the half q | k | v
     q5 = (xn[:rows].float() @ W.float().t() + bias).to(TD[dt]).float().view(B, F, T, 3, H, hd)
@@ -281,5 +282,5 @@ def test_fused_qkv_attention_rejects_other_shapes(lib, dev):
     w = torch.zeros(384, 128, dtype=torch.bfloat16, device=dev)
     b = torch.zeros(384, device=dev)
     o = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
-    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 0, 0, stream_ptr()) != 0   # T != 256
-    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 1, 0, stream_ptr()) != 0   # F != 16
+    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 0, 0, 0, stream_ptr()) != 0   # T != 256
+    assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 1, 0, 0, stream_ptr()) != 0   # F != 16

@@ -519,7 +519,7 @@ def test_fused_qkv_attention_path_is_bit_identical_to_the_unfused(name):
     x = torch.randn(B, 16, 4, 32, 32, generator=torch.Generator("cpu").manual_seed(2)).cuda()
     t = torch.tensor([900, 41]).cuda()
     outs = {}
-    for opt in (3, 0, 1, 2):
+    for opt in (3, 0, 1, 2, 3 + 4, 3 + 8, 3 + 12):     # + 4 / + 8: schedule variants of the fused kernel (same bits)
         m.set_engine_option("fuse_qkv_attn", opt, B)
         outs[opt] = m(x, t).clone()
         prof = m.profile_forward(x, t)
@@ -528,5 +528,5 @@ def test_fused_qkv_attention_path_is_bit_identical_to_the_unfused(name):
         assert prof["qkv_attn_temporal"][1] == (half if opt & 2 else 0) and prof["attn_temporal"][1] == (0 if opt & 2 else half)
         assert prof["gemm_qkv"][1] == (0 if opt & 1 else half) + (0 if opt & 2 else half)
     assert torch.isfinite(outs[3]).all()
-    for opt in (0, 1, 2):
+    for opt in (0, 1, 2, 7, 11, 15):
         assert torch.equal(outs[opt], outs[3]), opt
