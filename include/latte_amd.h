@@ -297,6 +297,9 @@ int latte_t2v_num_keys(const latte_t2v_t* e);
 const char* latte_t2v_key(const latte_t2v_t* e, int i);
 int latte_t2v_load_tensor(latte_t2v_t* e, const char* key, const float* data, int64_t numel, int on_device, void* stream);
 int latte_t2v_check_weights(latte_t2v_t* e);
+/* "fuse_qkv_attn": as latte_engine_set_option (the to_q | to_k | to_v projection of attn1 and its attention core as one kernel
+ * wherever the sequences are 256 tokens of a frame / 16 frames of a token; default 3; every setting gives the same bits). */
+int latte_t2v_set_option(latte_t2v_t* e, const char* name, int64_t value);
 /* x:[B,C,F,H,W] fp32 (channels before frames, latte_t2v.py:729), t: int64[B], encoder_hidden_states:[B,n_text,caption_channels]
  * fp32, encoder_attention_mask:[B,n_text] fp32 1 = keep / 0 = padded, or NULL; out:[B,out_channels,F,H,W] fp32.  All device
  * pointers.  enable_temporal_attentions = 0 skips the temporal blocks (latte_t2v.py:867). */

@@ -30,6 +30,10 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
  * the other, spatial only). */
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T,
                               int D, int heads, int mode, int flags, int dtype, void* stream);
+/* The same launch with a phase trace (measurement): trace = int64 [8 waves][4] receives workgroup 0's shader-clock ticks in
+ * {QKV projection loop, LDS image write, attention phase} summed over its units, and its unit count. */
+int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, long long* trace,
+                                    int B, int F, int T, int D, int heads, int mode, int flags, int dtype, void* stream);
 /* half y = LN(x) * (1 + scale[sample]) + shift[sample]; optional x += temp_embed[frame] first
  * (latte.py:28-29,166,179; :357-358). */
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,

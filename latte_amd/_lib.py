@@ -91,6 +91,7 @@ PROTOTYPES = {
     "latte_t2v_key": (c_char, [c_void, c_int]),
     "latte_t2v_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
     "latte_t2v_check_weights": (c_int, [c_void]),
+    "latte_t2v_set_option": (c_int, [c_void, c_char, c_i64]),
     "latte_t2v_forward": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "latte_t2v_set_text": (c_int, [c_void, c_void, c_void, c_int, c_int, c_void]),
     "latte_t2v_guided_ddim_loop": (c_int, [c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_f32, c_int, c_void]),
@@ -110,6 +111,8 @@ PROTOTYPES = {
                                       c_void]),
     "latte_debug_qkv_attention": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_void]),
+    "latte_debug_qkv_attention_trace": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, c_void]),
     "latte_debug_ln_modulate": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_int,
                                         c_int, c_int, c_void]),
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),

@@ -679,19 +679,23 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) st = mfma_k32<DT>(kf[ks], qf[ks], st);  // S^T[key = 4g + r][q = fl]
 
+  // softmax in the exp2 domain, max on the RAW scores (c > 0), p = exp2(fma(s, c, -max c)): every operation is explicit (one
+  // multiply, one fma, no contraction left to the compiler), so the fused kernel of qkv_attn.hip -- which repeats exactly this
+  // sequence on the same half q / k / v -- gives the same bits
   const float c = a.scale * 1.4426950408889634f;
   float mx = NEG_BIG;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    st[r] = (4 * g + r) < a.L ? st[r] * c : NEG_BIG;
+    if ((4 * g + r) >= a.L) st[r] = NEG_BIG;
     mx = fmaxf(mx, st[r]);
   }
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float nm = -mx * c;
   float ls = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    st[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+    st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nm));
     ls += st[r];
   }
   ls += __shfl_xor(ls, 16, 64);

@@ -134,6 +134,8 @@ struct QkvAttnArgs {
   const float* bias;   // [3 D]
   half_t* out;         // [B F T, D]  column = head * hd + d                    (latte.py:70)
   half_t* dbg_qkv;     // test hook: when set, [B F T, 3 D] receives the half q | k | v the kernel holds in LDS
+  long long* dbg_trace;  // measurement hook: int64 [8 waves][4] = shader-clock ticks of workgroup 0 in {projection loop, image
+                         // write, attention} summed over its units, and the unit count
   int B, F, T, D, heads, hd;
   int mode;
   float scale;         // hd^-0.5

@@ -163,9 +163,15 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
 
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T, int D,
                               int heads, int mode, int flags, int dtype, void* stream) {
+  return latte_debug_qkv_attention_trace(xn, w, bias, out, dbg_qkv, nullptr, B, F, T, D, heads, mode, flags, dtype, stream);
+}
+
+int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, long long* trace, int B,
+                                    int F, int T, int D, int heads, int mode, int flags, int dtype, void* stream) {
   if (heads <= 0 || D % heads) return fail(LATTE_ERR_INVALID, "qkv_attention: D must be a multiple of heads");
   QkvAttnArgs a{};
   a.xn = (const half_t*)xn; a.w = (const half_t*)w; a.bias = bias; a.out = (half_t*)out; a.dbg_qkv = (half_t*)dbg_qkv;
+  a.dbg_trace = trace;
   a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = flags;
   a.scale = 1.0f / sqrtf((float)a.hd);
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);

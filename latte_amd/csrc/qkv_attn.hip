@@ -161,6 +161,16 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   if (it >= it_end) return;
   Unit cur = decode(it);
   fill_first(cur);
+  // measurement hook (tools/fused_probe.py --trace): workgroup 0 sums shader-clock ticks per phase over its units
+  const bool trace = a.dbg_trace != nullptr && blockIdx.x == 0;
+  long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
+  if (trace) tprev = (long long)__builtin_readcyclecounter();
+#define LATTE_PHASE(IDX)                                               \
+  if (trace) {                                                         \
+    const long long now_ = (long long)__builtin_readcyclecounter();    \
+    tacc[IDX] += now_ - tprev;                                         \
+    tprev = now_;                                                      \
+  }
   for (;;) {
     const int head = cur.head, row_base = cur.row_base;
     const int it_next = it + it_step;
@@ -221,6 +231,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // balance group 1's extra barrier: all stage reads are done
+    LATTE_PHASE(0)
 
     // ================================================================ E: accumulators + bias -> half -> Q | K | V images
     {
@@ -246,6 +257,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       }
     }
     __syncthreads();
+    LATTE_PHASE(1)
 
     if (a.dbg_qkv != nullptr) {   // test hook: the images as the [rows, 3 D] tensor the un-fused GEMM writes
       for (int idx = threadIdx.x; idx < 256 * 3 * NCH; idx += 512) {
@@ -411,16 +423,14 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         f32x4 st = st2[s2];
         float mx = NEG_BIG_F;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[r] = st[r] * c;
-          mx = fmaxf(mx, st[r]);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nm = -mx * c;
         float ls = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+          st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nm));   // attn_small_kernel's explicit sequence
           ls += st[r];
         }
         ls += __shfl_xor(ls, 16, 64);
@@ -443,10 +453,18 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is done with the images: the next unit's DMA may overwrite all of them
+    LATTE_PHASE(2)
+    tacc[3] += 1;
     if (!has_next) break;
     if (!filled_next) fill_first(nxt);
     cur = nxt;
     it = it_next;
+  }
+#undef LATTE_PHASE
+  if (trace && lane == 0) {
+    long long* o = a.dbg_trace + wave * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = tacc[i];
   }
 }
 

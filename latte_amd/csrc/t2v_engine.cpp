@@ -62,6 +62,8 @@ struct latte_t2v {
   latte_t2v_config_t cfg;
   int max_batch = 0, D = 0, T = 0, G = 0, F = 0, H = 0, P = 0, KPE = 0, Hm = 0, hd = 0, heads = 0, L = 0, Cc = 0, maxk = 0;
   int nblk = 0;            // 2 * num_layers: block 2i = spatial i, 2i + 1 = temporal i
+  int fuse_qkv_attn = 3;   // as latte_engine: bit 0 spatial / bit 1 temporal blocks run to_q|k|v + attention as ONE kernel (qkv_attn.hip)
+                           // where the shape allows it (256 tokens per frame / 16 frames); latte_t2v_set_option("fuse_qkv_attn", ...)
   int64_t rows_pad = 0, trows_pad = 0;
   std::vector<T2VBlock> blocks;
   float *tables = nullptr, *head_table = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
@@ -318,6 +320,16 @@ int latte_t2v_load_tensor(latte_t2v_t* e, const char* key, const float* data, in
   return LATTE_OK;
 }
 
+int latte_t2v_set_option(latte_t2v_t* e, const char* name, int64_t value) {
+  if (!e || !name) return fail(LATTE_ERR_INVALID, "t2v_set_option: null argument");
+  if (std::string(name) == "fuse_qkv_attn") {
+    if (value < 0 || value > 15) return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant");
+    e->fuse_qkv_attn = (int)value;
+    return LATTE_OK;
+  }
+  return fail(LATTE_ERR_INVALID, std::string("t2v_set_option: unknown option '") + name + "'");
+}
+
 int latte_t2v_check_weights(latte_t2v_t* e) {
   if (!e) return fail(LATTE_ERR_INVALID, "t2v_check_weights: null engine");
   for (const auto& s : e->slots)
@@ -387,15 +399,27 @@ static int t2v_core(latte_t2v* e, const float* x, const int64_t* t, bool t_share
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
     g = GemmArgs{};
     g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
-    g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
-    if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, 0, st))) return rc;
-    AttnArgs a{};
-    a.qkv = e->qkv; a.out = e->xn; a.heads = e->heads; a.hd = e->hd; a.D = D;
-    a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
-    if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
-    else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
-    if ((rc = launch_attention(a, dt, st))) return rc;
-    g.A = e->xn; g.W = w.o_w; g.bias = w.o_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
+    const half_t* attn_out = e->xn;
+    const float attn_scale = 1.0f / std::sqrt((float)e->hd);
+    if (((e->fuse_qkv_attn >> (spatial ? 0 : 1)) & 1) && qkv_attention_fusable(D, e->heads, e->hd, F, T, spatial ? 0 : 1, M)) {
+      // to_q | to_k | to_v + the attention core in one kernel, q / k / v only in LDS (Latte-1: the temporal blocks, 16 frames per
+      // token; the 1024-token spatial sequences keep the separate kernels); output to the idle qkv buffer viewed as [rows, D]
+      QkvAttnArgs qa{};
+      qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
+      qa.heads = e->heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = attn_scale; qa.flags = (e->fuse_qkv_attn >> 2) & 3;
+      if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
+      attn_out = e->qkv;
+    } else {
+      g.A = e->xn; g.W = w.qkv_w; g.bias = w.qkv_b; g.out = e->qkv; g.N = 3 * D; g.K = D;
+      if ((rc = launch_gemm(g, EPI_BIAS_H16, dt, 0, st))) return rc;
+      AttnArgs a{};
+      a.qkv = e->qkv; a.out = e->xn; a.heads = e->heads; a.hd = e->hd; a.D = D;
+      a.sample_stride = rps; a.scale = attn_scale;
+      if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
+      else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
+      if ((rc = launch_attention(a, dt, st))) return rc;
+    }
+    g.A = attn_out; g.W = w.o_w; g.bias = w.o_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
     if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, 0, st))) return rc;
     if (spatial) {
       // cross-attention on the UN-normalised stream (PixArt: no norm before attn2, no gate after it)
@@ -405,7 +429,7 @@ static int t2v_core(latte_t2v* e, const float* x, const int64_t* t, bool t_share
       AttnArgs x2{};
       x2.qkv = e->qkv; x2.q_ld = D; x2.kv = e->kv_all + (size_t)(i / 2) * e->trows_pad * 2 * D; x2.kbias = kbias; x2.Lk = Lk;
       x2.out = e->xn;
-      x2.heads = e->heads; x2.hd = e->hd; x2.D = D; x2.sample_stride = rps; x2.scale = a.scale;
+      x2.heads = e->heads; x2.hd = e->hd; x2.D = D; x2.sample_stride = rps; x2.scale = attn_scale;
       x2.num_seq = B * F; x2.L = T; x2.U = F; x2.seq_stride = T; x2.row_stride = 1;
       if ((rc = launch_cross_attention(x2, dt, st))) return rc;
       g.A = e->xn; g.W = w.o2_w; g.bias = w.o2_b; g.out = e->xres; g.gate = e->ones; g.gate_stride = 0; g.N = D; g.K = D;

@@ -129,6 +129,12 @@ class LatteT2V:
             self._synced = True
         return self._h
 
+    def set_engine_option(self, name, value):
+        """latte_t2v_set_option on the live engine (tuning / test hook: e.g. fuse_qkv_attn); an engine must exist."""
+        if self._h is None:
+            raise LatteError("set_engine_option: no engine yet (run a forward or set_text first)")
+        check(load_library().latte_t2v_set_option(self._h, name.encode(), int(value)))
+
     # ------------------------------------------------------------------ forward (latte_t2v.py:677-941)
     def forward(self, hidden_states, timestep=None, encoder_hidden_states=None, added_cond_kwargs=None, class_labels=None,
                 cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None, use_image_num=0,

@@ -91,6 +91,11 @@ def test_t2v_forward_matches_oracle(case):
     m = _model(cfg, sd, "f16", max_batch=B).to("cuda")
     got = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
     assert rel_l2(got, want) < TOL
+    # attn1 of the blocks with 256-token / 16-frame sequences ran as the fused projection + attention kernel (csrc/qkv_attn.hip):
+    # the separate qkv GEMM + attention kernels give the same bits
+    m.set_engine_option("fuse_qkv_attn", 0)
+    assert torch.equal(m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample, got)
+    m.set_engine_option("fuse_qkv_attn", 3)
     # default operand type of LatteT2V = f16, the type the reference runs this transformer in (sample_t2x.py:29)
     md = _model(cfg, sd, None, max_batch=B).to("cuda")
     assert md.compute_dtype == "f16"
