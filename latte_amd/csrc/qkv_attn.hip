@@ -18,7 +18,8 @@
 //      address, BK = 64, two stages), wave tile 64 x NPAD/2.  The W tile's rows are gathered from the three row blocks
 //      q | k | v of the head (8-row DMA groups never straddle a block: hd % 8 == 0); the pad rows re-read rows of the q block
 //      and their output columns are dropped.
-//   E  accumulators + bias -> half -> three row-major LDS images Q, K, V [256][160 B] (they overlay the operand stages).
+//   E  accumulators + bias (staged in LDS one unit ahead) -> half -> three row-major LDS images Q, K, V [256][160 B] (they
+//      overlay the operand stages).
 //   A  spatial: every wave owns 32 queries against all 256 keys -- the register-resident exact softmax of attn_full_kernel
 //      (attention.hip), V^T through ds_read_b64_tr_b16; temporal: every wave owns two 16-token sequences (attn_small_kernel's
 //      arithmetic).  Outputs are written as in the un-fused kernels (row = token, column = head * hd + d).
@@ -57,27 +58,37 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-constexpr int RP = 160;                 // row pitch of the Q / K / V images: conflict-free for the b128 and the transpose reads
-constexpr int IMG = 256 * RP;           // one image
-constexpr int FUSED_LDS = 3 * IMG;      // 122880 B = the two operand stages at hd = 72; the images overlay them
+// Row pitches of the images: Q and K 144 B (9 x 16 B: b128 fragment reads of 16 consecutive rows spread over all banks, and the
+// 8-byte image writes of the 16 rows of an accumulator fragment are 2-way instead of 4-way conflicted), V 160 B (the pitch at which
+// the transpose reads of 8 rows x 32 B tile the 64 banks).  At hd = 72 a Q / K row has no pad: chunk 9 of the padded contraction
+// is the next row's first chunk (real, finite data; it meets a zero Q chunk).
+constexpr int RPQ = 144, RPV = 160;
+constexpr int Q_OFF = 0, K_OFF = 256 * RPQ, V_OFF = 2 * 256 * RPQ, IMG_END = V_OFF + 256 * RPV;   // 0, 36864, 73728, 114688
+// LDS map (bytes).  The images overlay the operand stages; stage 0's W tile sits BEHIND the images, so that all of stage 0 is
+// dead memory as soon as every wave has fetched its Q fragments (the A tile of stage 0 lies inside the Q image):
+//   [0, 36864) Q image        [36864, 73728) K image       [73728, 114688) V image
+//   [0, 32768) A tile stage 0                               [61440, 94208) A tile stage 1   [94208, 122880) W tile stage 1
+//   [122880, 151552) W tile stage 0     [151552, 152704) bias of the head (3 hd floats)
+constexpr int A0_OFF = 0, A1_OFF = 61440, B1_OFF = 94208, B0_OFF = 122880, BIAS_OFF = B0_OFF + 224 * 128;
+constexpr int FUSED_LDS = BIAS_OFF + 288 * 4;
 
-// FLAGS bit 0 (EARLY): the next unit's K tile 0 is DMA'd into stage 0 as soon as every wave is done with the Q and K images
-//   (stage 0 = bytes [0, 61440) lies inside the Q + K images [0, 81920); softmax and PV only touch the V image), so the fill
-//   latency of the next unit's operand pipeline hides under the rest of the attention phase.
-// FLAGS bit 1 (SPLITQ, spatial): a wave takes its two 16-query groups through QK^T -> softmax -> PV one after the other (64
-//   live scores instead of 128): the two waves of a SIMD fall out of phase after the first MFMA segment, so one wave's softmax
-//   VALU work runs under the other's MFMAs (attn_blocks_kernel's order).
+// FLAGS bit 0 (EARLY): the next unit's K tile 0 is DMA'd into stage 0 right after the attention phase has fetched its Q
+//   fragments (one barrier, taken while the waves are still aligned), so the fill latency of the next unit's operand pipeline
+//   hides under the attention phase.
+// FLAGS bit 1 (PRIO): during the attention phase the waves of group 0 (one per SIMD) run at a higher issue priority than their
+//   SIMD partners of group 1: the two fall out of phase (group 1's MFMA segments run under group 0's softmax VALU work and vice
+//   versa) instead of competing for the same pipe in lock step.
 template <int HD, int DT, int MODE, int FLAGS>
 __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
-  constexpr bool EARLY = (FLAGS & 1) != 0, SPLITQ = (FLAGS & 2) != 0;
+  constexpr bool EARLY = (FLAGS & 1) != 0, PRIO = (FLAGS & 2) != 0;
   constexpr int NQ = 3 * HD;
   constexpr int NPAD = (NQ + 31) / 32 * 32;      // 224 | 192
   constexpr int FN = NPAD / 32;                  // 16-column fragments per wave: 7 | 6
-  constexpr int A_BYTES = 256 * 128, STAGE = A_BYTES + NPAD * 128;
   constexpr int B_MAIN = NPAD / 8 / 4;           // W-tile DMA groups (8 rows) per wave of group 0: 7 | 6
   constexpr int GPM = HD / 8;                    // DMA groups per q / k / v row block: 9 | 8
   constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
-  static_assert(2 * STAGE <= FUSED_LDS && HD % 8 == 0, "LDS plan");
+  static_assert(NPAD <= 224 && NQ <= 288 && HD % 8 == 0 && A1_OFF >= 256 * 128 && B1_OFF - A1_OFF == 256 * 128 && B1_OFF + NPAD * 128 <= B0_OFF && IMG_END <= B0_OFF && K_OFF >= 256 * 128,
+                "LDS plan");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -113,7 +124,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   const int fr = lane & 15, g = lane >> 4;
   const int chunkb = (g ^ ((lane >> 1) & 7)) << 4;
   const int a_off = (grp * 128 + wm * 64 + fr) * 128 + chunkb;
-  const int b_off = A_BYTES + (wn * (NPAD / 2) + fr) * 128 + chunkb;
+  const int b_off = (wn * (NPAD / 2) + fr) * 128 + chunkb;
 
   struct Unit {
     unsigned a_so0;            // A-row DMA offset of this wave's first group
@@ -143,24 +154,42 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     return u;
   };
   auto dma_a_half = [&](const Unit& u, int kt, int stg) {
-    char* sA = smem + stg * STAGE + (grp * 16 + w4) * 1024;
+    char* sA = smem + (stg ? A1_OFF : A0_OFF) + (grp * 16 + w4) * 1024;
     const unsigned so = u.a_so0 + (unsigned)kt * 128u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma16(rsA, sA + j * 4096, voff_a, so + (unsigned)j * a_jstep);
   };
   auto dma_b_all = [&](const Unit& u, int kt, int stg) {
-    char* sB = smem + stg * STAGE + A_BYTES + w4 * 1024;
+    char* sB = smem + (stg ? B1_OFF : B0_OFF) + w4 * 1024;
 #pragma unroll
     for (int j = 0; j < B_MAIN; ++j) dma16(rsB, sB + j * 4096, voff_b, u.b_so[j] + (unsigned)kt * 128u);
   };
-  auto fill_first = [&](const Unit& u) {   // K tile 0 of a unit into stage 0
+  // K tile 0 of a unit into stage 0.  Nothing of the ping-pong stagger applies here (the fill is drained by every wave before
+  // the barrier that opens the unit), so the W tile's groups are spread over all 8 waves: gi = wave + 8 j (same swizzle parity
+  // as w4 + 4 j: wave & 1 == w4 & 1)
+  auto fill_first = [&](const Unit& u) {
     dma_a_half(u, 0, 0);
-    if (grp == 0) dma_b_all(u, 0, 0);
+    char* sB = smem + B0_OFF + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gi = wave + 8 * j;
+      if (gi < NPAD / 8) {
+        const int mat = gi / GPM, wi = gi - mat * GPM;
+        dma16(rsB, sB + j * 8192, voff_b, (unsigned)((mat < 3 ? mat : 0) * D + u.head * HD + wi * 8) * row_bytes);
+      }
+    }
   };
+
+  // bias of a head (q | k | v: 3 hd floats) -> LDS, fetched one unit ahead so that the image-write phase never waits for HBM:
+  // thread i < 3 hd / 4 carries floats 4 i .. 4 i + 3 of the NEXT unit's head in a register from the fetch point to the next
+  // unit's first barrier, where the operand DMA is drained anyway
+  const int bias_i = min((int)threadIdx.x, NQ / 4 - 1) * 4, bias_mat = bias_i / HD, bias_d = bias_i - bias_mat * HD;
+  auto fetch_bias = [&](int head_) -> float4 { return *(const float4*)(a.bias + bias_mat * D + head_ * HD + bias_d); };
 
   if (it >= it_end) return;
   Unit cur = decode(it);
   fill_first(cur);
+  float4 bias_reg = fetch_bias(cur.head);
   // measurement hook (tools/fused_probe.py --trace): workgroup 0 sums shader-clock ticks per phase over its units
   const bool trace = a.dbg_trace != nullptr && blockIdx.x == 0;
   long long tacc[4] = {0, 0, 0, 0}, tprev = 0;
@@ -178,13 +207,15 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     Unit nxt = cur;
     if (has_next) nxt = decode(it_next);
     bool filled_next = false;
-    // the mid-attention hook: every wave has finished its reads of the Q and K images
+    // hook of the attention phase, called right after a wave has fetched its Q fragments: once every wave has, stage 0 (A tile
+    // inside the Q image, W tile behind the images) is dead memory and takes the next unit's K tile 0
     auto early_fill = [&]() {
       if constexpr (EARLY) {
         if (has_next) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           fill_first(nxt);
+          bias_reg = fetch_bias(nxt.head);
           filled_next = true;
         }
       }
@@ -196,7 +227,9 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // K tile 0 has landed for everybody
+    if (threadIdx.x < NQ / 4) *(float4*)(smem + BIAS_OFF + threadIdx.x * 16) = bias_reg;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // K tile 0 has landed for everybody; the head's bias is in LDS
     dma_a_half(cur, 1, 1);
     if (grp == 0) dma_b_all(cur, 1, 1);
     if (grp == 1) __builtin_amdgcn_s_barrier();         // stagger the two groups by one segment
@@ -204,14 +237,15 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     // DMA of u + 2 into the stage just consumed (group 0 issues after the barrier that ends its C(u): by then group 1 has
     // finished L(u); group 1 only overwrites its own A rows).  Hand-offs as in gemm_pp_kernel / gemm_pps_kernel.
     for (int kt = 0; kt < nk; ++kt) {
-      const char* sbuf = smem + (kt & 1) * STAGE;
+      const char* sbuf_a = smem + ((kt & 1) ? A1_OFF : A0_OFF);
+      const char* sbuf_b = smem + ((kt & 1) ? B1_OFF : B0_OFF);
       u32x4 bf[2][FN], af[2][4];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf_b + ((b_off + j * 2048) ^ (ks << 6)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+        for (int i = 0; i < 4; ++i) af[ks][i] = *(const u32x4*)(sbuf_a + ((a_off + i * 2048) ^ (ks << 6)));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -241,19 +275,14 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         if (n0 < NQ) {
           const int mat = n0 >= 2 * HD ? 2 : (n0 >= HD ? 1 : 0);
           const int d = n0 - mat * HD;
-          const float4 b4 = *(const float4*)(a.bias + mat * D + head * HD + d);
-          char* dst = smem + mat * IMG + (grp * 128 + wm * 64 + fr) * RP + d * 2;
+          const float4 b4 = *(const float4*)(smem + BIAS_OFF + n0 * 4);     // q | k | v bias of the head, column n0 .. n0 + 3
+          char* dst = smem + (mat == 2 ? V_OFF + (grp * 128 + wm * 64 + fr) * RPV : mat * K_OFF + (grp * 128 + wm * 64 + fr) * RPQ) + d * 2;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const u32x2 pk = {pack2<DT>(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y), pack2<DT>(acc[i][j][2] + b4.z, acc[i][j][3] + b4.w)};
-            *(u32x2*)(dst + i * 16 * RP) = pk;
+            *(u32x2*)(dst + i * 16 * (mat == 2 ? RPV : RPQ)) = pk;
           }
         }
-      }
-      if constexpr (HD % 32 != 0) {
-        // the QK^T contraction runs over hd padded to 32: the pad chunk of a K row (d hd .. hd + 7) meets zero Q chunks, but must
-        // be finite -- clear it (the chunks after it belong to the next row / image and hold real data)
-        if (threadIdx.x < 256) *(u32x4*)(smem + IMG + threadIdx.x * RP + HD * 2) = (u32x4){0u, 0u, 0u, 0u};
       }
     }
     __syncthreads();
@@ -263,39 +292,43 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       for (int idx = threadIdx.x; idx < 256 * 3 * NCH; idx += 512) {
         const int r = idx / (3 * NCH), rem = idx - r * (3 * NCH), mat = rem / NCH, ch = rem - mat * NCH;
         const int grow = MODE == 0 ? row_base + r : row_base + (r & 15) * T + (r >> 4);
-        *(u32x4*)(a.dbg_qkv + (size_t)grow * (3 * D) + mat * D + head * HD + ch * 8) = *(const u32x4*)(smem + mat * IMG + r * RP + ch * 16);
+        *(u32x4*)(a.dbg_qkv + (size_t)grow * (3 * D) + mat * D + head * HD + ch * 8) = *(const u32x4*)(smem + (mat == 2 ? V_OFF + r * RPV : mat * K_OFF + r * RPQ) + ch * 16);
       }
     }
 
     // ================================================================ A: attention on the LDS images
     const char* q_img = smem;
-    const char* k_img = smem + IMG;
-    const char* v_img = smem + 2 * IMG;
+    const char* k_img = smem + K_OFF;
+    const char* v_img = smem + V_OFF;
     const float c = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
+    if constexpr (PRIO) {
+      if (grp == 0) __builtin_amdgcn_s_setprio(2);
+    }
     if constexpr (MODE == 0) {
-      // every wave: 32 queries (two 16-query MFMA column groups) x 256 keys; attn_full_kernel's pass (attention.hip) on NG = 2
-      // groups at once, or (SPLITQ) on one group after the other
+      // every wave: 32 queries (two 16-query MFMA column groups sharing every K / V fragment read) x 256 keys;
+      // attn_full_kernel's pass (attention.hip)
       constexpr int NKT = 16;
       const int q0 = wave * 32;
-      const char* kbase = k_img + fr * RP + g * 16;
-      const char* vbase = v_img + (4 * g + (fr >> 2)) * RP + (fr & 3) * 8;
-      auto pass = [&](auto ng_tag, int gq0, bool last) {
-        constexpr int NG = decltype(ng_tag)::value;
+      const char* kbase = k_img + fr * RPQ + g * 16;
+      const char* vbase = v_img + (4 * g + (fr >> 2)) * RPV + (fr & 3) * 8;
+      constexpr int NG = 2, gq0 = 0;
+      {
         u32x4 qf[NG][KS];
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const int ch = g + 4 * ks;
-            qf[gq][ks] = *(const u32x4*)(q_img + (q0 + (gq0 + gq) * 16 + fr) * RP + ch * 16);
+            qf[gq][ks] = *(const u32x4*)(q_img + (q0 + (gq0 + gq) * 16 + fr) * RPQ + ch * 16);
             if (ch >= NCH) qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
           }
+        early_fill();   // the Q image is dead for this wave from here on
         // S^T[key][q] for all 256 keys; K fragments software-pipelined two key tiles ahead through four rotating register sets
         f32x4 st[NG][NKT];
         u32x4 kf[4][KS];
         auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+          for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RPQ + ks * 64);
         };
         load_k(0, kf[0]);
         load_k(1, kf[1]);
@@ -311,7 +344,6 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
             for (int gq = 0; gq < NG; ++gq) st[gq][kt] = mfma16<DT>(kf[kt & 3][ks], qf[gq][ks], st[gq][kt]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (last) early_fill();   // Q and K images are dead for this wave from here on
         // exact softmax over the key axis: in-lane over 64 values, then the 4 lanes g = 0..3 of a query.
         // max on the raw scores (c > 0), p = exp2(s * c - max * c): one max, one fma, one exp2, one add per element
         float inv[NG];
@@ -353,8 +385,8 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
 #pragma unroll
           for (int d = 0; d < DF; ++d) {
-            const u32x2 lo = tr16(vbase + (32 * ks2) * RP + d * 32);
-            const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RP + d * 32);
+            const u32x2 lo = tr16(vbase + (32 * ks2) * RPV + d * 32);
+            const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RPV + d * 32);
             dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
           }
         };
@@ -388,12 +420,6 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
             }
           }
         }
-      };
-      if constexpr (SPLITQ) {
-        pass(std::integral_constant<int, 1>{}, 0, false);
-        pass(std::integral_constant<int, 1>{}, 1, true);
-      } else {
-        pass(std::integral_constant<int, 2>{}, 0, true);
       }
     } else {
       // every wave: two sequences of 16 tokens (tile rows 16 p .. 16 p + 15); attn_small_kernel's arithmetic (attention.hip)
@@ -405,8 +431,8 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int ch = g + 4 * ks;
-          qf[ks] = *(const u32x4*)(q_img + (16 * p + fr) * RP + ch * 16);
-          kf[ks] = *(const u32x4*)(k_img + (16 * p + fr) * RP + ch * 16);
+          qf[ks] = *(const u32x4*)(q_img + (16 * p + fr) * RPQ + ch * 16);
+          kf[ks] = *(const u32x4*)(k_img + (16 * p + fr) * RPQ + ch * 16);
           if (ch >= NCH) {
             qf[ks] = (u32x4){0u, 0u, 0u, 0u};
             kf[ks] = (u32x4){0u, 0u, 0u, 0u};
@@ -440,7 +466,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         half_t* orow = a.out + (size_t)(row_base + fr * T + p) * D + head * HD;    // token fr (frame) of sequence p
 #pragma unroll
         for (int d = 0; d < DF; ++d) {
-          const u32x2 vf = tr16(v_img + (16 * p + 4 * g + (fr >> 2)) * RP + (fr & 3) * 8 + d * 32);
+          const u32x2 vf = tr16(v_img + (16 * p + 4 * g + (fr >> 2)) * RPV + (fr & 3) * 8 + d * 32);
           f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
           oacc = mfma_k16h<DT>(vf, pb, oacc);                                  // O^T[d = 16 d + 4g + r][q = fr]
           const int dd = 16 * d + 4 * g;
@@ -451,12 +477,16 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         }
       }
     }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave is done with the images: the next unit's DMA may overwrite all of them
     LATTE_PHASE(2)
     tacc[3] += 1;
     if (!has_next) break;
-    if (!filled_next) fill_first(nxt);
+    if (!filled_next) {
+      fill_first(nxt);
+      bias_reg = fetch_bias(nxt.head);
+    }
     cur = nxt;
     it = it_next;
   }

@@ -406,7 +406,7 @@ static int t2v_core(latte_t2v* e, const float* x, const int64_t* t, bool t_share
       // token; the 1024-token spatial sequences keep the separate kernels); output to the idle qkv buffer viewed as [rows, D]
       QkvAttnArgs qa{};
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
-      qa.heads = e->heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = attn_scale; qa.flags = (e->fuse_qkv_attn >> 2) & 3;
+      qa.heads = e->heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = attn_scale; qa.flags = ((e->fuse_qkv_attn >> 2) & 3) ^ 3;
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       attn_out = e->qkv;
     } else {
