@@ -544,8 +544,8 @@ def main():
             elif k == "config5":
                 tb, D5, dep5, M5 = 5, 768, 12, 5 * 16 * 256
                 fwd5 = dep5 * 2.0 * M5 * 12 * D5 * D5 + (dep5 // 2) * (4.0 * tb * 16 * 256 * 256 * D5 + 4.0 * tb * 256 * 16 * 16 * D5)
-                res["config5"] = {"workload": "train.py step, Latte-B/2 16x256x256 synthetic latents, local batch 5, bf16 operands / "
-                                              "fp32 masters: forward + MSE/VB loss + backward + grad all-reduce + clip + AdamW + EMA",
+                res["config5"] = {"workload": "train.py step, Latte-B/2 16x256x256 synthetic latents, local batch 5, f16 operands (loss-scaled backward: the "
+                                              "mantissa of the reference's TF32 matmuls) / fp32 masters: forward + MSE/VB loss + backward + grad all-reduce + clip + AdamW + EMA",
                                   "value": round(world * tb / (v["ms_per_step"] * 1e-3), 3), "unit": "training samples/s",
                                   "ms_per_step": round(v["ms_per_step"], 3), "steps": v["steps"], "global_batch": tb * world,
                                   "algorithmic_tflops_per_gpu": round(3 * fwd5 / (v["ms_per_step"] * 1e-3) / 1e12, 1),

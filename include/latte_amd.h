@@ -241,6 +241,11 @@ int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offs
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream);
 /* clip_grad_norm_ (utils.py:72-117: total 2-norm, g *= min(max_norm / (norm + 1e-6), 1) when clip != 0) + AdamW + update_ema
  * (utils.py:191-200) on the bound buffers; step counts from 1; norm_out: optional device float[2] = {norm, applied coefficient} */
+/* "loss_scale" (a power of two in [1, 2^24]): d loss / d model_output is multiplied by it before the backward and every finished
+ * gradient slice by its inverse, so that the half-precision gradient operands stay inside the operand type's range.  Default: 1 with
+ * bf16 operands, 16384 with f16 operands -- f16's 10 mantissa bits are the precision class of the TF32 matmuls the reference trains
+ * with (train.py:12-14 allow_tf32), bf16 has 7; the reference itself needs no scaling because it keeps fp32 ranges. */
+int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value);
 int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                  float clip_max_norm, int clip, float ema_decay, float* norm_out, void* stream);
 

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "latte_trainer_stage_range": (c_int, [c_void, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "latte_trainer_backward_stage": (c_int, [c_void, c_int, c_void]),
     "latte_trainer_optimizer_step": (c_int, [c_void, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_int, c_f32, c_void, c_void]),
+    "latte_trainer_set_option": (c_int, [c_void, c_char, ctypes.c_double]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),

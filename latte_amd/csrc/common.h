@@ -178,6 +178,7 @@ int launch_adaln_single(const float* tables /* [nblk, 6, D] */, const float* hea
 // out[b, f, c, :] = in[b, c, f, :] (to_bfc = 1) or out[b, c, f, :] = in[b, f, c, :] (to_bfc = 0); hw contiguous floats
 int launch_permute_cf(const float* in, float* out, int B, int C, int F, int hw, int to_bfc, hipStream_t st);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+int launch_scale_f32(float* p, float s, size_t n, hipStream_t st);   // p[i] *= s
 // One guided DDIM step of the text-to-video loop (pipeline_latte.py:747-758 + DDIMScheduler.step, eta = 0) on x [b, C, F, HW]
 // in place: model_out is the denoiser output of the guidance pair in FRAME layout [(2b) F, Cout, HW] ([negative | prompt]):
 // eps = u + s (c - u) on the first C channels (learned sigma dropped), x0 = (x - c1 eps) / c2, x' = c3 x0 + c4 eps.

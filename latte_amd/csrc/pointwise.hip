@@ -913,6 +913,16 @@ int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st) {
   return LATTE_OK;
 }
 
+__global__ void scale_f32_kernel(float* __restrict__ p, float s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] *= s;
+}
+
+int launch_scale_f32(float* p, float s, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, s, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, v, n);
   LATTE_HIP(hipGetLastError());

@@ -121,7 +121,10 @@ int latte_t2v_create(const latte_t2v_config_t* cfg, int max_batch, latte_t2v_t**
   if (c.patch_size <= 0 || c.sample_size % c.patch_size) return fail(LATTE_ERR_INVALID, "t2v_create: sample_size % patch_size != 0");
   if (c.in_channels != 4) return fail(LATTE_ERR_INVALID, "t2v_create: in_channels must be 4");
   if (c.num_layers <= 0 || c.video_length <= 0 || c.max_text_tokens <= 0) return fail(LATTE_ERR_INVALID, "t2v_create: bad sizes");
-  if (c.compute_dtype != LATTE_DTYPE_BF16 && c.compute_dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "t2v_create: bad compute dtype");
+  // f16 operands only: the type the reference runs this transformer in (sample_t2x.py:29 `.to(device, dtype=torch.float16)`).  With
+  // bf16 operands the guidance pair (scale 7.5, pipeline_latte.py:752-754) amplifies the 2^-9 operand roundoff past the 1e-3
+  // parity bar on every stress case (measured < 3e-3), so the type is not offered.
+  if (c.compute_dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "t2v_create: LatteT2V runs with f16 MFMA operands only (LATTE_DTYPE_F16)");
 
   auto* e = new latte_t2v();
   e->cfg = c;

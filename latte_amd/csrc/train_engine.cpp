@@ -38,6 +38,11 @@ struct latte_trainer {
   int max_batch = 0;
   int D = 0, T = 0, F = 0, G = 0, Cin = 0, Cout = 0, H = 0, P = 0, KPE = 0, Hm = 0, hd = 0, nmod = 0, dt = 0;
   int64_t rows_max = 0, rows_pad = 0, ld = 0;
+  // Loss scaling (f16 operands): d loss / d model_output is multiplied by loss_scale before the backward and every finished slice
+  // of the gradient buffer by 1 / loss_scale -- the backward is linear in that seed, the scale is a power of two, so the result is
+  // the unscaled gradient exactly unless something leaves f16's range.  Per-token gradients of this model are 1e-7 ... 1e-4
+  // (Latte-B/2, batch 5): x 2^14 puts them at 1.6e-3 ... 1.6, inside f16's normal range (6e-5 ... 65504).  bf16: 1 (fp32's range).
+  float loss_scale = 1.0f;
   std::vector<ParamInfo> params;
   std::map<std::string, int> index;
   int64_t total = 0;
@@ -129,6 +134,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   e->Cin = c.in_channels; e->Cout = c.learn_sigma ? 2 * c.in_channels : c.in_channels; e->H = c.input_size;
   e->P = c.patch_size * c.patch_size * e->Cout; e->KPE = c.in_channels * c.patch_size * c.patch_size;
   e->Hm = c.mlp_hidden; e->hd = hd; e->dt = c.compute_dtype;
+  e->loss_scale = c.compute_dtype == LATTE_DTYPE_F16 ? 16384.0f : 1.0f;
   e->nmod = c.depth * 6 * e->D + 2 * e->D;
   if ((e->F * e->T) % 64) { delete e; return fail(LATTE_ERR_INVALID, "trainer: frames * tokens per sample must be a multiple of 64"); }
   e->rows_max = (int64_t)max_batch * e->F * e->T;
@@ -350,6 +356,7 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
                                   e->loss_ws_floats - 3 * e->max_batch, terms_out + B, terms_out + 2 * B, terms_out, stream))) return rc;
   if ((rc = launch_loss_grad(tab, s->num_timesteps, s->mean_type, s->var_type, x_start, e->x_t, noise, e->model_out, t, B, F, e->Cin, hw,
                              vb_scale, e->dmodel_out, st))) return rc;
+  if (e->loss_scale != 1.0f && (rc = launch_scale_f32(e->dmodel_out, e->loss_scale, (size_t)B * F * e->Cout * hw, st))) return rc;
 
   LATTE_HIP(hipMemsetAsync(e->dc, 0, sizeof(float) * (size_t)B * D, st));   // d SiLU(c), summed over the adaLN linears by the stages
   e->cur_batch = B;
@@ -394,7 +401,30 @@ int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offs
 
 // Backward of one stage (in order 0, 1, ..., depth + 1 after latte_trainer_begin).  After stage k the gradient slice
 // latte_trainer_stage_range(k) is final: the data-parallel driver starts its all-reduce while the next stages run.
+static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream);
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream) {
+  int rc = backward_stage_impl(e, stage, stream);
+  if (!rc && e->loss_scale != 1.0f) {   // the slice this stage finalised leaves the loss-scaled domain
+    int64_t off = 0, n = 0;
+    if ((rc = latte_trainer_stage_range(e, stage, &off, &n))) return rc;
+    rc = launch_scale_f32(e->Gr + off, 1.0f / e->loss_scale, (size_t)n, (hipStream_t)stream);
+  }
+  return rc;
+}
+
+int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value) {
+  if (!e || !name) return fail(LATTE_ERR_INVALID, "trainer_set_option: null argument");
+  if (std::string(name) == "loss_scale") {
+    int ex = 0;
+    if (!(value >= 1.0) || value > 16777216.0 || std::frexp(value, &ex) != 0.5)
+      return fail(LATTE_ERR_INVALID, "loss_scale must be a power of two in [1, 2^24]");
+    e->loss_scale = (float)value;
+    return LATTE_OK;
+  }
+  return fail(LATTE_ERR_INVALID, std::string("trainer_set_option: unknown option '") + name + "'");
+}
+
+static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
   if (!e || !e->Pm) return fail(LATTE_ERR_STATE, "backward_stage: no step in flight");
   if (stage != e->next_stage || stage > e->cfg.depth + 1) return fail(LATTE_ERR_STATE, "backward_stage: stages run in order after latte_trainer_begin");
   e->next_stage = stage + 1;

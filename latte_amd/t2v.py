@@ -35,7 +35,10 @@ class LatteT2V:
                                       in_channels=in_channels, out_channels=out_channels or in_channels, num_layers=num_layers,
                                       sample_size=sample_size, patch_size=patch_size, cross_attention_dim=cross_attention_dim,
                                       caption_channels=caption_channels, video_length=video_length, norm_type=norm_type)
-        self.compute_dtype, self.max_batch, self.max_text_tokens = compute_dtype, max_batch, max_text_tokens
+        if compute_dtype not in (None, "f16"):
+            raise LatteError("latte_amd.LatteT2V runs with f16 MFMA operands only -- the type the reference runs this transformer in "
+                             "(sample_t2x.py:29); bf16's 2^-9 operand roundoff, amplified by the guidance pair, misses the 1e-3 parity bar")
+        self.compute_dtype, self.max_batch, self.max_text_tokens = "f16", max_batch, max_text_tokens
         self._sd, self._device, self._h, self._key, self._synced = {}, torch.device("cpu"), None, None, False
 
     # ------------------------------------------------------------------ loading (latte_t2v.py from_pretrained_2d)
@@ -72,8 +75,8 @@ class LatteT2V:
                 self._device = torch.device(a)
                 if self._device.type == "cuda" and self._device.index is None:
                     self._device = torch.device("cuda", torch.cuda.current_device())
-            elif a in (torch.float16, torch.bfloat16):
-                self.compute_dtype = "f16" if a == torch.float16 else "bf16"
+            elif a == torch.bfloat16:
+                raise LatteError("latte_amd.LatteT2V runs with f16 MFMA operands only (see the constructor)")
         self._synced = False
         return self
 

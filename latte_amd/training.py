@@ -47,10 +47,17 @@ class LatteTrainer:
     lr, betas, eps, weight_decay: ``torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)`` (train.py:127);
     clip_max_norm / start_clip_iter: train.py:228-231 (the gradient norm is always computed, clipping starts at that step);
     ema_decay: utils.update_ema's default; class_dropout_prob: LabelEmbedder's (latte.py:130), applied here because the engine
-    takes the labels AFTER token_drop."""
+    takes the labels AFTER token_drop.
+    compute_dtype: MFMA operand type of the forward / backward GEMMs and attention products; masters, gradients, AdamW state and
+    EMA are fp32 either way.  "f16" runs the backward loss-scaled (``loss_scale``, a power of two, default 2**14: the per-token
+    gradients of 1e-7 ... 1e-4 would underflow f16 otherwise; scaling and unscaling by a power of two is exact) and has the 10
+    mantissa bits of the TF32 matmuls the reference trains with (train.py:12-14) -- the default: every gradient tensor within
+    3.8e-4 relative L2 of the reference's fp32 gradients (tests/test_training_step.py); "bf16" needs no scaling, has 7 bits
+    (3.2e-3) and is 1.6 % faster."""
 
     def __init__(self, model, diffusion, max_batch, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_max_norm=0.1,
-                 start_clip_iter=20000, ema_decay=0.9999, class_dropout_prob=0.1, compute_dtype="bf16", process_group=None):
+                 start_clip_iter=20000, ema_decay=0.9999, class_dropout_prob=0.1, compute_dtype="f16", process_group=None,
+                 loss_scale=None):
         if not isinstance(model, Latte):
             raise LatteError("LatteTrainer needs a latte_amd.Latte model")
         if not isinstance(diffusion, SpacedDiffusion):
@@ -59,9 +66,8 @@ class LatteTrainer:
             raise LatteError("T2V training are Not supported at this moment!")             # train.py:213-214
         if diffusion.loss_type not in ("mse", "rescaled_mse"):
             raise LatteError("the engine trains the MSE loss types (create_diffusion's default and rescale_learned_sigmas)")
-        if _lib.DTYPES.get(compute_dtype) != 0:
-            raise LatteError("the engine trains with bf16 MFMA operands: the per-token gradients (1e-7 ... 1e-4) underflow f16 "
-                             "without loss scaling (the reference trains in fp32, train.py has no GradScaler)")
+        if compute_dtype not in _lib.DTYPES:
+            raise LatteError(f"compute_dtype must be one of {sorted(_lib.DTYPES)}")
         _lib.require_gpu()
         self.model, self.diffusion = model, diffusion
         self.max_batch = int(max_batch)
@@ -81,6 +87,9 @@ class LatteTrainer:
         with torch.cuda.device(dev):
             check(lib.latte_trainer_create(cfg, self.max_batch, h))
         self._h = h
+        if loss_scale is not None:
+            check(lib.latte_trainer_set_option(h, b"loss_scale", float(loss_scale)))
+        self.compute_dtype = compute_dtype
         n = lib.latte_trainer_num_params(h)
         self.layout = [(lib.latte_trainer_param_key(h, i).decode(), int(lib.latte_trainer_param_offset(h, i)),
                         int(lib.latte_trainer_param_numel(h, i))) for i in range(n)]

@@ -36,7 +36,7 @@ def main():
     torch.set_grad_enabled(False)
     assert torch.cuda.is_available(), "sample_t2x needs an MI355X"
     device = "cuda"
-    cdt = "f16" if args.use_fp16 else "bf16"                       # sample_t2x.py:28 .to(device, dtype=torch.float16)
+    cdt = "f16"                       # sample_t2x.py:29 .to(device, dtype=torch.float16): the only operand type of latte_amd.LatteT2V
     latent = args.image_size[0] // 8
     if args.sample_method != "DDIM":
         raise SystemExit("only the DDIM scheduler has an offline stand-in; pass a diffusers scheduler to LattePipeline otherwise")

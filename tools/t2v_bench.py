@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="f16", choices=["f16"])
     a = ap.parse_args()
     sd = t2v_state_dict(0, num_layers=a.layers)
     m = latte_amd.LatteT2V(num_layers=a.layers, compute_dtype=a.dtype, max_batch=a.batch).load_state_dict(sd).to("cuda")
