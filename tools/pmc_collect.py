@@ -28,6 +28,8 @@ def classify(name):
         return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
     if "gemm_pwr_kernel<2," in n or "gemm_pw_kernel<2," in n:   # 12-wave kernels: <EPI, DT, TAG>
         return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
+    if "qkv_attn_kernel<" in n:   # fused QKV projection + attention: <HD, DT, MODE, FLAGS>
+        return "qkv_attn_temporal" if n.split("qkv_attn_kernel<")[1].split(",")[2] == "1" else "qkv_attn_spatial"
     if "attn_full_kernel" in n:
         return "attn_spatial"
     if "attn_small_kernel" in n:
@@ -43,6 +45,8 @@ ALG = {  # algorithmic bytes per launch: operands read once + outputs written on
     "gemm_fc1": M * D * 2 + HM * D * 2 + M * HM * 2,
     "gemm_fc2": M * HM * 2 + D * HM * 2 + 2 * M * D * 4,
     "attn_spatial": M * 4 * D * 2, "attn_temporal": M * 4 * D * 2, "ln_modulate": M * D * 6,
+    # fused kernel: xn read once, W_qkv once, the attention output written once (q / k / v never reach HBM)
+    "qkv_attn_spatial": M * D * 2 + 3 * D * D * 2 + M * D * 2, "qkv_attn_temporal": M * D * 2 + 3 * D * D * 2 + M * D * 2,
 }
 acc = defaultdict(lambda: defaultdict(list))
 names = {}
