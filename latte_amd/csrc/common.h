@@ -140,7 +140,7 @@ struct QkvAttnArgs {
   int mode;
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
-                       // attention phase, bit 1 = the two query groups of a wave one after the other (spatial)
+                       // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);

@@ -237,7 +237,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       QkvAttnArgs qa{};
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
-      qa.flags = ((e->fuse_qkv_attn >> 2) & 3) ^ 3;   // option bits 2-3 switch the default schedule features OFF (A/B hook)
+      qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-3 switch the default schedule features OFF (A/B hook)
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
       attn_out = e->qkv;
@@ -498,8 +498,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     return LATTE_OK;
   }
   if (k == "fuse_qkv_attn") {
-    if (value < 0 || value > 15)
-      return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..15)");
+    if (value < 0 || value > 31)
+      return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..31)");
     e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }

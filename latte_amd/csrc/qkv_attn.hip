@@ -102,6 +102,10 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   // an output row share 128-byte lines)
   const int S = MODE == 0 ? a.B * F : a.B * (T >> 4);
   const bool xmap = (S & 7) == 0;
+  // a.flags bit 2 (16 heads, even S): an XCD owns FOUR heads and every second sequence group instead of all heads of every
+  // eighth one -- its 32 workgroups then share 4 W slices (2 MB, resident in the 4 MB L2 across rounds) and 8 xn panels per
+  // round instead of 16 W slices (8 MB, re-streamed from the Infinity Cache every round) and 2 panels
+  const bool hmap = (a.flags & 4) != 0 && a.heads == 16 && xmap;
   const int xcd = blockIdx.x & 7;
   int it = xmap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int it_step = xmap ? (int)(gridDim.x >> 3) : (int)gridDim.x;
@@ -133,8 +137,8 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   };
   auto decode = [&](int it_) -> Unit {
     Unit u;
-    u.head = it_ % a.heads;
-    const int sg = xmap ? (it_ / a.heads) * 8 + xcd : it_ / a.heads;
+    u.head = hmap ? ((xcd & 3) << 2) + (it_ & 3) : it_ % a.heads;
+    const int sg = hmap ? ((it_ >> 2) << 1) + (xcd >> 2) : xmap ? (it_ / a.heads) * 8 + xcd : it_ / a.heads;
     if constexpr (MODE == 0) {
       u.row_base = sg * 256;
       u.a_so0 = (unsigned)(u.row_base + (grp * 16 + w4) * 8) * row_bytes;          // groups grp * 16 + w4 + 4 j
@@ -236,6 +240,9 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     // Per K tile u (stage u & 1): L(u) fragment reads, barrier, C(u) MFMAs, own DMA of u + 1 confirmed, barrier, then the
     // DMA of u + 2 into the stage just consumed (group 0 issues after the barrier that ends its C(u): by then group 1 has
     // finished L(u); group 1 only overwrites its own A rows).  Hand-offs as in gemm_pp_kernel / gemm_pps_kernel.
+    // (Measured and removed, round 3: group 1 taking 3 of the 7 W-tile DMA groups at the START of its compute segment, to shorten
+    //  group 0's [fragment reads + 11 DMA issues] segment -- 264 -> 284 us per launch: an LDS-DMA issue in front of a compute
+    //  segment delays that segment's MFMAs by more than it saves the other group.)
     for (int kt = 0; kt < nk; ++kt) {
       const char* sbuf_a = smem + ((kt & 1) ? A1_OFF : A0_OFF);
       const char* sbuf_b = smem + ((kt & 1) ? B1_OFF : B0_OFF);
@@ -521,7 +528,7 @@ int launch_mode(const QkvAttnArgs& a, hipStream_t st) {
       default: return launch_one<HD, DT, 0, 3>(a, grid, st);
     }
   }
-  return (a.flags & 1) ? launch_one<HD, DT, 1, 1>(a, grid, st) : launch_one<HD, DT, 1, 0>(a, grid, st);
+  return (a.flags & 1) ? launch_one<HD, DT, 1, 1>(a, grid, st) : launch_one<HD, DT, 1, 0>(a, grid, st);   // (bit 2 is a runtime flag)
 }
 
 }  // namespace

@@ -326,7 +326,7 @@ int latte_t2v_load_tensor(latte_t2v_t* e, const char* key, const float* data, in
 int latte_t2v_set_option(latte_t2v_t* e, const char* name, int64_t value) {
   if (!e || !name) return fail(LATTE_ERR_INVALID, "t2v_set_option: null argument");
   if (std::string(name) == "fuse_qkv_attn") {
-    if (value < 0 || value > 15) return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant");
+    if (value < 0 || value > 31) return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant");
     e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }
@@ -409,7 +409,7 @@ static int t2v_core(latte_t2v* e, const float* x, const int64_t* t, bool t_share
       // token; the 1024-token spatial sequences keep the separate kernels); output to the idle qkv buffer viewed as [rows, D]
       QkvAttnArgs qa{};
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
-      qa.heads = e->heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = attn_scale; qa.flags = ((e->fuse_qkv_attn >> 2) & 3) ^ 3;
+      qa.heads = e->heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = attn_scale; qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       attn_out = e->qkv;
     } else {

@@ -256,7 +256,7 @@ def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
     check(lib.latte_debug_attention(ptr(qkv), ptr(want), *args, dt, stream_ptr()))
     out = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
     dbg = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
-    for flags in ((0, 0, 1, 2, 3) if mode == 0 else (0, 0, 1)):   # flags 0 twice: same result with warm LDS / caches (stale-image screen)
+    for flags in ((0, 0, 1, 2, 3, 4, 7) if mode == 0 else (0, 0, 1, 4, 5)):   # bit 2: the four-heads-per-XCD unit order   # flags 0 twice: same result with warm LDS / caches (stale-image screen)
         check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), ptr(dbg), B, F, T, D, H, mode, flags, dt, stream_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(dbg.view(torch.int16), qkv[:rows].view(torch.int16)), f"flags {flags}: in-LDS q | k | v != qkv GEMM output"
