@@ -1,0 +1,14 @@
+#!/bin/bash
+# The closing GPU evidence of a round, one command on the GPU box (from the repo root; results under gpurun_out/):
+#   full GPU test suite, smoke, the driver's default bench line, then rocprofv3 kernel stats of the bench command and the PMC
+#   passes (tools/pmc_round.sh <tag>); fold the PMC output into profiles/ afterwards with  python tools/pmc_collect.py <tag>.
+# Usage:  bash tools/gpu_evidence_round.sh [tag]        (e.g. through gpurun: /usr/local/graft/bin/gpurun -- 'bash tools/gpu_evidence_round.sh r3')
+set -u
+TAG=${1:-r3}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/${TAG}_pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
+timeout 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+timeout 900 bash tools/pmc_round.sh $TAG > $O/${TAG}_pmc_round.log 2>&1
