@@ -10,6 +10,7 @@
 // is kept for measurements: slower, see the launcher), 64 rows of m per stage, two stages, register-staged global loads (rows
 // of a tile are 256 B contiguous).  The contraction (M = 20 480 rows at Latte-B/2, batch 5) is split over grid.y;
 // every split ASSIGNS its fp32 partial product to its own slab (fixed-order reduction afterwards: deterministic).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -129,7 +130,169 @@ __global__ void __launch_bounds__(WN * 128) gemm_tn_kernel(TnArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn8_kernel (round 3): the same product on the machinery of the forward GEMMs -- 256 (n) x 256 (k) output tile, 8 waves as two
+// groups (n halves) x 4 waves (64 k columns each, wave tile 128 x 64 = 32 accumulators), 64 rows of the contraction per stage, two
+// stages, the ping-pong schedule of gemm_pp_kernel (gemm.hip), and the tiles staged by LDS DMA instead of through registers (the
+// 128 x 128 kernel above is bound by its ds_write_b128 tile stores: 550 TF/s).  A tile is kept as four half-images [64 m][128
+// columns] (rows of 256 B = the 64 banks exactly): dY columns of group 0 / group 1, X columns 0-127 / 128-255.  The DMA image is
+// lane-linear (one instruction = 4 rows x 256 B), so the swizzle that makes the transpose reads conflict-free lives in the per-lane
+// SOURCE address: 32-byte block b of row m is stored at block b ^ (m & 7) -- the 8 rows x 32 B that a 32-lane service group of a
+// transpose read touches then tile the 64 banks.  For a lane the block swizzle of instruction i differs from instruction 0's by
+// 4 (i & 1): its source offset is voffset0 ^ ((i & 1) << 7) (row pitches are multiples of 256 B: N % 128 == 0, K % 128 == 0).
+// Fragments as above (two ds_read_b64_tr_b16 per 16 x 32 fragment, the same slot permutation for both operands).
+// Group g's waves stage their own dY half (4 instructions per wave and stage), group 0's also the X tile (8): the DMA split and
+// every hand-off are those of gemm_pp_kernel.  Requires M % 64 == 0 (no ragged contraction rows), N % 128 == 0, K % 128 == 0;
+// a half-image beyond N / K is not staged and its outputs are not stored.
+typedef __attribute__((address_space(3))) void lds_void_tn;
+__device__ __forceinline__ void dma16tn(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_tn*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int DT>
+__global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
+  constexpr int HALF = 64 * 256;             // one half-image: 64 rows x 256 B
+  constexpr int STG = 4 * HALF;              // dY half 0 | dY half 1 | X half 0 | X half 1
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wk = wave & 3;
+  const int fl = lane & 15, gq = lane >> 4;
+  const int tiles_k = (g.K + 255) / 256;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int m_begin = blockIdx.y * g.m_chunk;
+  const int m_end = min(g.M, m_begin + g.m_chunk);
+  const int nk = (m_end - m_begin) / 64;
+  float* outp = g.out + (size_t)blockIdx.y * g.N * g.K;
+  // which halves exist (N, K multiples of 128: a tile may own only its first half)
+  const bool y_ok = n0 + grp * 128 < g.N;                       // this group's dY half / output rows
+  const bool x1_ok = k0 + 128 < g.K;                            // X half 1
+  const bool k_ok = k0 + (wk >> 1) * 128 < g.K;                 // this wave's output columns
+
+  const unsigned ldy = (unsigned)g.N * 2u, ldx = (unsigned)g.K * 2u;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)g.dY, 0, (unsigned)g.M * ldy, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (unsigned)g.M * ldx, 0x00020000);
+  // DMA lane map: row (lane >> 4) of a 4-row group, physical 16-byte chunk (lane & 15) = physical 32-byte block (lane & 15) >> 1;
+  // instruction i covers rows 4 i .. 4 i + 3, so (row & 7) = 4 (i & 1) + (lane >> 4): logical block = physical ^ that
+  const unsigned col0 = (unsigned)(((((lane & 15) >> 1) ^ (lane >> 4)) << 5) + ((lane & 1) << 4));
+  const unsigned voy = (unsigned)(lane >> 4) * ldy + col0, vox = (unsigned)(lane >> 4) * ldx + col0;
+  // a wave's instructions of a half-image: i = wk + 4 j (j = 0..3): i & 1 = wk & 1 for every j
+  const unsigned voy_w = voy ^ ((unsigned)(wk & 1) << 7), vox_w = vox ^ ((unsigned)(wk & 1) << 7);
+  auto dma_y = [&](int kt, int stg) {       // own dY half of K tile kt
+    if (!y_ok) return;
+    char* dst = smem + stg * STG + grp * HALF + wk * 1024;
+    const unsigned so = (unsigned)(m_begin + kt * 64 + wk * 4) * ldy + (unsigned)(n0 + grp * 128) * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16tn(rsY, dst + j * 4096, voy_w, so + (unsigned)(16 * j) * ldy);
+  };
+  auto dma_x = [&](int kt, int stg) {       // both X halves of K tile kt (group 0's waves)
+    char* dst = smem + stg * STG + 2 * HALF + wk * 1024;
+    const unsigned so = (unsigned)(m_begin + kt * 64 + wk * 4) * ldx + (unsigned)k0 * 2u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16tn(rsX, dst + j * 4096, vox_w, so + (unsigned)(16 * j) * ldx);
+    if (x1_ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma16tn(rsX, dst + HALF + j * 4096, vox_w, so + 256u + (unsigned)(16 * j) * ldx);
+    }
+  };
+
+  // fragment read addresses: rows 32 ks + 4 gq + (fl >> 2) (+ 16), 8 bytes at column block c, in-block offset (fl & 3) * 8;
+  // (row & 7) = 4 (gq & 1) + (fl >> 2) for every such row -> physical block c ^ that
+  const int sblk = ((gq & 1) << 2) + (fl >> 2);
+  const int lane_base = (4 * gq + (fl >> 2)) * 256 + (fl & 3) * 8 + (sblk << 5);
+  const int yb = grp * HALF, xb = 2 * HALF + (wk >> 1) * HALF, xc0 = (wk & 1) * 4;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_y(0, 0);
+  if (grp == 0) dma_x(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nk > 1) {
+    dma_y(1, 1);
+    if (grp == 0) dma_x(1, 1);
+  }
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger the two groups by one segment
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * STG;
+    u32x4 nf[2][8], kf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const char* pb = sb + xb + ((lane_base ^ ((xc0 + c) << 5)) + ks * 8192);
+        const u32x2 lo = tr16t(pb), hi = tr16t(pb + 4096);
+        kf[ks][c] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const char* pa = sb + yb + ((lane_base ^ (c << 5)) + ks * 8192);
+        const u32x2 lo = tr16t(pa), hi = tr16t(pa + 4096);
+        nf[ks][c] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(kf[ks][j], nf[ks][i], acc[i][j]);   // D[k = 4 gq + r][n = fl]
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      dma_y(kt + 2, kt & 1);
+      if (grp == 0) dma_x(kt + 2, kt & 1);
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+  // lane holds dW[n = n0 + 128 grp + 16 i + fl][k = k0 + 64 wk + 16 j + 4 gq + {0..3}]
+  if (y_ok && k_ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + grp * 128 + i * 16 + fl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + gq * 4;
+        *(float4*)(outp + (size_t)n * g.K + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// The 8-wave LDS-DMA kernel takes a shape when the contraction has no ragged 64-row step and both output extents are whole
+// 128-column half-tiles (every linear of the Latte family); LATTE_TN_KERNEL=4 (measurement hook) forces the 4-wave kernel.
+bool gemm_tn8_ok(int M, int N, int K) {
+  const char* e_ = getenv("LATTE_TN_KERNEL");
+  if (e_ && atoi(e_) == 4) return false;
+  return M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && (uint64_t)M * N * 2 < (1ull << 32) && (uint64_t)M * K * 2 < (1ull << 32);
+}
+// split of the contraction: -> number of splits, *chunk = rows per split (a multiple of 64).  8-wave kernel: one workgroup per
+// CU (128 KB of LDS), so about 256 workgroups; 4-wave kernel: about four workgroups per CU in flight.
+int gemm_tn_plan(int M, int N, int K, int* chunk) {
+  int splits;
+  if (gemm_tn8_ok(M, N, K)) {
+    const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+    splits = std::max(1, std::min(M / 64, 256 / tiles));
+  } else {
+    const int tn = gemm_tn_tile_n();
+    const int tiles = ((N + tn - 1) / tn) * (K / 128);
+    splits = std::max(1, std::min(M / 64, ((tn == 256 ? 512 : 768) + tiles - 1) / tiles));
+  }
+  *chunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+  return (M + *chunk - 1) / *chunk;
+}
 
 // partial: float [splits][N][K] with splits = ceil(M / m_chunk) (m_chunk a multiple of 64); K % 128 == 0, N % 8 == 0
 int gemm_tn_tile_n() {
@@ -140,6 +303,22 @@ int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int
   if (K % 128 || N % 8 || m_chunk % 64 || m_chunk <= 0) return fail(LATTE_ERR_INVALID, "gemm_tn: need K % 128 == 0, N % 8 == 0, m_chunk % 64 == 0");
   TnArgs a{dY, X, partial, M, N, K, m_chunk};
   const int splits = (M + m_chunk - 1) / m_chunk;
+  if (gemm_tn8_ok(M, N, K)) {
+    constexpr int LDS8 = 2 * 4 * 64 * 256;
+    dim3 grid8(((N + 255) / 256) * ((K + 255) / 256), splits), block8(512);
+#define LATTE_TN8_CASE(DT)                                                                          \
+  {                                                                                                 \
+    static std::atomic<uint64_t> done{0};                                                           \
+    if (int rc = ensure_dynamic_lds((const void*)gemm_tn8_kernel<DT>, LDS8, done)) return rc;       \
+    hipLaunchKernelGGL((gemm_tn8_kernel<DT>), grid8, block8, LDS8, st, a);                          \
+  }
+    if (dtype == LATTE_DTYPE_BF16) LATTE_TN8_CASE(LATTE_DTYPE_BF16)
+    else if (dtype == LATTE_DTYPE_F16) LATTE_TN8_CASE(LATTE_DTYPE_F16)
+    else return fail(LATTE_ERR_INVALID, "gemm_tn: unknown dtype");
+#undef LATTE_TN8_CASE
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   // 128 x 128 tile on 4 waves, two workgroups per CU.  Measured against it (training step, Latte-B/2, batch 5, same box): one
   // 256 x 128 / 8-wave workgroup per CU (a quarter fewer ds_write_b128 bytes per MFMA) 28.1 against 26.4 ms, one 128 x 256 /
   // 4-wave workgroup per CU 27.0 against 25.0 ms -- two independent workgroups de-phase (one's barrier bubble and global-load

@@ -102,12 +102,8 @@ int gemm_half(latte_trainer* e, const half_t* A, const half_t* W, const float* b
 // dW[N, K] = dY[M, N]^T X[M, K] on the transposed-operand GEMM (gemm_tn.hip: no transposed copies), the contraction split so
 // that about four workgroups per CU are in flight; the partial products are reduced in a fixed order; result ASSIGNED to dW
 int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st) {
-  int rc;
-  const int tn = gemm_tn_tile_n();
-  const int tiles = ((N + tn - 1) / tn) * (K / 128);
-  int splits = std::max(1, std::min(M / 64, ((tn == 256 ? 512 : 768) + tiles - 1) / tiles));
-  int chunk = ((M + splits - 1) / splits + 63) / 64 * 64;
-  splits = (M + chunk - 1) / chunk;
+  int rc, chunk = 0;
+  const int splits = gemm_tn_plan(M, N, K, &chunk);
   if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
   if ((rc = launch_gemm_tn(dY, X, e->wg_ws, M, N, K, chunk, e->dt, st))) return rc;
   return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
