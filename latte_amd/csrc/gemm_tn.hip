@@ -145,6 +145,16 @@ __global__ void __launch_bounds__(WN * 128) gemm_tn_kernel(TnArgs g) {
 // Group g's waves stage their own dY half (4 instructions per wave and stage), group 0's also the X tile (8): the DMA split and
 // every hand-off are those of gemm_pp_kernel.  Requires M % 64 == 0 (no ragged contraction rows), N % 128 == 0, K % 128 == 0;
 // a half-image beyond N / K is not staged and its outputs are not stored.
+// Transpose read as inline assembly for the DMA-staged kernel: hipcc puts `s_waitcnt vmcnt(0)` in front of the BUILTIN whenever an
+// LDS DMA is in flight (it treats the pending DMA as a store the read may alias), which drained the next tiles' DMA at the top of
+// every K step (5.4 k clocks per step instead of ~3 k).  The asm form is invisible to that bookkeeping; its completion is waited
+// for by the kernel's own `s_waitcnt lgkmcnt(0)` + barrier before the MFMAs (cdna_hip_programming.md section 5.7, form (iii)).
+template <int OFF>
+__device__ __forceinline__ u32x2 tr16_asm(unsigned lds_addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
+  return v;
+}
 typedef __attribute__((address_space(3))) void lds_void_tn;
 __device__ __forceinline__ void dma16tn(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_tn*)lds_wave_base, 16, voff, soff, 0, 0);
@@ -159,13 +169,22 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, wk = wave & 3;
   const int fl = lane & 15, gq = lane >> 4;
+  // Workgroup -> (split, tile).  N and K are a few tiles only, so every panel of a split (dY columns of an n tile, X columns of
+  // a k tile) is read by several tiles: un-mapped, the launch moved 566 MB for the 126 MB of a Latte-B/2 qkv weight gradient and
+  // ran at HBM speed (6.1 TB/s).  Workgroups are dispatched round-robin over the 8 XCDs; give every XCD a contiguous range of
+  // the (split-major) work list, so that the tiles of one split run on ONE XCD and share their panels in its L2.
   const int tiles_k = (g.K + 255) / 256;
-  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int tiles = tiles_k * ((g.N + 255) / 256);
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const int tn = tile / tiles_k, tk = tile % tiles_k;
   const int n0 = tn * 256, k0 = tk * 256;
-  const int m_begin = blockIdx.y * g.m_chunk;
+  const int m_begin = split * g.m_chunk;
   const int m_end = min(g.M, m_begin + g.m_chunk);
   const int nk = (m_end - m_begin) / 64;
-  float* outp = g.out + (size_t)blockIdx.y * g.N * g.K;
+  float* outp = g.out + (size_t)split * g.N * g.K;
   // which halves exist (N, K multiples of 128: a tile may own only its first half)
   const bool y_ok = n0 + grp * 128 < g.N;                       // this group's dY half / output rows
   const bool x1_ok = k0 + 128 < g.K;                            // X half 1
@@ -219,25 +238,26 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
     if (grp == 0) dma_x(1, 1);
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger the two groups by one segment
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + (kt & 1) * STG;
+    const unsigned sb = smem_base + (unsigned)((kt & 1) * STG);
     u32x4 nf[2][8], kf[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int c = 0; c < 4; ++c) {
+      const unsigned pb = sb + (unsigned)(xb + (lane_base ^ ((xc0 + c) << 5)));
+      const u32x2 l0 = tr16_asm<0>(pb), h0 = tr16_asm<4096>(pb), l1 = tr16_asm<8192>(pb), h1 = tr16_asm<12288>(pb);
+      kf[0][c] = (u32x4){l0[0], l0[1], h0[0], h0[1]};
+      kf[1][c] = (u32x4){l1[0], l1[1], h1[0], h1[1]};
+    }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const char* pb = sb + xb + ((lane_base ^ ((xc0 + c) << 5)) + ks * 8192);
-        const u32x2 lo = tr16t(pb), hi = tr16t(pb + 4096);
-        kf[ks][c] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const char* pa = sb + yb + ((lane_base ^ (c << 5)) + ks * 8192);
-        const u32x2 lo = tr16t(pa), hi = tr16t(pa + 4096);
-        nf[ks][c] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-      }
+    for (int c = 0; c < 8; ++c) {
+      const unsigned pa = sb + (unsigned)(yb + (lane_base ^ (c << 5)));
+      const u32x2 l0 = tr16_asm<0>(pa), h0 = tr16_asm<4096>(pa), l1 = tr16_asm<8192>(pa), h1 = tr16_asm<12288>(pa);
+      nf[0][c] = (u32x4){l0[0], l0[1], h0[0], h0[1]};
+      nf[1][c] = (u32x4){l1[0], l1[1], h1[0], h1[1]};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // nothing that consumes the fragments may move above the wait (guide rule 18)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -305,7 +325,7 @@ int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int
   const int splits = (M + m_chunk - 1) / m_chunk;
   if (gemm_tn8_ok(M, N, K)) {
     constexpr int LDS8 = 2 * 4 * 64 * 256;
-    dim3 grid8(((N + 255) / 256) * ((K + 255) / 256), splits), block8(512);
+    dim3 grid8(((N + 255) / 256) * ((K + 255) / 256) * splits), block8(512);   // 1-D: the kernel maps workgroups to (split, tile)
 #define LATTE_TN8_CASE(DT)                                                                          \
   {                                                                                                 \
     static std::atomic<uint64_t> done{0};                                                           \
