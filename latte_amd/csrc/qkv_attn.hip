@@ -54,6 +54,15 @@ __device__ __forceinline__ u32x2 tr16(const char* p) {
   i16v4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16v4_t*)p);
   return __builtin_bit_cast(u32x2, v);
 }
+// The same read as inline assembly: in front of the BUILTIN hipcc waits (s_waitcnt vmcnt) for any LDS DMA in flight, which in the
+// temporal attention phase is the next unit's operand fill issued a few instructions earlier.  Completion: the caller's own
+// s_waitcnt lgkmcnt(0) + sched_barrier (cdna_hip_programming.md section 5.7, form (iii)).
+template <int OFF>
+__device__ __forceinline__ u32x2 tr16_asm(const char* p) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)(const __attribute__((address_space(3))) char*)p), "i"(OFF));
+  return v;
+}
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -471,11 +480,17 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         const u32x2 pb = {pack2<DT>(st[0], st[1]), pack2<DT>(st[2], st[3])};   // P^T[key = 4g + i][q = fr]
         const float inv = 1.0f / ls;
         half_t* orow = a.out + (size_t)(row_base + fr * T + p) * D + head * HD;    // token fr (frame) of sequence p
+        u32x2 vf[5];
+        {
+          const char* vp = v_img + (16 * p + 4 * g + (fr >> 2)) * RPV + (fr & 3) * 8;
+          vf[0] = tr16_asm<0>(vp); vf[1] = tr16_asm<32>(vp); vf[2] = tr16_asm<64>(vp); vf[3] = tr16_asm<96>(vp); vf[4] = tr16_asm<128>(vp);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int d = 0; d < DF; ++d) {
-          const u32x2 vf = tr16(v_img + (16 * p + 4 * g + (fr >> 2)) * RPV + (fr & 3) * 8 + d * 32);
           f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
-          oacc = mfma_k16h<DT>(vf, pb, oacc);                                  // O^T[d = 16 d + 4g + r][q = fr]
+          oacc = mfma_k16h<DT>(vf[d], pb, oacc);                               // O^T[d = 16 d + 4g + r][q = fr]
           const int dd = 16 * d + 4 * g;
           if (dd < HD) {
             const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
