@@ -327,6 +327,26 @@ __global__ void split_reduce_kernel(const float* __restrict__ partial, int split
     out[i] = a;
   }
 }
+// the same sum in the same (slab) order on 16-byte accesses, four slabs in flight per step (n, stride multiples of 4, 16-byte
+// aligned buffers: every weight matrix): the reductions of the weight-gradient partial products are bandwidth-bound streams
+__global__ void __launch_bounds__(256) split_reduce4_kernel(const float4* __restrict__ partial, int splits, size_t stride4, size_t n4,
+                                                            float4* __restrict__ out, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      const float4 p0 = partial[(size_t)s * stride4 + i], p1 = partial[(size_t)(s + 1) * stride4 + i];
+      const float4 p2 = partial[(size_t)(s + 2) * stride4 + i], p3 = partial[(size_t)(s + 3) * stride4 + i];
+      a.x = (((a.x + p0.x) + p1.x) + p2.x) + p3.x; a.y = (((a.y + p0.y) + p1.y) + p2.y) + p3.y;
+      a.z = (((a.z + p0.z) + p1.z) + p2.z) + p3.z; a.w = (((a.w + p0.w) + p1.w) + p2.w) + p3.w;
+    }
+    for (; s < splits; ++s) {
+      const float4 p = partial[(size_t)s * stride4 + i];
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    out[i] = a;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------- weight packing
 // fp32 [N, K] master weight -> half [N, K] and half [K, N] (the operand of the input-gradient GEMM dX = dY W)
@@ -655,6 +675,12 @@ int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* ou
   return LATTE_OK;
 }
 int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st) {
+  if (n % 4 == 0 && stride % 4 == 0 && ((uintptr_t)partial & 15) == 0 && ((uintptr_t)out & 15) == 0 && n >= 4096) {
+    hipLaunchKernelGGL(split_reduce4_kernel, dim3(blocks_for(n / 4, 8192)), dim3(256), 0, st, (const float4*)partial, splits, stride / 4, n / 4,
+                       (float4*)out, accumulate);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, partial, splits, stride, n, out, accumulate);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
