@@ -12,3 +12,5 @@ timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/${TAG}_pytest_g
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
 timeout 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 timeout 900 bash tools/pmc_round.sh $TAG > $O/${TAG}_pmc_round.log 2>&1
+# the N = 2 code path of the bench INCLUDING the side measurements, both ranks on this GPU over gloo (numbers are not reported)
+LATTE_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 4 --warmup 1 --no-vae --no-cpu-baseline > $O/${TAG}_bench_two_ranks_gloo.json 2> $O/${TAG}_bench_two_ranks_gloo.err
