@@ -34,6 +34,11 @@ int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, 
  * {QKV projection loop, LDS image write, attention phase} summed over its units, and its unit count. */
 int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, long long* trace,
                                     int B, int F, int T, int D, int heads, int mode, int flags, int dtype, void* stream);
+/* Weight-gradient product of the training step: dW[N, K] = sum_m dY[m, n] X[m, k] (autograd of nn.Linear, latte.py:43-45) on the
+ * transposed-operand GEMM of csrc/gemm_tn.hip + its fixed-order split reduction; dY half [M, N], X half [M, K], both row-major.
+ * workspace: >= splits * N * K floats (256 * 256 * ceil(N/256) * ceil(K/256) * 256 is always enough). */
+int latte_debug_gemm_tn(const void* dY, const void* X, float* dW, float* workspace, int64_t workspace_floats, int M, int N, int K,
+                        int dtype, void* stream);
 /* half y = LN(x) * (1 + scale[sample]) + shift[sample]; optional x += temp_embed[frame] first
  * (latte.py:28-29,166,179; :357-358). */
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,

@@ -177,6 +177,15 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);
 }
 
+int latte_debug_gemm_tn(const void* dY, const void* X, float* dW, float* workspace, int64_t workspace_floats, int M, int N, int K,
+                        int dtype, void* stream) {
+  int chunk = 0;
+  const int splits = gemm_tn_plan(M, N, K, &chunk);
+  if ((int64_t)splits * N * K > workspace_floats) return fail(LATTE_ERR_INVALID, "gemm_tn: workspace too small");
+  if (int rc = launch_gemm_tn((const half_t*)dY, (const half_t*)X, workspace, M, N, K, chunk, dtype, (hipStream_t)stream)) return rc;
+  return launch_split_reduce(workspace, splits, (size_t)N * K, (size_t)N * K, dW, 0, (hipStream_t)stream);
+}
+
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,
                             int rows_per_sample, const float* temp_embed, int T, int F, int dtype, void* stream) {
   return launch_ln_modulate(x, x, (half_t*)y, shift, scale, mod_stride, M, D, rows_per_sample, temp_embed, T, F, dtype,

@@ -284,3 +284,32 @@ def test_fused_qkv_attention_rejects_other_shapes(lib, dev):
     o = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
     assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 0, 0, 0, stream_ptr()) != 0   # T != 256
     assert lib.latte_debug_qkv_attention(ptr(x), ptr(w), ptr(b), ptr(o), None, 1, 4, 64, 128, 2, 1, 0, 0, stream_ptr()) != 0   # F != 16
+
+
+# (M, N, K): the Latte-B/2 linears at a short contraction, XL width (1152 = 4.5 tiles: half-tile edges in n and k), a contraction
+# that is not a multiple of 64 and an N that is not a multiple of 128 (both fall back to the 4-wave kernel)
+TN_CASES = [(1024, 768, 768), (2048, 2304, 768), (1536, 768, 3072), (1280, 1152, 1152), (640, 3456, 1152), (1000, 768, 768),
+            (1024, 200, 256)]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", TN_CASES)
+def test_weight_gradient_gemm_tn(lib, dev, dt, shape, monkeypatch):
+    """dW = dY^T X (csrc/gemm_tn.hip: the 8-wave LDS-DMA kernel where the shape allows it, else the 4-wave one) against fp32
+    torch on the same half operands, and the two kernels against each other (LATTE_TN_KERNEL=4 forces the 4-wave kernel)."""
+    M, N, K = shape
+    g = torch.Generator("cpu").manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).to(dev).to(TD[dt])
+    X = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
+    ws = torch.empty(64 * 1024 * 1024, device=dev)
+    want = dY.float().t() @ X.float()
+    outs = []
+    for force4 in (False, True):
+        if force4:
+            monkeypatch.setenv("LATTE_TN_KERNEL", "4")
+        dW = torch.full((N, K), float("nan"), device=dev)
+        check(lib.latte_debug_gemm_tn(ptr(dY), ptr(X), ptr(dW), ptr(ws), ws.numel(), M, N, K, dt, stream_ptr()))
+        torch.cuda.synchronize()
+        assert float((dW - want).norm() / want.norm()) < 2e-5, force4       # fp32 accumulation of exact half products
+        outs.append(dW)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * float(want.abs().max())
