@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       const int q0 = wave * 32;
       const char* kbase = k_img + fr * RPQ + g * 16;
       const char* vbase = v_img + (4 * g + (fr >> 2)) * RPV + (fr & 3) * 8;
-      constexpr int NG = 2, gq0 = 0;
+      constexpr int NG = 2;   // query groups of a wave, processed together
       {
         u32x4 qf[NG][KS];
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const int ch = g + 4 * ks;
-            qf[gq][ks] = *(const u32x4*)(q_img + (q0 + (gq0 + gq) * 16 + fr) * RPQ + ch * 16);
+            qf[gq][ks] = *(const u32x4*)(q_img + (q0 + gq * 16 + fr) * RPQ + ch * 16);
             if (ch >= NCH) qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
           }
         early_fill();   // the Q image is dead for this wave from here on
