@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         }
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-          half_t* orow = a.out + (size_t)(row_base + q0 + (gq0 + gq) * 16 + fr) * D + head * HD;
+          half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD;
 #pragma unroll
           for (int d = 0; d < DF; ++d) {
             const int dd = 16 * d + 4 * g;
