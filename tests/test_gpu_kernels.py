@@ -229,7 +229,8 @@ def test_gemm_bias_residual_half_epilogue(lib, dev, dt):
 
 # (B, F, T, heads, hd): spatial needs T == 256, temporal F == 16; more than 256 units (persistent walk), fewer than 256, a
 # sequence-group count that is not a multiple of 8 (plain unit order), hd 64 (192 columns per head) and 72 (216 -> padded 224)
-FUSED_CASES = [(2, 16, 256, 16, 72), (1, 3, 256, 6, 64), (1, 16, 256, 8, 72), (3, 16, 64, 4, 64), (1, 16, 16, 8, 72)]
+FUSED_CASES = [(2, 16, 256, 16, 72), (1, 3, 256, 6, 64), (1, 16, 256, 8, 72), (3, 16, 64, 4, 64), (1, 16, 16, 8, 72),
+               (1, 16, 256, 16, 64)]   # Latte-L width: 16 heads of 64 (the four-heads-per-XCD unit order at hd = 64)
 
 
 @pytest.mark.parametrize("dt", [0, 1])
