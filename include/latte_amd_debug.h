@@ -34,6 +34,13 @@ int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, 
  * {QKV projection loop, LDS image write, attention phase} summed over its units, and its unit count. */
 int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, long long* trace,
                                     int B, int F, int T, int D, int heads, int mode, int flags, int dtype, void* stream);
+/* Backward of the attention core (autograd of latte.py:61-70 on the [rows, 3 D] qkv layout): dqkv [rows, 3 D] from qkv, the
+ * forward output o [rows, D] and its gradient dout [rows, D]; stats: float scratch [num_seq * heads * L * 3].  Sequences are
+ * addressed as in latte_debug_attention.  L <= 16 runs one wave per (sequence, head), larger L the two tile passes
+ * (LATTE_ATTN_BWD_TILES=1 forces the tile passes: test hook). */
+int latte_debug_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, float* stats, int num_seq, int L,
+                              int heads, int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype,
+                              void* stream);
 /* Weight-gradient product of the training step: dW[N, K] = sum_m dY[m, n] X[m, k] (autograd of nn.Linear, latte.py:43-45) on the
  * transposed-operand GEMM of csrc/gemm_tn.hip + its fixed-order split reduction; dY half [M, N], X half [M, K], both row-major.
  * workspace: >= splits * N * K floats (256 * 256 * ceil(N/256) * ceil(K/256) * 256 is always enough). */

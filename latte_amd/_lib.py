@@ -114,6 +114,8 @@ PROTOTYPES = {
                                           c_int, c_void]),
     "latte_debug_qkv_attention_trace": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_void]),
+    "latte_debug_attention_bwd": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64,
+                                          c_int, c_void]),
     "latte_debug_gemm_tn": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_int, c_void]),
     "latte_debug_ln_modulate": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_int,
                                         c_int, c_int, c_void]),

@@ -177,6 +177,12 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);
 }
 
+int latte_debug_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, float* stats, int num_seq, int L, int heads,
+                               int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream) {
+  return launch_attention_bwd((const half_t*)qkv, (const half_t*)o, (const half_t*)dout, (half_t*)dqkv, stats, num_seq, L, heads, hd, U,
+                              sample_stride, seq_stride, row_stride, dtype, (hipStream_t)stream);
+}
+
 int latte_debug_gemm_tn(const void* dY, const void* X, float* dW, float* workspace, int64_t workspace_floats, int M, int N, int K,
                         int dtype, void* stream) {
   int chunk = 0;

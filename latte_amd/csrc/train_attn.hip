@@ -15,6 +15,8 @@
 //   stats[(seq, head, q)] = {m, 1 / l, D}.
 // Pass B (own rows = 16 keys per wave, tiles = 64 queries): S^T and dP^T by the same score products with the roles swapped
 //   (images Q and dO, fragments K and V), P and dS from the per-query statistics of pass A (staged in LDS) -> dV, dK.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace latte {
@@ -68,6 +70,7 @@ struct AttnBwdArgs {
   int num_seq, L, heads, hd, D, U;
   int64_t sample_stride, seq_stride, row_stride;
   float scale;
+  int force_tiles;     // test / measurement hook: 1 = the two tile kernels also for L <= 16
 };
 
 __device__ __forceinline__ int64_t seq_base(const AttnBwdArgs& a, int seq) {
@@ -310,8 +313,160 @@ __global__ void __launch_bounds__(256) attn_bwd_kv_kernel(AttnBwdArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ L <= 16: one wave per (sequence, head)
+// The temporal attention of the training step (16 frames per token; latte.py:355-368) gave the two tile kernels above one
+// quarter-filled 64-row tile per workgroup -- 110 us per pass for 0.4 GFLOP.  Here a wave owns a whole (sequence, head) problem:
+// every score-type product is one MFMA chain on row fragments loaded straight from global memory (both orientations: S^T for dQ,
+// S for dK / dV, so that the softmax statistics -- per query -- are lane-local in the first and fetched by three lane shuffles per
+// query in the second), the three value-type products (dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS) contract over the 16 tokens
+// with the 16 x 16 x 16 MFMA on hardware-transposed reads of wave-private row-major LDS images of K, dO and Q.
+template <int DT>
+__device__ __forceinline__ f32x4b mfma16k(u32x2b a, u32x2b b, f32x4b c) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4b;
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4b;
+  if constexpr (DT == LATTE_DTYPE_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4b, a), __builtin_bit_cast(s16x4b, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4b, a), __builtin_bit_cast(f16x4b, b), c, 0, 0, 0);
+}
+
+template <int HD, int DT>
+__global__ void __launch_bounds__(256) attn_bwd_small_kernel(AttnBwdArgs a) {
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
+  constexpr int IMG = 17 * RPB;                                  // 16 rows + one row of slack (pad d-columns of the last fragment)
+  __shared__ __attribute__((aligned(16))) char lds[4 * 3 * IMG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fl = lane & 15, g = lane >> 4;
+  const int items = a.num_seq * a.heads;
+  int item = blockIdx.x * 4 + wave;
+  const bool active = item < items;
+  item = min(item, items - 1);
+  const int seq = item / a.heads, head = item % a.heads;
+  const int64_t base = seq_base(a, seq);
+  const size_t ld3 = (size_t)3 * a.D;
+  const int tok = min(fl, a.L - 1);
+  const int64_t row = base + (int64_t)tok * a.row_stride;
+  char* const k_img = lds + wave * 3 * IMG;
+  char* const do_img = k_img + IMG;
+  char* const q_img = k_img + 2 * IMG;
+
+  // own-row fragments: lane = (token fl, chunk g + 4 ks); the same chunks go into the row-major images
+  u32x4b qf[KS], kf[KS], vf[KS], dof[KS];
+  const half_t* qrow = a.qkv + (size_t)row * ld3 + head * HD;
+  load_own<HD>(qf, qrow, g);
+  load_own<HD>(kf, qrow + a.D, g);
+  load_own<HD>(vf, qrow + 2 * a.D, g);
+  load_own<HD>(dof, a.dout + (size_t)row * a.D + head * HD, g);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int ch = g + 4 * ks;
+    if (ch < NCH) {
+      *(u32x4b*)(k_img + fl * RPB + ch * 16) = kf[ks];
+      *(u32x4b*)(do_img + fl * RPB + ch * 16) = dof[ks];
+      *(u32x4b*)(q_img + fl * RPB + ch * 16) = qf[ks];
+    }
+  }
+  // D_q = dO[q] . O[q] for q = fl (this lane's chunks, then the 4 lanes of the token)
+  float dsum = 0.f;
+  {
+    const half_t* orow = a.o + (size_t)row * a.D + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = g + 4 * ks;
+      if (ch < NCH) {
+        const u32x4b ov = *(const u32x4b*)(orow + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dsum += hf<DT>((unsigned short)(ov[e] & 0xffffu)) * hf<DT>((unsigned short)(dof[ks][e] & 0xffffu));
+          dsum += hf<DT>((unsigned short)(ov[e] >> 16)) * hf<DT>((unsigned short)(dof[ks][e] >> 16));
+        }
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+  }
+  const float c = a.scale * 1.4426950408889634f;
+  // ---- orientation 1: S^T[key = 4 g + r][q = fl], dP^T likewise -> statistics of query fl, dS^T -> dQ
+  f32x4b st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    st = mfma32<DT>(kf[ks], qf[ks], st);
+    dpt = mfma32<DT>(vf[ks], dof[ks], dpt);
+  }
+  float mx = NEG_BIG_B;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (4 * g + r >= a.L) st[r] = NEG_BIG_B;
+    mx = fmaxf(mx, st[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float nm = -mx * c;
+  float ls = 0.f;
+  float pt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pt[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nm));   // masked keys: exp2(-huge) = 0
+    ls += pt[r];
+  }
+  ls += __shfl_xor(ls, 16, 64);
+  ls += __shfl_xor(ls, 32, 64);
+  const float inv_l = 1.0f / ls;
+  f32x4b dst;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[r] = pt[r] * inv_l * (dpt[r] - dsum) * a.scale;       // dS^T[key][q]
+  __syncthreads();   // the images of this wave are complete (block-wide barrier keeps it simple)
+  const u32x2b dsb = {pk2<DT>(dst[0], dst[1]), pk2<DT>(dst[2], dst[3])};                  // 4 keys x query fl
+  const int tro = (4 * g + (fl >> 2)) * RPB + (fl & 3) * 8;                                // transpose-read lane offset inside an image
+  const bool tok_ok = active && fl < a.L;
+  half_t* drow = a.dqkv + (size_t)row * ld3 + head * HD;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    f32x4b o = {0.f, 0.f, 0.f, 0.f};
+    o = mfma16k<DT>(tr16(k_img + tro + d * 32), dsb, o);                                   // dQ^T[d][q = fl]
+    const int dd = 16 * d + 4 * g;
+    if (tok_ok && dd < HD) *(u32x2b*)(drow + dd) = (u32x2b){pk2<DT>(o[0], o[1]), pk2<DT>(o[2], o[3])};
+  }
+  // ---- orientation 2: S[q = 4 g + r][key = fl], dP likewise; statistics of query 4 g + r from the lanes that own it
+  f32x4b s2 = {0.f, 0.f, 0.f, 0.f}, dp2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    s2 = mfma32<DT>(qf[ks], kf[ks], s2);
+    dp2 = mfma32<DT>(dof[ks], vf[ks], dp2);
+  }
+  f32x4b p2, ds2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = 4 * g + r;                                   // lane q (g = 0) holds the statistics of query q
+    const float nm_q = __shfl(nm, q, 64), il_q = __shfl(inv_l, q, 64), d_q = __shfl(dsum, q, 64);
+    const bool ok = q < a.L && fl < a.L;                       // masked key columns / absent query rows contribute nothing
+    const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[r], c, nm_q)) * il_q : 0.f;
+    p2[r] = p;
+    ds2[r] = p * (dp2[r] - d_q) * a.scale;
+  }
+  const u32x2b pb = {pk2<DT>(p2[0], p2[1]), pk2<DT>(p2[2], p2[3])};                        // 4 queries x key fl
+  const u32x2b dsb2 = {pk2<DT>(ds2[0], ds2[1]), pk2<DT>(ds2[2], ds2[3])};
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    f32x4b ov = {0.f, 0.f, 0.f, 0.f}, ok_ = {0.f, 0.f, 0.f, 0.f};
+    ov = mfma16k<DT>(tr16(do_img + tro + d * 32), pb, ov);                                 // dV^T[d][key = fl]
+    ok_ = mfma16k<DT>(tr16(q_img + tro + d * 32), dsb2, ok_);                              // dK^T[d][key = fl]
+    const int dd = 16 * d + 4 * g;
+    if (tok_ok && dd < HD) {
+      *(u32x2b*)(drow + a.D + dd) = (u32x2b){pk2<DT>(ok_[0], ok_[1]), pk2<DT>(ok_[2], ok_[3])};
+      *(u32x2b*)(drow + 2 * a.D + dd) = (u32x2b){pk2<DT>(ov[0], ov[1]), pk2<DT>(ov[2], ov[3])};
+    }
+  }
+}
+
 template <int HD, int DT>
 int launch_hd_dt(const AttnBwdArgs& a, hipStream_t st) {
+  if (a.L <= 16 && !a.force_tiles) {
+    hipLaunchKernelGGL((attn_bwd_small_kernel<HD, DT>), dim3((a.num_seq * a.heads + 3) / 4), dim3(256), 0, st, a);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   const int tiles = (a.L + 63) / 64;
   dim3 grid(a.num_seq * a.heads * tiles), block(256);
   hipLaunchKernelGGL((attn_bwd_q_kernel<HD, DT>), grid, block, 0, st, a);
@@ -330,6 +485,10 @@ int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout,
   a.num_seq = num_seq; a.L = L; a.heads = heads; a.hd = hd; a.D = heads * hd; a.U = U;
   a.sample_stride = sample_stride; a.seq_stride = seq_stride; a.row_stride = row_stride;
   a.scale = 1.0f / sqrtf((float)hd);
+  {
+    const char* e_ = getenv("LATTE_ATTN_BWD_TILES");
+    a.force_tiles = e_ && atoi(e_) == 1;
+  }
   if (dtype != LATTE_DTYPE_BF16 && dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "attention_bwd: unknown dtype");
 #define CASE(HD)                                                                                         \
   case HD:                                                                                               \

@@ -314,3 +314,41 @@ def test_weight_gradient_gemm_tn(lib, dev, dt, shape, monkeypatch):
         assert float((dW - want).norm() / want.norm()) < 2e-5, force4       # fp32 accumulation of exact half products
         outs.append(dW)
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * float(want.abs().max())
+
+
+# (B, F, T, heads, hd): temporal sequences of 16 / 8 / 5 frames (the one-wave-per-problem kernel, ragged L), spatial 64 and 256 tokens
+ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 2, 64, 2, 72), (1, 2, 256, 2, 64)]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", ATTN_BWD_CASES)
+@pytest.mark.parametrize("mode", ["spatial", "temporal"])
+def test_attention_backward(lib, dev, dt, case, mode, monkeypatch):
+    """dq, dk, dv of the attention core (csrc/train_attn.hip) against torch autograd on the same half q / k / v / dout, for the
+    strided sequence layouts of both block kinds; where L <= 16 the one-wave kernel AND the tile passes (forced) are checked."""
+    B, F, T, H, hd = case
+    D, rows = H * hd, B * F * T
+    g = torch.Generator("cpu").manual_seed(rows + hd)
+    qkv = (torch.randn(rows, 3 * D, generator=g) * 0.7).to(dev).to(TD[dt])
+    dout = torch.randn(rows, D, generator=g).to(dev).to(TD[dt])
+    q5 = qkv.float().view(B, F, T, 3, H, hd).detach().requires_grad_(True)
+    if mode == "spatial":
+        q, k, v = [q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3)]
+        o = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(rows, D)
+        args, L = (B * F, T, H, hd, F, F * T, T, 1), T
+    else:
+        q, k, v = [q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3)]
+        o = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(rows, D)
+        args, L = (B * T, F, H, hd, T, F * T, 1, T), F
+    o.backward(dout.float())
+    want = q5.grad.reshape(rows, 3 * D)
+    oh = o.detach().to(TD[dt])
+    stats = torch.zeros(args[0] * H * L * 3 + 16, device=dev)
+    for force in ([False, True] if L <= 16 else [False]):
+        if force:
+            monkeypatch.setenv("LATTE_ATTN_BWD_TILES", "1")
+        got = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
+        check(lib.latte_debug_attention_bwd(ptr(qkv), ptr(oh), ptr(dout), ptr(got), ptr(stats), *args, dt, stream_ptr()))
+        torch.cuda.synchronize()
+        rel = float((got.float() - want).norm() / want.norm())
+        assert rel < (1.2e-2 if dt == 0 else 2e-3), (force, rel)
