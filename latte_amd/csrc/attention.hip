@@ -614,6 +614,272 @@ __global__ void __launch_bounds__(256, 2) attn_blocks_kernel(AttnArgs a) {
       stage(kb + 1);
     }
   }
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_idx = q0 + gq * 16 + fl;
+    if (q_idx < a.L) {
+      const float inv = 1.0f / l_run[gq];
+      half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int dd = 16 * d + 4 * g;
+        if (dd < HD) {
+          u32x2 pk = {pack2<DT>(o[gq][d][0] * inv, o[gq][d][1] * inv), pack2<DT>(o[gq][d][2] * inv, o[gq][d][3] * inv)};
+          *(u32x2*)(orow + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// attn_stream (round 3) : L > 256.  attn_blocks_kernel stages a 256-key block, waits, computes, and restages -- staging and
+// compute take turns inside a workgroup (two workgroups per CU cover part of it), and every K / V block is staged once per
+// 128-query workgroup: at Latte-1 (L = 1024) 1.3 GB of L2 -> LDS traffic per launch, 300 us for 155 GFLOP.  Here one 8-wave
+// workgroup per CU owns 256 queries (32 per wave, two 16-query MFMA column groups sharing every fragment read) and STREAMS the
+// keys through a ring of three 128-key blocks (K image | V image, 40 KB each): the LDS DMA of blocks kb + 1 and kb + 2 is in
+// flight while block kb is multiplied (counted vmcnt, one barrier per block), and each block is staged half as often.
+// Online softmax across blocks as in attn_blocks_kernel (running max on the raw scores, unconditional rescale).
+// The V^T fragments come from the transpose read in its inline-assembly form: in front of the builtin hipcc drains every LDS
+// DMA in flight (see gemm_tn.hip), which would serialise the ring again.
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr16_asm(const char* p) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)(const __attribute__((address_space(3))) char*)p), "i"(OFF));
+  return v;
+}
+
+template <int HD, int DT, int ABL = 0>
+__global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
+  constexpr int RP = 160, KB = 128, NKT = KB / 16;     // keys per block, 16-key tiles per block
+  constexpr int IMG = KB * RP, BLK = 2 * IMG;          // K image | V image
+  static_assert(DF <= 5, "the V fragment reads below are written out for up to five 16-wide d fragments");
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];   // 3 x BLK
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fl = lane & 15, g = lane >> 4;
+  const int qblocks = (a.L + 255) >> 8;
+  int seq, head, qb;
+  {
+    int b = blockIdx.x;
+    const int per_seq = a.heads * qblocks;
+    if ((a.num_seq & 7) == 0) {   // the heads and query blocks of one sequence on ONE XCD (shared K / V panels, shared output lines)
+      const int xcd = b & 7, slot = b >> 3;
+      seq = (slot / per_seq) * 8 + xcd;
+      b = slot % per_seq;
+    } else {
+      seq = b / per_seq;
+      b = b % per_seq;
+    }
+    head = b / qblocks;
+    qb = b % qblocks;
+  }
+  const int64_t base = seq_base_row(a, seq);
+  const size_t ld = (size_t)3 * a.D;
+  const half_t* qkv_h = a.qkv + (size_t)head * HD;
+  const int q0 = qb * 256 + wave * 32;
+  const int nkb = (a.L + KB - 1) / KB;
+
+  // Q fragments first, and completed before any DMA is issued (hipcc would otherwise wait for them with vmcnt(0) at their first
+  // use, i.e. in the middle of the ring)
+  u32x4 qf[2][KS];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_ld = min(q0 + gq * 16 + fl, a.L - 1);
+    const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = g + 4 * ks;
+      qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
+      if (ch < NCH) qf[gq][ks] = *(const u32x4*)(qrow + ch * 8);
+    }
+  }
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[gq][ks]));
+
+  // a block = 40 DMA instructions (20 per image: 1280 16-byte chunks); wave w issues 5 of them, all inside one image.  The
+  // per-lane part of a source address (key row inside the block, chunk, K or V column offset) does not depend on the block:
+  // it is formed once as a 32-bit byte offset (the launcher checks the range); a block adds a wave-uniform base.  Only a ragged
+  // last block re-forms the offsets (its rows >= L re-read row L - 1: they meet P = 0 and finite data).
+  unsigned voff[5];
+  auto lane_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
+    const int inst = wave * 5 + j;                      // 0..19: K image, 20..39: V image
+    const int ii = inst >= 20 ? inst - 20 : inst;
+    const int idx = ii * 64 + lane;
+    const int key = idx / 10, ch = idx - key * 10;
+    const int key_ld = min(key, a.L - 1 - kb * KB), ch_ld = min(ch, NCH - 1);
+    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch_ld * 8 + (inst >= 20 ? 2 : 1) * a.D) * 2);
+  };
+#pragma unroll
+  for (int j = 0; j < 5; ++j) voff[j] = lane_offset(j, 0);
+  const bool ragged = (a.L % KB) != 0;
+  auto stage = [&](int kb, int slot) __attribute__((always_inline)) {
+    char* dst = smem_attn + slot * BLK;
+    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb * KB * a.row_stride) * ld);   // wave-uniform
+    if (ragged && kb == nkb - 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + lane_offset(j, kb)),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave * 5 + j) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + voff[j]),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave * 5 + j) * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  if (nkb > 1) stage(1, 1);
+
+  const float c = a.scale * 1.4426950408889634f;
+  f32x4 o[2][DF];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+  const bool wave_active = q0 < a.L;
+  f32x4 st[2][NKT];     // S^T of one block, then P: [16-query group][16-key tile]
+
+  // S^T = K Q^T of block kb (MFMA phase 1): K fragments two key tiles ahead
+  auto scores = [&](int kb) __attribute__((always_inline)) {
+    const char* kbase = smem_attn + (kb % 3) * BLK + fl * RP + g * 16;
+    u32x4 kf[4][KS];
+    auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+    };
+    load_k(0, kf[0]);
+    load_k(1, kf[1]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st[0][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[0][ks], st[0][kt]);
+        st[1][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[1][ks], st[1][kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // online softmax of the block held in st (VALU phase): running max on the raw scores, unconditional rescale
+  auto softmax = [&](int kb) __attribute__((always_inline)) {
+    const int kleft = a.L - kb * KB;
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      if (kleft < KB) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * kt + 4 * g + r >= kleft) st[gq][kt][r] = NEG_BIG;
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[gq], mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[gq] - m_new) * c);   // first block: exp2(-huge) = 0 on o = l = 0
+      const float nm = -m_new * c;
+      // two scores per VALU instruction where the ISA has packed fp32 forms (v_pk_fma_f32, v_pk_add_f32); the exp2 is scalar
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 c2 = {c, c}, nm2 = {nm, nm};
+      f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 e = __builtin_elementwise_fma((f32x2){st[gq][kt][r], st[gq][kt][r + 1]}, c2, nm2);
+          const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          st[gq][kt][r] = p.x;
+          st[gq][kt][r + 1] = p.y;
+          ls2 += p;
+        }
+      float ls = ls2.x + ls2.y;
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      l_run[gq] = l_run[gq] * alpha + ls;
+      // no query of this wave raised its maximum (the usual case after the first blocks): alpha is exactly 1 in every lane and
+      // the rescale of the accumulators is the identity -- skipped, bit-identical
+      const bool raised = __builtin_amdgcn_ballot_w64(m_new != m_run[gq]) != 0;
+      m_run[gq] = m_new;
+      if (raised) {
+#pragma unroll
+        for (int d = 0; d < DF; ++d) o[gq][d] *= alpha;
+      }
+    }
+  };
+  auto softmax_sel = [&](int kb) __attribute__((always_inline)) { if constexpr (ABL != 8) softmax(kb); };   // (ABL: measurement ablations, results garbage)
+  // O^T += V^T P^T of block kb (MFMA phase 2); k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4).  V^T
+  // fragments one 32-key step ahead; the reads are inline assembly, so their completion is counted here: 2 DF reads per step
+  auto weighted_sum = [&](int kb) __attribute__((always_inline)) {
+    const char* vbase = smem_attn + (kb % 3) * BLK + IMG + (4 * g + (fl >> 2)) * RP + (fl & 3) * 8;
+    u32x2 vlo[2][5], vhi[2][5];
+    auto load_v = [&](int ks2, u32x2 (&lo)[5], u32x2 (&hi)[5]) {
+      const char* pv = vbase + (32 * ks2) * RP;
+      lo[0] = lds_tr16_asm<0>(pv); hi[0] = lds_tr16_asm<16 * RP>(pv);
+      lo[1] = lds_tr16_asm<32>(pv); hi[1] = lds_tr16_asm<16 * RP + 32>(pv);
+      lo[2] = lds_tr16_asm<64>(pv); hi[2] = lds_tr16_asm<16 * RP + 64>(pv);
+      lo[3] = lds_tr16_asm<96>(pv); hi[3] = lds_tr16_asm<16 * RP + 96>(pv);
+      if constexpr (DF == 5) { lo[4] = lds_tr16_asm<128>(pv); hi[4] = lds_tr16_asm<16 * RP + 128>(pv); }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler's own LDS traffic of the softmax shuffles)
+    load_v(0, vlo[0], vhi[0]);
+#pragma unroll
+    for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+      if (ks2 + 1 < NKT / 2) {
+        load_v(ks2 + 1, vlo[(ks2 + 1) & 1], vhi[(ks2 + 1) & 1]);
+        if constexpr (DF == 5) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 pb[2];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+        pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const u32x4 vfrag = {vlo[ks2 & 1][d][0], vlo[ks2 & 1][d][1], vhi[ks2 & 1][d][0], vhi[ks2 & 1][d][1]};
+        o[0][d] = mfma_k32<DT>(vfrag, pb[0], o[0][d]);
+        o[1][d] = mfma_k32<DT>(vfrag, pb[1], o[1][d]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Interval kb: own DMA of block kb landed (block kb + 1 may stay in flight), then everybody's; the barrier also retires every
+  // read of block kb - 1, whose slot takes block kb + 2.  (Running waves 4-7 one phase behind waves 0-3 -- softmax of block
+  // kb - 1 under the other wave's score MFMAs -- was built and measured: 250 against 242 us, no gain; ABL: measurement ablations.)
+  for (int kb = 0; kb < nkb; ++kb) {
+    if constexpr (ABL != 9) {
+      if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (ABL != 7) {
+      if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
+    }
+    if (wave_active) {
+      scores(kb);
+      softmax_sel(kb);
+      weighted_sum(kb);
+    }
+  }
   if (!wave_active) return;
 #pragma unroll
   for (int gq = 0; gq < 2; ++gq) {
@@ -732,18 +998,38 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
   AttnArgs a = a_in;
   if (const char* ab = getenv("LATTE_ATTN_ABLATE")) a.variant = atoi(ab);   // measurement only (tools/attn_pmc.py)
   // variant 1 forces the generic flash kernel (tests); variant 4 (measurement) sends 128 < L <= 256 to the block kernel
-  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1 && a.variant != 4;
-  const bool blocks = (a.L > 256 && a.variant != 1) || (a.L > 128 && a.variant == 4);   // 256-key blocks + online softmax
-  constexpr int FULL_LDS = 2 * 256 * 160;
-  dim3 block(256);
+  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1 && a.variant != 4 && a.variant != 5;
+  // L > 256: the streaming kernel (8 waves, 256 queries, ring of 128-key blocks); variant 4 keeps the stage-then-compute block
+  // kernel reachable (tests, A/B measurements), variant 5 forces the streaming kernel for 128 < L <= 256 as well
+  // (its per-lane source offsets are 32-bit: 128 rows of a block must span less than 2 GiB)
+  const bool stream_ok = (int64_t)a.row_stride * 3 * a.D * 2 * 128 < (1ll << 31);
+  const bool stream = stream_ok && ((a.L > 256 && a.variant != 1 && a.variant != 4) || (a.L > 128 && a.variant == 5));
+  const bool blocks = !stream && ((a.L > 256 && a.variant != 1) || (a.L > 128 && a.variant == 4));   // 256-key blocks + online softmax
+  constexpr int FULL_LDS = 2 * 256 * 160, STREAM_LDS = 3 * 2 * 128 * 160;
+  dim3 block(stream ? 512 : 256);
   dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4)
-                    : (full ? dim3(a.num_seq * a.heads)
-                            : (blocks ? dim3(a.num_seq * a.heads * ((a.L + 127) / 128)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64))));
+                    : (full && !stream ? dim3(a.num_seq * a.heads)
+                            : (stream ? dim3(a.num_seq * a.heads * ((a.L + 255) / 256))
+                               : (blocks ? dim3(a.num_seq * a.heads * ((a.L + 127) / 128)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64)))));
 #define ATTN_LAUNCH(HD, DT)                                                                                   \
   do {                                                                                                        \
     if (small)                                                                                                \
       hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);                                 \
-    else if (full) {                                                                                          \
+    else if (stream) {                                                                                        \
+      static std::atomic<uint64_t> attr_done_s{0};                                                            \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
+      if (a.variant >= 7 && a.variant <= 9 && HD == 72 && DT == LATTE_DTYPE_F16) {                            \
+        static std::atomic<uint64_t> attr_done_a{0};                                                          \
+        const void* fn_ = a.variant == 7 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 7>            \
+                          : a.variant == 8 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 8>          \
+                                           : (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 9>;         \
+        hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS);                     \
+        void* args_[] = {(void*)&a};                                                                          \
+        LATTE_HIP(hipLaunchKernel(fn_, grid, block, args_, STREAM_LDS, st));                                  \
+        (void)attr_done_a;                                                                                    \
+      } else                                                                                                  \
+      hipLaunchKernelGGL((attn_stream_kernel<HD, DT>), grid, block, STREAM_LDS, st, a);                       \
+    } else if (full) {                                                                                          \
       static std::atomic<uint64_t> attr_done{0};                                                              \
       if (int rc_ = ensure_dynamic_lds((const void*)attn_full_kernel<HD, DT>, FULL_LDS, attr_done)) return rc_; \
       hipLaunchKernelGGL((attn_full_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                           \

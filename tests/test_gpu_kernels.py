@@ -120,6 +120,20 @@ CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100,
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("mode", ["spatial", "temporal"])
 def test_attention(lib, dev, dt, case, mode):
+    _attention_case(lib, dev, dt, case, mode)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", [c for c in CASES if c[2] > 128])
+@pytest.mark.parametrize("variant", [4, 5])
+def test_attention_long_sequence_kernels_forced(lib, dev, dt, case, variant, monkeypatch):
+    """The spatial cases with more than 128 tokens through the kernels the default choice does not take for them: 4 = the 256-key
+    block kernel, 5 = the streaming kernel (also for 128 < L <= 256, where the single-block kernel is the default)."""
+    monkeypatch.setenv("LATTE_ATTN_ABLATE", str(variant))
+    _attention_case(lib, dev, dt, case, "spatial")
+
+
+def _attention_case(lib, dev, dt, case, mode):
     B, F, T, H, hd = case
     D, rows = H * hd, B * F * T
     g = torch.Generator("cpu").manual_seed(rows + hd)
@@ -158,9 +172,13 @@ def test_attention_forced_rescale(lib, dev):
 
 
 @pytest.mark.parametrize("hd,spike_key", [(72, 900), (64, 300), (72, 1023)])
-def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key):
-    """The 256-key-block kernel (L = 1024): a key in a LATE block dominates one query, so the running maximum jumps and the
-    accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
+@pytest.mark.parametrize("kernel", ["stream", "blocks"])
+def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key, kernel, monkeypatch):
+    """The online-softmax kernels for L > 256 (L = 1024: the streaming kernel with its ring of 128-key blocks, and the 256-key
+    stage-then-compute block kernel, LATTE_ATTN_ABLATE=4): a key in a LATE block dominates one query, so the running maximum
+    jumps and the accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
+    if kernel == "blocks":
+        monkeypatch.setenv("LATTE_ATTN_ABLATE", "4")
     T, dt = 1024, 1
     g = torch.Generator("cpu").manual_seed(spike_key)
     qkv = torch.randn(T, 3 * hd, generator=g)
