@@ -82,10 +82,11 @@ void latte_engine_destroy(latte_engine_t* e);
 
 /* Engine options: "gemm_variant" (0 auto; 1-3 simple kernel 128x128 / 256x128 / 256x256; 4-6 ping-pong kernel
  * 256x128 / 256x192 / 256x256 tiles; 7-9 the persistent ping-pong kernel, same tiles; 10 / 11 the 12-wave
- * producer / consumer kernel, 256x192, two-segment / rolling schedule),
+ * producer / consumer kernel, 256x192, two-segment / rolling schedule; 12 / 13 the small-M kernel, 128x144 tile with a
+ * four-stage ring, DMA by the twelve MFMA waves / by four extra waves -- what the gated GEMMs of a 4096-row batch run on),
  * "gemm_variant_qkv" / "_proj" / "_fc1" / "_fc2" (the same, for one of the four GEMMs of the block only; tuning hook),
  * "gated_split_k" (small batches: 0 = the rule -- a gated GEMM with >= 64 K tiles whose tiles fill at most half of the
- * CUs runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
+ * CUs, and which the 128x144 tile does not take, runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
  * "fuse_qkv_attn" (bit 0: spatial blocks, bit 1: temporal blocks run the QKV projection and the attention core of
  * latte.py:48-70 as ONE kernel with q / k / v held in LDS -- csrc/qkv_attn.hip -- wherever the shape allows it: 256 tokens per
  * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; bits 2-3 select schedule

@@ -96,11 +96,13 @@ struct GemmArgs {
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
 // 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
 int launch_gemm(const GemmArgs& a, int epi, int dtype, int variant, hipStream_t st);
-// variants 10 / 11 = producer-wave kernels, 256x192 tile, 12 waves (gemm_pw.hip): two-segment / rolling schedule
+// variants 10 / 11 = producer-wave kernels, 256x192 tile, 12 waves (gemm_pw.hip): two-segment / rolling schedule;
+// variants 12 / 13 = small-M kernel, 128x144 tile, four LDS stages: 12 waves / 12 MFMA + 4 DMA waves (gemm.hip)
 int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, int roll, hipStream_t st);
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);
 int gemm_auto_variant(int M, int N, int epi);
+bool gemm_small_tile_ok(int M, int N, int K);   // gated GEMM: the 128 x 144 tile (variant 13) takes it when no variant is forced
 
 // ---- attention --------------------------------------------------------------------------------
 struct AttnArgs {

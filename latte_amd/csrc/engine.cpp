@@ -146,6 +146,7 @@ enum { C_QKV = 0, C_PROJ, C_FC1, C_FC2, C_ATTN_S, C_ATTN_T, C_LN, C_COND, C_PATC
 constexpr int64_t SPLIT_WS_FLOATS = 256ll * 256 * 192;   // s * tiles <= 256 tiles of 256 x 192
 int gated_split_choice(const latte_engine* e, int M, int N, int K, int variant) {
   if (variant != 0 || e->gated_split_k == 1 || N % 192 || K % 64) return 1;
+  if (e->gated_split_k == 0 && gemm_small_tile_ok(M, N, K)) return 1;   // one 128 x 144 tile per CU beats the split (launch_gemm)
   const int tiles = ((M + 255) / 256) * (N / 192), nk = K / 64;
   if (e->gated_split_k >= 2) {
     const int s = e->gated_split_k;
@@ -477,8 +478,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 11) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..11");
-    const int bn = value >= 7 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);
+    if (value < 0 || value > 13) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..13");
+    const int bn = value >= 7 && value <= 9 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);   // 7-9: whole wave widths
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
     e->gemm_variant = (int)value;
@@ -487,7 +488,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   for (int gi = 0; gi < 4; ++gi) {
     static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
     if (k == names[gi]) {
-      if (value < 0 || value > 11) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..11");
+      if (value < 0 || value > 13) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..13");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }

@@ -170,6 +170,193 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-M kernel (variants 12 / 13): 128 x 144 tile, twelve MFMA waves (4 along M x 3 along N, wave tile 32 x 48), four LDS
+// stages.  At B = 1 (M = 4096 rows) the gated GEMMs with N = 1152 have 96 tiles of 256 x 192 for 256 CUs; 128 x 144 gives
+// exactly 32 x 8 = 256 tiles, one per CU, and N = 1152 = 8 x 144 -- the tile shape that minimises the operand bytes a CU has to
+// pull (BM + BN at BM x BN = M N / 256), which is what bounds these launches: a CU keeps three K tiles (104 KB) in flight and
+// gets 47 GB/s out of them whatever issues the DMA (measured: fc2 57 / 55 / 54 us with the DMA after the barrier, between the
+// MFMA groups, in producer waves; warming the L2 eight K tiles ahead with one-dword loads made it 68).  One tile per workgroup
+// means nothing hides the pipeline fill of a persistent walk, so the ring is deep instead: 4 stages of (128 + 144) x 128 B =
+// 34 KB, the DMA of K tiles kt + 1 .. kt + 3 in flight while K tile kt is multiplied (counted vmcnt, one barrier per K tile).
+// A K tile is 34 one-KB DMA pieces (16 A row-groups, then 18 W row-groups: the LDS image of a stage is contiguous in that
+// order).  PRODUCER = 0 (variant 12, 768 threads): wave w issues pieces w, w + 12, w + 24.  PRODUCER = 1 (variant 13, 1024
+// threads, the default for the shapes it takes): waves 12-15, one per SIMD, issue everything -- pieces pw + 4 j, nine per wave
+// -- and the MFMA waves issue none.  A wave whose last piece index runs past 33 repeats its previous piece (same bytes to the
+// same place), so that every issuing wave has the same number of pieces per K tile in flight and one vmcnt constant serves all;
+// 12 and 4 are even, so the source-side swizzle of a wave's pieces is the same.  24 accumulators per lane.
+template <int EPI, int DT, int PRODUCER>
+__global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 144, NS = 4;
+  constexpr int FM = 2, FN = 3;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, NPIECE = (BM + BN) / 8;
+  constexpr int NISSUE = PRODUCER ? 4 : 12, PER_WAVE = (NPIECE + NISSUE - 1) / NISSUE;   // issuing waves, pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_coords((g.M + BM - 1) / BM, g.N / BN, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int K = g.K, nk = K / 64;
+
+  // ---- DMA: piece p < 16 = A rows 8 p .. 8 p + 7, else W rows 8 (p - 16) ..; lane -> (row lane >> 3, chunk swizzled)
+  const bool issuer = PRODUCER ? wave >= 12 : true;
+  const half_t* src[PER_WAVE];
+  int dst_off[PER_WAVE];
+  if (issuer) {
+    const int iw = PRODUCER ? wave - 12 : wave;
+    const int lrow = lane >> 3, cpos = lane & 7;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      int p = iw + NISSUE * j;
+      if (p >= NPIECE) p -= NISSUE;
+      const int grp8 = p < 16 ? p : p - 16;
+      const int row = grp8 * 8 + lrow;
+      const int schunk = cpos ^ ((row >> 1) & 7);
+      // A rows beyond M exist (row-padded operand); W rows are all inside N (N % 144 == 0)
+      src[j] = (p < 16 ? g.A + (size_t)(m0 + row) * K : g.W + (size_t)(n0 + row) * K) + schunk * 8;
+      dst_off[j] = p * 1024;
+    }
+  }
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    char* s = smem + (kt & (NS - 1)) * STAGE;
+    const int koff = kt * 64;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + koff, s + dst_off[j]);
+  };
+  // own pieces of K tile kt landed (those of kt + 1, kt + 2 may stay in flight)
+  auto wait_tile = [&](int kt) __attribute__((always_inline)) {
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  if constexpr (PRODUCER) {
+    if (wave >= 12) {
+      stage(0);
+      if (nk > 1) stage(1);
+      if (nk > 2) stage(2);
+      for (int kt = 0; kt < nk; ++kt) {
+        wait_tile(kt);
+        __builtin_amdgcn_s_barrier();   // K tile kt is complete for the MFMA waves; every read of K tile kt - 1 has retired
+        if (kt + 3 < nk) stage(kt + 3);
+      }
+      return;
+    }
+  }
+
+  const int wm = wave / 3, wn = wave - wm * 3;
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int chunk0 = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (wm * 32 + frow) * 128 + chunk0;
+  const int b_off = A_BYTES + (wn * 48 + frow) * 128 + chunk0;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Gated read-modify-write epilogue: every residual element belongs to exactly one lane of one workgroup, so its old value,
+  // the gate and the bias are fetched NOW, ahead of the first DMA: vmcnt retires in order, so the first counted wait of the K
+  // loop also covers them and their latency disappears under the main loop (a load / wait / store chain per fragment after it
+  // cost six dependent round trips).  Rows >= M read row M - 1 and are not stored.
+  const int ncol = n0 + wn * 48 + (lane >> 4) * 4;
+  float4 rres[FM][FN], g4[FM][FN], b4[FN];
+  if constexpr (EPI == EPI_GATE_RES_F32) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol + j * 16);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int mc = min(m0 + wm * 32 + i * 16 + frow, g.M - 1);
+      const float* gate_row = g.gate + (size_t)(mc / g.rows_per_sample) * g.gate_stride;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        rres[i][j] = *(const float4*)((const float*)g.out + (size_t)mc * g.N + ncol + j * 16);
+        g4[i][j] = *(const float4*)(gate_row + ncol + j * 16);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  if constexpr (!PRODUCER) {
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // K tile kt has landed for everybody; the barrier also retires every read of K tile kt - 1, whose stage takes K tile kt + 3
+    if constexpr (!PRODUCER) wait_tile(kt);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (!PRODUCER) {
+      if (kt + 3 < nk) stage(kt + 3);
+    }
+    const char* sbuf = smem + (kt & (NS - 1)) * STAGE;
+    u32x4 af[2][FM], bf[2][FN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+  }
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + frow;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if constexpr (EPI == EPI_GATE_RES_F32) {
+        float4 r = rres[i][j];
+        r.x += g4[i][j].x * (acc[i][j][0] + b4[j].x);
+        r.y += g4[i][j].y * (acc[i][j][1] + b4[j].y);
+        r.z += g4[i][j].z * (acc[i][j][2] + b4[j].z);
+        r.w += g4[i][j].w * (acc[i][j][3] + b4[j].w);
+        *(float4*)((float*)g.out + (size_t)m * g.N + ncol + j * 16) = r;
+      } else {
+        epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, nullptr);
+      }
+    }
+  }
+}
+
+template <int DT, int PRODUCER>
+int launch_n144(const GemmArgs& a, int epi, hipStream_t st) {
+  constexpr int LDS = 4 * (128 + 144) * 128;
+  if (a.N % 144 != 0 || a.K % 64 != 0 || a.k_chunk != 0)
+    return fail(LATTE_ERR_INVALID, "gemm (128 x 144 tile): need N % 144 == 0, K % 64 == 0, no K split");
+  dim3 grid(((a.M + 127) / 128) * (a.N / 144)), block(PRODUCER ? 1024 : 768);
+#define LATTE_GEMM_CASE(E)                                                                           \
+  case E: {                                                                                          \
+    auto kern = gemm_n144_kernel<E, DT, PRODUCER>;                                                   \
+    static std::atomic<uint64_t> attr_done{0};                                                       \
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+    break;                                                                                           \
+  }
+  switch (epi) {
+    LATTE_GEMM_CASE(EPI_BIAS_H16)
+    LATTE_GEMM_CASE(EPI_BIAS_GELU_H16)
+    LATTE_GEMM_CASE(EPI_GATE_RES_F32)
+    LATTE_GEMM_CASE(EPI_BIAS_F32)
+    default:
+      return fail(LATTE_ERR_INVALID, "gemm (128 x 144 tile): unknown epilogue");
+  }
+#undef LATTE_GEMM_CASE
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN, int DT>
 int launch_cfg(const GemmArgs& a, int epi, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -846,18 +1033,21 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
     case 7: return launch_pps<128, DT>(a, epi, st);
     case 8: return launch_pps<192, DT>(a, epi, st);
     case 9: return launch_pps<256, DT>(a, epi, st);
+    case 12: return launch_n144<DT, 0>(a, epi, st);
+    case 13: return launch_n144<DT, 1>(a, epi, st);
     default: return fail(LATTE_ERR_INVALID, "gemm: unknown tile variant");
   }
 }
 
 }  // namespace
 
-int gemm_tile_m(int variant) { return variant == 1 ? 128 : 256; }
+int gemm_tile_m(int variant) { return variant == 1 || variant == 12 || variant == 13 ? 128 : 256; }
 
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: return 256;
     case 5: case 8: case 10: case 11: return 192;
+    case 12: case 13: return 144;
     default: return 128;
   }
 }
@@ -890,6 +1080,14 @@ int gemm_auto_variant(int M, int N, int epi) {
   return best;
 }
 
+// The 128 x 144 tile (variant 13) for a gated read-modify-write GEMM: whole 144-wide tile columns and at most one tile per CU
+// -- B = 1 at XL/2 (M = 4096, N = 1152: 256 tiles): out-projection 31 -> 23 us, fc2 70 (two-way split K + reduction) -> 54 us
+// per launch inside the forward; at B = 2 (512 tiles) it loses to the 256 x 192 producer-wave kernel (45 against 38 us, 113
+// against 88).
+bool gemm_small_tile_ok(int M, int N, int K) {
+  return N % 144 == 0 && K % 64 == 0 && (long)((M + 127) / 128) * (N / 144) <= 256;
+}
+
 int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
   GemmArgs a = a_in;
   // grouped tile order of the persistent kernel: the gated-residual GEMMs (192-wide tiles: an A K-tile is 32 KB, a W K-tile
@@ -909,6 +1107,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     }
   }
 #endif
+  if (variant == 0 && epi == EPI_GATE_RES_F32 && gemm_small_tile_ok(a.M, a.N, a.K)) variant = 13;
   if (variant == 0) {
     variant = gemm_auto_variant(a.M, a.N, epi);
     // the gated read-modify-write GEMMs on 192-wide tiles run on the 12-wave producer / consumer kernel (gemm_pw.hip, rolling
@@ -922,7 +1121,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
   }
   if (variant == 10 || variant == 11) return launch_gemm_pw(a, epi, dtype, variant == 11, st);
   const int bn = gemm_tile_n(variant);
-  const int nq = variant >= 7 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
+  const int nq = variant >= 7 && variant <= 9 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)
     return fail(LATTE_ERR_INVALID, "gemm: shape not tileable (need K % 64 == 0, N % tileN == 0)");
   if (dtype == LATTE_DTYPE_BF16) return launch_dt<LATTE_DTYPE_BF16>(a, epi, variant, st);

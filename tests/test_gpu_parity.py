@@ -329,11 +329,13 @@ def test_xl_chain_is_bitwise_reproducible():
 
 
 @pytest.mark.parametrize("B", [1, 2])
-def test_small_batch_split_k_gated_gemms(B):
-    """B = 1 at XL/2: fc2 (96 tiles of 256 x 192 for 256 CUs, K = 4608) runs as two partial products over halves of the
-    contraction + a reduction into the residual stream (engine.cpp: gated_gemm).  The forward must agree with the unsplit path
-    up to the re-association (the contraction is summed in two parts instead of one), with the split forced on both gated GEMMs
-    likewise, be bit-identical run to run, and at B = 2 (192 tiles: no split) the rule must change nothing."""
+def test_small_batch_gated_gemms(B):
+    """B = 1 at XL/2 (M = 4096): the gated GEMMs (out-projection, fc2; N = 1152) have 96 tiles of 256 x 192 for 256 CUs.  The rule
+    (gemm.hip: gemm_small_tile_ok) gives them the 128 x 144 tile -- 256 tiles, one per CU -- which sums the contraction in the
+    same order as the 256 x 192 kernels: bit-identical to the forward with the 12-wave kernel forced.  A forced split of the
+    contraction (engine.cpp: gated_gemm, 2 partial products + a reduction into the residual stream) agrees up to the
+    re-association, every path is bit-identical run to run, and at B = 2 (512 small tiles: not taken; 192 large ones: no split)
+    the options must change nothing."""
     from oracle import latte_oracle as lo
     kw = dict(input_size=32, num_frames=16, extras=1)
     cfg = lo.preset_config("Latte-XL/2", **kw)
@@ -351,17 +353,20 @@ def test_small_batch_split_k_gated_gemms(B):
         torch.cuda.synchronize()
         assert torch.isfinite(o).all()
         if mode in outs:
-            assert torch.equal(o, outs[mode]), "split-K path is not deterministic"
+            assert torch.equal(o, outs[mode]), "not deterministic"
         outs[mode] = o.clone()
     m.set_engine_option("gated_split_k", 0, B)
-    if B == 1:
-        assert not torch.equal(outs[0], outs[1]), "the rule did not split at B = 1"
-        assert rel_l2(outs[0], outs[1]) < 6e-4      # fp32 re-association, amplified by the half-precision operand rounding downstream
-    else:
-        assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1])            # the rule never splits: small tile at B = 1, enough large tiles at B = 2
     if B == 1:
         assert not torch.equal(outs[2], outs[1]), "the forced split did not split"
-    assert rel_l2(outs[2], outs[1]) < 6e-4
+    assert rel_l2(outs[2], outs[1]) < 6e-4          # fp32 re-association, amplified by the half-precision operand rounding downstream
+    for gname in ("proj", "fc2"):
+        m.set_engine_option("gemm_variant_" + gname, 11, B)
+    big = m.forward(x, t)
+    torch.cuda.synchronize()
+    for gname in ("proj", "fc2"):
+        m.set_engine_option("gemm_variant_" + gname, 0, B)
+    assert torch.equal(big, outs[0]), "128 x 144 tile and 256 x 192 tile disagree"
 
 
 @pytest.mark.parametrize("cd", [None, "f16"])

@@ -326,7 +326,7 @@ def gemm_in_model():
         t = torch.full((B,), 500, device=dev, dtype=torch.int64)
         for gname, key in (("qkv", "gemm_qkv"), ("proj", "gemm_proj"), ("fc1", "gemm_fc1"), ("fc2", "gemm_fc2")):
             row = []
-            for v in (1, 5, 6, 7, 8, 9, 10, 11):
+            for v in [int(s) for s in os.environ.get('LATTE_FL_VARIANTS', '0,1,5,6,7,8,9,10,11,12').split(',')]:
                 try:
                     m.set_engine_option("gemm_variant_" + gname, v, B)
                     m.profile_forward(x, t)
