@@ -176,7 +176,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
 // exactly 32 x 8 = 256 tiles, one per CU, and N = 1152 = 8 x 144 -- the tile shape that minimises the operand bytes a CU has to
 // pull (BM + BN at BM x BN = M N / 256), which is what bounds these launches: a CU keeps three K tiles (104 KB) in flight and
 // gets 47 GB/s out of them whatever issues the DMA (measured: fc2 57 / 55 / 54 us with the DMA after the barrier, between the
-// MFMA groups, in producer waves; warming the L2 eight K tiles ahead with one-dword loads made it 68).  One tile per workgroup
+// MFMA groups, in producer waves; warming the L2 eight K tiles ahead with one-dword loads made it 68).  (The same idea for fc1
+// at B = 1 -- a 256 x 288 tile, 16 x 16 = 256 tiles, eight waves, K tiles of 32 in a four-stage ring, 64-byte LDS rows with the
+// chunk position kg ^ (row & 8 ? 3 : 0), conflict-free by PMC -- was built, passed the GEMM tests and TIED the 256 x 192 12-wave
+// kernel inside the forward: 54.1 against 54.3 us; removed.)  One tile per workgroup
 // means nothing hides the pipeline fill of a persistent walk, so the ring is deep instead: 4 stages of (128 + 144) x 128 B =
 // 34 KB, the DMA of K tiles kt + 1 .. kt + 3 in flight while K tile kt is multiplied (counted vmcnt, one barrier per K tile).
 // A K tile is 34 one-KB DMA pieces (16 A row-groups, then 18 W row-groups: the LDS image of a stage is contiguous in that
