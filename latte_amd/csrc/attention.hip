@@ -900,6 +900,181 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_cross (round 3): the text cross-attention of LatteT2V (attn2, latte_t2v.py:740-760) for Lk <= 128 keys (Latte-1: 120 T5
+// tokens).  The generic flash kernel gave every 64 queries their own workgroup, each staging the sample's K / V through registers
+// in two 64-key tiles with an online softmax between them: 102 us per launch at the Latte-1 shape for 18 GFLOP and 150 MB.
+// Here one 8-wave workgroup owns 256 queries of a (frame, head) as in attn_stream_kernel, ALL keys and values of the head are
+// staged ONCE by LDS DMA (two 128-row images, rows >= Lk re-read row Lk - 1), the score bias of the caption mask sits in LDS,
+// and the softmax over the <= 128 scores a query meets is exact in registers (no running maximum, no rescale).
+// z = s * scale * log2(e) + bias * log2(e) as in the flash kernel; keys >= Lk get -1e30.
+template <int HD, int DT>
+__global__ void __launch_bounds__(512) attn_cross_kernel(AttnArgs a) {
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
+  constexpr int RP = 160, KB = 128, NKT = KB / 16;
+  constexpr int IMG = KB * RP;                          // K image | V image | bias[128]
+  static_assert(DF <= 5, "the V fragment reads below are written out for up to five 16-wide d fragments");
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  float* const bias_lds = (float*)(smem_attn + 2 * IMG);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fl = lane & 15, g = lane >> 4;
+  const int qblocks = (a.L + 255) >> 8;
+  int seq, head, qb;
+  {
+    int b = blockIdx.x;
+    const int per_seq = a.heads * qblocks;
+    if ((a.num_seq & 7) == 0) {   // the heads and query blocks of one sequence on ONE XCD (shared output lines, one K / V panel)
+      const int xcd = b & 7, slot = b >> 3;
+      seq = (slot / per_seq) * 8 + xcd;
+      b = slot % per_seq;
+    } else {
+      seq = b / per_seq;
+      b = b % per_seq;
+    }
+    head = b / qblocks;
+    qb = b % qblocks;
+  }
+  const int64_t base = seq_base_row(a, seq);
+  const size_t ld = (size_t)a.q_ld;
+  const half_t* q_h = a.qkv + (size_t)head * HD;
+  const int NK = a.Lk, smp = seq / a.U;
+  const half_t* kv_h = a.kv + ((size_t)smp * a.Lk) * (2 * (size_t)a.D) + (size_t)head * HD;
+  const int q0 = qb * 256 + wave * 32;
+
+  u32x4 qf[2][KS];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_ld = min(q0 + gq * 16 + fl, a.L - 1);
+    const half_t* qrow = q_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = g + 4 * ks;
+      qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
+      if (ch < NCH) qf[gq][ks] = *(const u32x4*)(qrow + ch * 8);
+    }
+  }
+  // 40 DMA instructions (20 per image: 1280 16-byte chunks), 5 per wave, all of a wave inside one image
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int inst = wave * 5 + j;                      // 0..19: K image, 20..39: V image
+    const int ii = inst >= 20 ? inst - 20 : inst;
+    const int idx = ii * 64 + lane;
+    const int key = idx / 10, ch = idx - key * 10;
+    const int key_ld = min(key, NK - 1), ch_ld = min(ch, NCH - 1);
+    const half_t* rowp = kv_h + (size_t)key_ld * (2 * (size_t)a.D) + ch_ld * 8 + (inst >= 20 ? a.D : 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rowp,
+                                     (__attribute__((address_space(3))) void*)(smem_attn + inst * 1024), 16, 0, 0);
+  }
+  if (threadIdx.x < KB) {
+    const int k = threadIdx.x;
+    float b = NEG_BIG;
+    if (k < NK) b = a.kbias != nullptr ? a.kbias[(size_t)smp * a.Lk + k] * 1.4426950408889634f : 0.f;
+    bias_lds[k] = b;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (q0 >= a.L) return;
+
+  const float c = a.scale * 1.4426950408889634f;
+  f32x4 st[2][NKT];
+  {  // S^T = K Q^T, K fragments two key tiles ahead
+    const char* kbase = smem_attn + fl * RP + g * 16;
+    u32x4 kf[4][KS];
+    auto load_k = [&](int kt, u32x4 (&dst)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
+    };
+    load_k(0, kf[0]);
+    load_k(1, kf[1]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st[0][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[0][ks], st[0][kt]);
+        st[1][kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[1][ks], st[1][kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float inv[2];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const float4 b4 = *(const float4*)(bias_lds + 16 * kt + 4 * g);     // keys 16 kt + 4 g + r
+      st[gq][kt][0] = fmaf(st[gq][kt][0], c, b4.x);
+      st[gq][kt][1] = fmaf(st[gq][kt][1], c, b4.y);
+      st[gq][kt][2] = fmaf(st[gq][kt][2], c, b4.z);
+      st[gq][kt][3] = fmaf(st[gq][kt][3], c, b4.w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[gq][kt][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[gq][kt][r] - mx);
+        st[gq][kt][r] = p;
+        ls += p;
+      }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    inv[gq] = 1.0f / ls;
+  }
+  // O^T = V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
+  f32x4 o[2][DF];
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+    for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const char* vbase = smem_attn + IMG + (4 * g + (fl >> 2)) * RP + (fl & 3) * 8;
+#pragma unroll
+    for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+      u32x4 pb[2];
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+        pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
+                         pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const char* vb = vbase + (32 * ks2) * RP + d * 32;
+        const u32x2 lo = lds_tr16<DT>(vb);
+        const u32x2 hi = lds_tr16<DT>(vb + 16 * RP);
+        const u32x4 vfrag = {lo[0], lo[1], hi[0], hi[1]};
+        o[0][d] = mfma_k32<DT>(vfrag, pb[0], o[0][d]);
+        o[1][d] = mfma_k32<DT>(vfrag, pb[1], o[1][d]);
+      }
+    }
+  }
+#pragma unroll
+  for (int gq = 0; gq < 2; ++gq) {
+    const int q_idx = q0 + gq * 16 + fl;
+    if (q_idx < a.L) {
+      half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int dd = 16 * d + 4 * g;
+        if (dd < HD) {
+          u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]), pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
+          *(u32x2*)(orow + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int HD, int DT>
 __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
@@ -1055,8 +1230,21 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
 int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st) {
   if (a.hd != 64 && a.hd != 72) return fail(LATTE_ERR_INVALID, "cross attention: head_dim must be 64 or 72");
   if (a.L <= 0 || a.Lk <= 0 || !a.kv || a.q_ld < a.D) return fail(LATTE_ERR_INVALID, "cross attention: bad arguments");
-  dim3 block(256), grid(a.num_seq * a.heads * ((a.L + 63) / 64));
-#define XATTN_LAUNCH(HD, DT) hipLaunchKernelGGL((attn_flash_kernel<HD, DT, true>), grid, block, 0, st, a)
+  // Lk <= 128 keys (Latte-1: 120) and at least half a 256-query block per sequence: the whole-panel kernel; LATTE_XATTN_FLASH=1
+  // keeps the generic flash kernel (tests, A/B)
+  const char* force_flash = getenv("LATTE_XATTN_FLASH");
+  const bool panel = a.Lk <= 128 && a.L >= 128 && !(force_flash && atoi(force_flash) == 1);
+  constexpr int CROSS_LDS = 2 * 128 * 160 + 128 * 4;
+  dim3 block(panel ? 512 : 256), grid(panel ? a.num_seq * a.heads * ((a.L + 255) / 256) : a.num_seq * a.heads * ((a.L + 63) / 64));
+#define XATTN_LAUNCH(HD, DT)                                                                                  \
+  do {                                                                                                        \
+    if (panel) {                                                                                              \
+      static std::atomic<uint64_t> attr_done_x{0};                                                            \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_cross_kernel<HD, DT>, CROSS_LDS, attr_done_x)) return rc_; \
+      hipLaunchKernelGGL((attn_cross_kernel<HD, DT>), grid, block, CROSS_LDS, st, a);                         \
+    } else                                                                                                    \
+      hipLaunchKernelGGL((attn_flash_kernel<HD, DT, true>), grid, block, 0, st, a);                           \
+  } while (0)
   if (dtype == LATTE_DTYPE_BF16) {
     if (a.hd == 64) XATTN_LAUNCH(64, LATTE_DTYPE_BF16); else XATTN_LAUNCH(72, LATTE_DTYPE_BF16);
   } else if (dtype == LATTE_DTYPE_F16) {

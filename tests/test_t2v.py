@@ -73,12 +73,14 @@ T2V_CASES = [
     (16, 72, 1, 16, 16, 20, 128, 1),     # T = 64: flash self-attention, temporal L = 16
     (16, 72, 1, 32, 4, 120, 256, 2),     # T = 256: the full-sequence self-attention kernel, 120 text tokens (two key tiles)
     (4, 64, 2, 8, 8, 7, 64, 2),          # hd = 64, ragged text length
+    (4, 64, 1, 32, 2, 33, 64, 2),        # T = 256, hd = 64, 33 text tokens: the whole-panel cross-attention kernel at hd = 64
+    (16, 72, 1, 24, 2, 50, 64, 1),       # T = 144: a partial 256-query block in the whole-panel cross-attention kernel
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", T2V_CASES, ids=lambda c: "h%dx%d_L%d_s%d_f%d_k%d" % c[:6])
-def test_t2v_forward_matches_oracle(case):
+def test_t2v_forward_matches_oracle(case, monkeypatch):
     from oracle import latte_t2v_oracle as to
     heads, hd, layers, ss, fr, lk, cc, B = case
     cfg = to.T2VConfig(num_attention_heads=heads, attention_head_dim=hd, num_layers=layers, sample_size=ss,
@@ -100,6 +102,12 @@ def test_t2v_forward_matches_oracle(case):
     m.set_engine_option("fuse_qkv_attn", 0)
     assert torch.equal(m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample, got)
     m.set_engine_option("fuse_qkv_attn", 3)
+    # text cross-attention: sequences of >= 128 tokens with <= 128 text tokens run the whole-panel kernel (attn_cross_kernel);
+    # the generic flash kernel agrees with it to rounding (exact softmax against two key tiles with an online rescale)
+    monkeypatch.setenv("LATTE_XATTN_FLASH", "1")
+    flash = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+    monkeypatch.delenv("LATTE_XATTN_FLASH")
+    assert rel_l2(flash, want) < TOL and rel_l2(flash, got) < 2e-4
     # default operand type of LatteT2V = f16, the type the reference runs this transformer in (sample_t2x.py:29)
     md = _model(cfg, sd, None, max_batch=B).to("cuda")
     assert md.compute_dtype == "f16"
