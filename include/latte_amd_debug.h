@@ -19,6 +19,9 @@ extern "C" {
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
                      int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
 /* Attention core of latte.py:50-70 on a [rows, 3*D] qkv buffer (see AttnArgs in csrc/common.h). */
+/* Host logic only (no GPU needed): the tile / kernel variant launch_gemm picks for C[M, N] = A[M, K] W[N, K]^T with epilogue
+ * `epi` when none is forced (csrc/gemm.hip: gemm_resolve_variant; variants as for the "gemm_variant" engine option). */
+int latte_debug_gemm_choice(int M, int N, int K, int epi);
 int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U,
                           int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream);
 /* Fused QKV projection + attention core (csrc/qkv_attn.hip; latte.py:48-70 up to, not including, the output projection):

@@ -108,6 +108,7 @@ PROTOTYPES = {
     # test hooks
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),
+    "latte_debug_gemm_choice": (c_int, [c_int, c_int, c_int, c_int]),
     "latte_debug_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int,
                                       c_void]),
     "latte_debug_qkv_attention": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1194,14 +1194,13 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
       static std::atomic<uint64_t> attr_done_s{0};                                                            \
       if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
       if (a.variant >= 7 && a.variant <= 9 && HD == 72 && DT == LATTE_DTYPE_F16) {                            \
-        static std::atomic<uint64_t> attr_done_a{0};                                                          \
+        static std::atomic<uint64_t> attr_done_a[3];                                                          \
         const void* fn_ = a.variant == 7 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 7>            \
                           : a.variant == 8 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 8>          \
                                            : (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 9>;         \
-        hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS);                     \
+        if (int rc_ = ensure_dynamic_lds(fn_, STREAM_LDS, attr_done_a[a.variant - 7])) return rc_;            \
         void* args_[] = {(void*)&a};                                                                          \
         LATTE_HIP(hipLaunchKernel(fn_, grid, block, args_, STREAM_LDS, st));                                  \
-        (void)attr_done_a;                                                                                    \
       } else                                                                                                  \
       hipLaunchKernelGGL((attn_stream_kernel<HD, DT>), grid, block, STREAM_LDS, st, a);                       \
     } else if (full) {                                                                                          \

@@ -102,6 +102,7 @@ int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, int roll, hipStream_t 
 int gemm_tile_m(int variant);
 int gemm_tile_n(int variant);
 int gemm_auto_variant(int M, int N, int epi);
+int gemm_resolve_variant(int M, int N, int K, int epi);   // the variant launch_gemm runs for variant == 0
 bool gemm_small_tile_ok(int M, int N, int K);   // gated GEMM: the 128 x 144 tile (variant 13) takes it when no variant is forced
 
 // ---- attention --------------------------------------------------------------------------------

@@ -152,6 +152,8 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
   return launch_gemm(g, epi, dtype, variant, (hipStream_t)stream);
 }
 
+int latte_debug_gemm_choice(int M, int N, int K, int epi) { return gemm_resolve_variant(M, N, K, epi); }
+
 int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U, int64_t sample_stride,
                           int64_t seq_stride, int64_t row_stride, int dtype, void* stream) {
   AttnArgs a{};

@@ -1091,6 +1091,21 @@ bool gemm_small_tile_ok(int M, int N, int K) {
   return N % 144 == 0 && K % 64 == 0 && (long)((M + 127) / 128) * (N / 144) <= 256;
 }
 
+// What launch_gemm runs when no variant is forced (pure host logic; latte_debug_gemm_choice exposes it to the CPU tests).
+int gemm_resolve_variant(int M, int N, int K, int epi) {
+  if (epi == EPI_GATE_RES_F32 && gemm_small_tile_ok(M, N, K)) return 13;
+  int variant = gemm_auto_variant(M, N, epi);
+  // the gated read-modify-write GEMMs on 192-wide tiles run on the 12-wave producer / consumer kernel (gemm_pw.hip, rolling
+  // schedule): proj 127 -> 119 us, fc2 316 -> 289 us per launch in the XL/2 forward at B = 8 (same box, round-2 sweep)
+  const bool pw_ok = N % 192 == 0 && K % 64 == 0 && K >= 128 && (uint64_t)((M + 255) / 256 * 256) * K * 2 < (1ull << 32) &&
+                     (uint64_t)N * K * 2 < (1ull << 32);
+  if (variant == 8 && epi == EPI_GATE_RES_F32 && pw_ok) variant = 11;
+  if (variant == 11 && !pw_ok) variant = 8;
+  // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
+  //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
+  return variant;
+}
+
 int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream_t st) {
   GemmArgs a = a_in;
   // grouped tile order of the persistent kernel: the gated-residual GEMMs (192-wide tiles: an A K-tile is 32 KB, a W K-tile
@@ -1110,18 +1125,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     }
   }
 #endif
-  if (variant == 0 && epi == EPI_GATE_RES_F32 && gemm_small_tile_ok(a.M, a.N, a.K)) variant = 13;
-  if (variant == 0) {
-    variant = gemm_auto_variant(a.M, a.N, epi);
-    // the gated read-modify-write GEMMs on 192-wide tiles run on the 12-wave producer / consumer kernel (gemm_pw.hip, rolling
-    // schedule): proj 127 -> 119 us, fc2 316 -> 289 us per launch in the XL/2 forward at B = 8 (same box, round-2 sweep)
-    const bool pw_ok = a.N % 192 == 0 && a.K >= 128 && (uint64_t)((a.M + 255) / 256 * 256) * a.K * 2 < (1ull << 32) &&
-                       (uint64_t)a.N * a.K * 2 < (1ull << 32);
-    if (variant == 8 && epi == EPI_GATE_RES_F32 && pw_ok) variant = 11;
-    if (variant == 11 && !pw_ok) variant = 8;
-    // (start cohorts -- GemmArgs::stagger -- stay off: +7 % on the stand-alone fc1 launch, where A streams from HBM,
-    //  but -9 % inside the model, where A was just written by the LN kernel and is Infinity-Cache resident)
-  }
+  if (variant == 0) variant = gemm_resolve_variant(a.M, a.N, a.K, epi);
   if (variant == 10 || variant == 11) return launch_gemm_pw(a, epi, dtype, variant == 11, st);
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 && variant <= 9 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
