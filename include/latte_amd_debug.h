@@ -22,6 +22,13 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
 /* Host logic only (no GPU needed): the tile / kernel variant launch_gemm picks for C[M, N] = A[M, K] W[N, K]^T with epilogue
  * `epi` when none is forced (csrc/gemm.hip: gemm_resolve_variant; variants as for the "gemm_variant" engine option). */
 int latte_debug_gemm_choice(int M, int N, int K, int epi);
+/* Host logic only: 1 when the fused QKV projection + attention kernel takes the shape (csrc/qkv_attn.hip: head_dim 64 | 72,
+ * spatial mode 0: 256 tokens per frame; temporal mode 1: 16 frames and a token count that is a multiple of 16; operands inside the
+ * 4 GiB buffer-offset range), else the engine runs the separate qkv GEMM + attention kernels. */
+int latte_debug_qkv_attention_fusable(int D, int heads, int F, int T, int mode, int64_t rows);
+/* Host logic only: how the weight-gradient GEMM dW[N, K] = dY[M, N]^T X[M, K] splits its contraction (csrc/gemm_tn.hip):
+ * returns the number of partial products, *rows_per_split (a multiple of 64) rows of M each. */
+int latte_debug_gemm_tn_plan(int M, int N, int K, int* rows_per_split);
 int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U,
                           int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream);
 /* Fused QKV projection + attention core (csrc/qkv_attn.hip; latte.py:48-70 up to, not including, the output projection):

@@ -109,6 +109,8 @@ PROTOTYPES = {
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),
     "latte_debug_gemm_choice": (c_int, [c_int, c_int, c_int, c_int]),
+    "latte_debug_qkv_attention_fusable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_i64]),
+    "latte_debug_gemm_tn_plan": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     "latte_debug_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int,
                                       c_void]),
     "latte_debug_qkv_attention": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

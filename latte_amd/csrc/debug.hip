@@ -154,6 +154,17 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
 
 int latte_debug_gemm_choice(int M, int N, int K, int epi) { return gemm_resolve_variant(M, N, K, epi); }
 
+int latte_debug_qkv_attention_fusable(int D, int heads, int F, int T, int mode, int64_t rows) {
+  return heads > 0 && D % heads == 0 && qkv_attention_fusable(D, heads, D / heads, F, T, mode, rows) ? 1 : 0;
+}
+
+int latte_debug_gemm_tn_plan(int M, int N, int K, int* rows_per_split) {
+  int chunk = 0;
+  const int splits = gemm_tn_plan(M, N, K, &chunk);
+  if (rows_per_split) *rows_per_split = chunk;
+  return splits;
+}
+
 int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U, int64_t sample_stride,
                           int64_t seq_stride, int64_t row_stride, int dtype, void* stream) {
   AttnArgs a{};

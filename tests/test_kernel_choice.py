@@ -43,3 +43,30 @@ def test_choice_is_launchable(shape, epi):
         assert K >= 128 and N % 192 == 0
     if v in (12, 13):
         assert epi == 2 and ((M + 127) // 128) * (N // 144) <= 256
+
+
+def test_fused_qkv_attention_shape_rule():
+    """csrc/qkv_attn.hip: which attention blocks run as ONE projection + attention kernel (latte.py:48-70 without the qkv round
+    trip through HBM): 256 tokens per frame (spatial) / 16 frames with a multiple of 16 tokens (temporal), head_dim 64 | 72."""
+    fus = load_library().latte_debug_qkv_attention_fusable
+    rows = 8 * ROWS_PER_VIDEO
+    assert fus(1152, 16, 16, 256, 0, rows) == 1 and fus(1152, 16, 16, 256, 1, rows) == 1      # Latte-XL/2 at 256 px, both block kinds
+    assert fus(1152, 16, 16, 1024, 0, rows) == 0 and fus(1152, 16, 16, 1024, 1, rows) == 1    # Latte-1 at 512 px: temporal blocks only
+    assert fus(768, 12, 16, 256, 0, rows) == 1 and fus(384, 6, 16, 256, 1, rows) == 1         # B/2, S/2 (head_dim 64)
+    assert fus(384, 6, 4, 64, 0, 256) == 0 and fus(384, 6, 4, 64, 1, 256) == 0                # 64 tokens, 4 frames: separate kernels
+    assert fus(1152, 12, 16, 256, 0, rows) == 0                                                 # head_dim 96
+    assert fus(1152, 16, 16, 256, 0, 2 ** 21) == 0                                              # operand beyond the 4 GiB offset range
+
+
+@pytest.mark.parametrize("shape", [(20480, 768, 768), (20480, 3072, 768), (20480, 768, 3072), (128, 384, 384), (64, 1152, 1152),
+                                   (8192, 1152, 4608), (100, 384, 384)])
+def test_weight_gradient_split_plan(shape):
+    """csrc/gemm_tn.hip: the contraction of dW = dY^T X is cut into whole multiples of 64 rows, the cuts cover M exactly once,
+    and the partial products fill the chip without exceeding the trainer's workspace rule (splits * N * K floats)."""
+    import ctypes
+    M, N, K = shape
+    rows = ctypes.c_int(0)
+    splits = load_library().latte_debug_gemm_tn_plan(M, N, K, ctypes.byref(rows))
+    assert splits >= 1 and rows.value % 64 == 0 and rows.value > 0
+    assert (splits - 1) * rows.value < M <= splits * rows.value
+    assert splits * ((N + 255) // 256) * ((K + 255) // 256) <= 768
