@@ -151,6 +151,7 @@ def _attention_case(lib, dev, dt, case, mode):
         want = a.permute(0, 3, 1, 2, 4).reshape(rows, D)
         args = (B * T, F, H, hd, T, F * T, 1, T)
     out = torch.zeros(rows, D, dtype=TD[dt], device=dev)
+    torch.cuda.synchronize()    # (the block kernel needs scratch memory: its first launch must not queue behind running work)
     check(lib.latte_debug_attention(ptr(qh), ptr(out), *args, dt, stream_ptr()))
     torch.cuda.synchronize()
     rel = float((out.float() - want).norm() / want.norm())
@@ -167,6 +168,7 @@ def test_attention_forced_rescale(lib, dev):
     q, k, v = qh.float()[:, :hd], qh.float()[:, hd:2 * hd], qh.float()[:, 2 * hd:]
     want = torch.softmax((q @ k.t()).double() * hd ** -0.5, dim=-1).float() @ v
     out = torch.zeros(T, hd, dtype=TD[dt], device=dev)
+    torch.cuda.synchronize()
     check(lib.latte_debug_attention(ptr(qh), ptr(out), 1, T, 1, hd, 1, T, T, 1, dt, stream_ptr()))
     torch.cuda.synchronize()
     assert float((out.float() - want).norm() / want.norm()) < 2e-3
