@@ -58,13 +58,16 @@ class Latte(nn.Module):
     Extra keyword arguments (not in the reference): ``compute_dtype`` ("bf16" | "f16" | None: MFMA operand
     type; accumulation / residual / statistics are always fp32) and ``max_batch`` (engine workspace).
 
-    Operand-type rule (``compute_dtype=None``, the default): unguided calls use bf16 operands, GUIDED calls
-    (``forward_with_cfg`` and the fused loop driven by it) use f16 operands.  Guidance computes
-    ``eps_u + s (eps_c - eps_u)`` (latte.py:395-397): the operand rounding of the two halves is amplified by
-    ``sqrt((s - 1)^2 + s^2)`` (9.2x at the reference's scale 7) wherever the conditioning is strong enough to decorrelate
-    them, which puts bf16's 2^-9 unit roundoff above the 1e-3 parity bar on the guided output, while f16's 2^-11 stays
-    below it at the same MFMA rate (the reference's own half mode is fp16 too, sample.py:72-75).  Passing
-    ``compute_dtype`` or calling ``.to(dtype=...)`` / ``.half()`` pins one type for every call.
+    Operand-type rule (``compute_dtype=None``, the default): **f16 operands for every call** (round 4) -- the reference's
+    own half mode is fp16 too (sample.py:72-75).  What decides it is the 1e-3 parity bar on weights that look like a trained
+    checkpoint: with the adaLN-Zero gates of latte.py:178-180 at O(0.1 - 1) every block branch reaches the latents at full
+    weight and bf16's 2^-9 operand roundoff lands at ~3e-3 on the model output (S/2, B/2 and XL/2 alike), f16's 2^-11 at
+    4e-4 ... 5e-4, guided (CFG 7.0, the ``eps_u + s (eps_c - eps_u)`` combination of latte.py:395-397 amplifies the two halves'
+    rounding) below 9e-4 -- predicted on CPU by ``oracle/emulate_operands.py`` and measured on the GPU by
+    ``tests/test_gpu_parity.py::test_forward_at_trained_scale_gates`` (``profiles/r4_gate_parity.json``).  bf16 stays
+    selectable (``compute_dtype="bf16"`` / ``.to(dtype=torch.bfloat16)``): it only meets 1e-3 where the gates are <~ 0.05 (a
+    freshly initialised model) and trades that for exponent range.  Passing ``compute_dtype`` or calling
+    ``.to(dtype=...)`` / ``.half()`` pins one type for every call.
     """
 
     def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
@@ -202,8 +205,9 @@ class Latte(nn.Module):
             pass
 
     def operand_dtype(self, guided=False):
-        """MFMA operand type of a call: the pinned one, else bf16 (unguided) / f16 (guided) -- class docstring."""
-        return self.compute_dtype or ("f16" if guided else "bf16")
+        """MFMA operand type of a call: the pinned one, else f16 for guided and unguided calls alike (class docstring;
+        ``guided`` is kept in the signature for callers written against the round-3 rule)."""
+        return self.compute_dtype or "f16"
 
     # ------------------------------------------------------------------ engine management
     def engine_config(self, dtype=None):

@@ -19,6 +19,13 @@ Cases (name -> model, latent, conditioning, steps):
   b2_uncond   Latte-B/2  16 x 16x16 unconditional                  250 (ddim, ddpm)
   b2_guided   Latte-B/2  16 x 16x16 class-cond, CFG 7.0            250 (ddim, ddpm)
   xl_segment  Latte-XL/2 16 x 32x32 unconditional, B = 2            the first 24 steps of the "250" respacing (ddim)
+Round 4 -- weights at TRAINED-CHECKPOINT gate magnitudes (every tensor the reference zero-initialises drawn N(0, gate_std)
+with gate_std = 0.3 instead of 0.02: gate_msa / gate_mlp of latte.py:178-180 are then O(0.1-1) as in a trained checkpoint and
+the block branches reach the latents at full weight), and the benchmarked chain at its full length and size:
+  s2_uncond_g03, b2_uncond_g03, b2_guided_g03     as above with gate_std 0.3            250 (ddim, ddpm)
+  xl_full       Latte-XL/2 16 x 32x32 unconditional, B = 1, gate_std 0.02                250 (ddim)   -> chain250_xl.npz
+  xl_full_g03   the same with gate_std 0.3                                               250 (ddim)   -> chain250_xl.npz
+``--only a,b`` regenerates the named cases and merges them into the existing file (the XL chains take ~30 min each).
 """
 import os
 import sys
@@ -31,7 +38,9 @@ from oracle import diffusion_oracle as do
 from oracle import latte_oracle as lo
 from oracle.reference_loader import load_reference_diffusion, load_reference_latte
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "chain250.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.path.join(GOLDEN, "chain250.npz")
+OUT_XL = os.path.join(GOLDEN, "chain250_xl.npz")      # the full-length XL/2 chains (kept apart: generated separately)
 
 CFG_SCALE = 7.0
 EVERY = 50
@@ -44,7 +53,19 @@ CASES = {
     "b2_guided": ("Latte-B/2", dict(input_size=16, num_frames=16, num_classes=101, extras=2), 41, 42, 43, 1, [5], 250,
                   ("ddim", "ddpm")),
     "xl_segment": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 51, 52, 53, 2, None, 24, ("ddim",)),
+    "s2_uncond_g03": ("Latte-S/2", dict(input_size=8, num_frames=4, extras=1), 61, 62, 63, 1, None, 250, ("ddim", "ddpm")),
+    "b2_uncond_g03": ("Latte-B/2", dict(input_size=16, num_frames=16, extras=1), 71, 72, 73, 1, None, 250, ("ddim", "ddpm")),
+    "b2_guided_g03": ("Latte-B/2", dict(input_size=16, num_frames=16, num_classes=101, extras=2), 81, 82, 83, 1, [5], 250,
+                      ("ddim", "ddpm")),
+    "xl_full": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 91, 92, 93, 1, None, 250, ("ddim",)),
+    "xl_full_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 101, 102, 103, 1, None, 250, ("ddim",)),
 }
+GATE_STD = {"s2_uncond_g03": 0.3, "b2_uncond_g03": 0.3, "b2_guided_g03": 0.3, "xl_full_g03": 0.3}   # default 0.02
+XL_FILE_CASES = ("xl_full", "xl_full_g03")
+
+
+def case_file(name):
+    return OUT_XL if name in XL_FILE_CASES else OUT
 
 
 def case_inputs(name):
@@ -52,7 +73,7 @@ def case_inputs(name):
     x0 = cat([z, z]), y = [labels..., null class...] (sample/sample.py:92-99)."""
     preset, kw, wseed, xseed, nseed, B, labels, steps, methods = CASES[name]
     cfg = lo.preset_config(preset, **kw)
-    sd = lo.init_state_dict(cfg, seed=wseed)
+    sd = lo.init_state_dict(cfg, seed=wseed, gate_std=GATE_STD.get(name, 0.02))
     g = torch.Generator("cpu").manual_seed(xseed)
     z = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
     if labels is None:
@@ -74,9 +95,21 @@ def main():
     a = [torch.randn_like(torch.empty(2, 3, 5)) for _ in range(3)]
     b = chain_noises(99, (2, 3, 5), 3)
     assert all(torch.equal(p, q) for p, q in zip(a, b))
-    arrays = {}
+    only = None
+    for i, a in enumerate(sys.argv):
+        if a == "--only":
+            only = set(sys.argv[i + 1].split(","))
+    arrays = {OUT: {}, OUT_XL: {}}
+    for path in arrays:
+        if only is not None and os.path.exists(path):      # merge into what is there
+            with np.load(path) as z:
+                arrays[path] = {k: z[k] for k in z.files}
     for name in CASES:
-        if name == "xl_segment" and "--skip-xl" in sys.argv:
+        if only is not None and name not in only:
+            continue
+        if name.startswith("xl") and "--skip-xl" in sys.argv:
+            continue
+        if only is None and name in XL_FILE_CASES:       # the long chains only on request
             continue
         preset, kw, cfg, sd, x0, y, steps, methods, nseed = case_inputs(name)
         model = rl.Latte_models[preset](**kw).eval()
@@ -98,8 +131,8 @@ def main():
                         keep.append((k, r["sample"].clone()))
                     if k + 1 == steps:
                         break
-            arrays[f"{name}::{method}::steps"] = np.asarray([k for k, _ in keep], dtype=np.int64)
-            arrays[f"{name}::{method}::samples"] = torch.stack([v for _, v in keep]).numpy()
+            arrays[case_file(name)][f"{name}::{method}::steps"] = np.asarray([k for k, _ in keep], dtype=np.int64)
+            arrays[case_file(name)][f"{name}::{method}::samples"] = torch.stack([v for _, v in keep]).numpy()
             msg = f"{name} {method}: {steps} reference steps in {time.time() - t0:.1f}s, |x_final| rms {float(keep[-1][1].pow(2).mean().sqrt()):.3f}"
             if not name.startswith("xl"):   # the oracle beside the reference (pin over the full chain length)
                 nz = chain_noises(nseed, x0.shape, steps)
@@ -113,8 +146,10 @@ def main():
                 msg += f"; oracle loop vs reference loop rel-L2 {err:.2e}"
                 assert err < 1e-6, err
             print(msg, flush=True)
-    np.savez_compressed(OUT, **arrays)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    for path, arr in arrays.items():
+        if arr:
+            np.savez_compressed(path, **arr)
+            print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

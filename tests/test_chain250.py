@@ -2,10 +2,15 @@
 the REAL reference (tests/golden/chain250.npz, generator oracle/make_chain_golden.py: reference Latte module under the
 reference's SpacedDiffusion loops, gaussian_diffusion.py:423-515 / :604-684 driven as sample/sample.py:67,100-107 does).
 
-Operand types are the shim's default rule (latte_amd.Latte docstring): unguided chains bf16 (the benchmarked path), guided
-chains (CFG 7.0 through forward_with_cfg) f16.  Tolerance: north_star's 1e-3 relative on the denoised latents, asserted
-after every 50th step and on the final latents; the measured drift per checkpoint is written to
-gpurun_out/chain250_drift.json (copied to profiles/ by the round script).
+Operand type: the shim's default (latte_amd.Latte docstring; f16 for every call since round 4).  Tolerance: north_star's 1e-3
+relative on the denoised latents, asserted after every 50th step and on the final latents; the measured drift per checkpoint
+is written to gpurun_out/chain250_drift.json (copied to profiles/ by the round script).
+
+Round 4 adds (a) the same chains on weights at trained-checkpoint gate magnitudes (``*_g03``: every tensor the reference
+zero-initialises drawn N(0, 0.3), so the gates of latte.py:178-180 are O(0.1 - 1) and the operand rounding of every block
+reaches the latents at full weight) and (b) the benchmarked chain at its full length and size: DDIM-250 of Latte-XL/2 at
+16 x 32 x 32 latents run by the reference (tests/golden/chain250_xl.npz), default gates and gate_std 0.3.  bf16 chains are run
+beside the default type on the unguided cases and recorded (asserted only at the near-zero gates where bf16 is a 1e-3 type).
 """
 import json
 import os
@@ -21,7 +26,8 @@ from latte_amd._lib import check, load_library, ptr, stream_ptr
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
-CHAIN = [(n, m) for n in ("s2_uncond", "s2_guided", "b2_uncond", "b2_guided") for m in ("ddim", "ddpm")] + [("xl_segment", "ddim")]
+CHAIN = [(n, m) for n in ("s2_uncond", "s2_guided", "b2_uncond", "b2_guided", "s2_uncond_g03", "b2_uncond_g03", "b2_guided_g03")
+         for m in ("ddim", "ddpm")] + [("xl_segment", "ddim"), ("xl_full", "ddim"), ("xl_full_g03", "ddim")]
 
 
 def _record(key, drift):
@@ -36,19 +42,32 @@ def _record(key, drift):
         json.dump(tab, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("name,method", CHAIN, ids=[f"{n}-{m}" for n, m in CHAIN])
-def test_chain_matches_reference_chain(name, method):
-    from oracle.make_chain_golden import CFG_SCALE, case_inputs, chain_noises
-    z = np.load(os.path.join(GOLDEN, "chain250.npz"))
+def _dtypes(name):
+    """Operand types run for a case: the default (None -> f16) everywhere; bf16 beside it on the unguided small cases."""
+    return [None, "bf16"] if ("uncond" in name or name == "xl_segment") else [None]
+
+
+CHAIN_DT = [(n, m, cd) for n, m in CHAIN for cd in _dtypes(n)]
+
+
+@pytest.mark.parametrize("name,method,cd", CHAIN_DT, ids=[f"{n}-{m}-{cd or 'default'}" for n, m, cd in CHAIN_DT])
+def test_chain_matches_reference_chain(name, method, cd):
+    from oracle.make_chain_golden import CFG_SCALE, GATE_STD, case_file, case_inputs, chain_noises
+    path = case_file(name)
+    if not os.path.exists(path):
+        pytest.skip("fixture file not generated")
+    z = np.load(path)
     if f"{name}::{method}::samples" not in z.files:
         pytest.skip("fixture case not generated")
     preset, kw, cfg, sd, x0, y, steps, methods, nseed = case_inputs(name)
     guided = y is not None
     rows = x0.shape[0]
-    m = latte_amd.Latte_models[preset](max_batch=rows, **kw)          # compute_dtype=None: bf16 unguided, f16 guided
+    m = latte_amd.Latte_models[preset](max_batch=rows, compute_dtype=cd, **kw)          # compute_dtype=None: f16
     m.load_state_dict(sd)
     m = m.cuda()
-    assert m.operand_dtype(guided) == ("f16" if guided else "bf16")
+    assert m.operand_dtype(guided) == (cd or "f16")
+    # bf16 holds 1e-3 only at near-zero gates: at trained-scale gates it is measured and recorded, with a sanity bound
+    tol = TOL if (cd is None or name not in GATE_STD) else 2e-2
     d = latte_amd.create_diffusion("250")
     xx = x0.cuda().contiguous()
     nz = torch.stack(chain_noises(nseed, x0.shape, steps)).cuda().contiguous()
@@ -66,4 +85,4 @@ def test_chain_matches_reference_chain(name, method):
     print(name, method, drift)
     assert int(ks[-1]) == steps - 1 and torch.equal(xx, ts[-1])
     for k, e in drift.items():
-        assert e < TOL, (k, e)
+        assert e < tol, (k, e)

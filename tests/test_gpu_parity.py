@@ -131,6 +131,92 @@ def test_forward_matches_oracle(case, cd):
     assert rel_l2(out[:, :, :4], ref[:, :, :4]) < TOL       # the epsilon channels on their own
 
 
+# Weights that look like a TRAINED checkpoint (round 4).  The reference zero-initialises the adaLN modulation and the final
+# layer (latte.py:284-295); the synthetic recipe re-draws them N(0, 0.02), which leaves every gate_msa / gate_mlp
+# (latte.py:178-180) at ~0.03 and damps the block branches ~30x before they reach the output.  A trained checkpoint
+# (sample/sample.py:62-64) has gates of O(0.1 - 1): here those tensors are drawn N(0, gate_std) with gate_std up to 1.0, so the
+# half-precision rounding of every block linear reaches the model output at full weight.
+GATE_CASES = [
+    ("Latte-S/2", dict(input_size=16, num_frames=8, extras=1), 1),
+    ("Latte-B/2", dict(input_size=16, num_frames=16, extras=1), 1),
+    ("Latte-S/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 2),    # fused qkv + attention kernel, hd = 64
+    ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 1),    # headline size
+]
+BF16_TOL_AT_TRAINED_GATES = 1e-2   # bf16 is NOT a 1e-3 type at these gates (measured ~3e-3, recorded); sanity bound only
+
+
+def _record_gate(key, val):
+    import json
+    import os
+    from _util import ROOT
+    path = os.path.join(ROOT, "gpurun_out", "gate_parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tab = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            tab = json.load(f)
+    tab[key] = val
+    with open(path, "w") as f:
+        json.dump(tab, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("gate_std", [0.1, 0.3, 1.0])
+@pytest.mark.parametrize("case", GATE_CASES, ids=lambda c: f"{c[0]}-{c[1]['input_size']}x{c[1]['num_frames']}")
+def test_forward_at_trained_scale_gates(case, gate_std):
+    """f16 operands (the default type) hold north_star's 1e-3 on the model output AND on its epsilon channels at every gate
+    magnitude; bf16 is measured beside it and written to gpurun_out/gate_parity.json (-> profiles/r4_gate_parity.json)."""
+    from oracle import latte_oracle as lo
+    name, kw, B = case
+    cfg = lo.preset_config(name, **kw)
+    sd = lo.init_state_dict(cfg, seed=0, gate_std=gate_std)
+    g = torch.Generator("cpu").manual_seed(1)
+    x = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
+    t = torch.tensor([999, 12][:B])
+    y = torch.tensor([7, kw.get("num_classes", 0)][:B]) if kw["extras"] == 2 else None
+    with torch.no_grad():
+        ref = lo.latte_forward(sd, cfg, x, t, y)
+    err = {}
+    for cd in ("f16", "bf16"):
+        m = latte_amd.Latte_models[name](compute_dtype=cd, max_batch=B, **kw)
+        m.load_state_dict(sd)
+        m = m.cuda()
+        out = m(x.cuda(), t.cuda(), y=None if y is None else y.cuda())
+        assert torch.isfinite(out).all()
+        err[cd] = (rel_l2(out, ref), rel_l2(out[:, :, :4], ref[:, :, :4]))
+        del m
+    _record_gate(f"forward::{name}::{kw['input_size']}x{kw['num_frames']}::gate_std={gate_std}",
+                 {"f16": err["f16"][0], "f16_eps": err["f16"][1], "bf16": err["bf16"][0], "bf16_eps": err["bf16"][1]})
+    print(name, gate_std, err)
+    assert err["f16"][0] < TOL and err["f16"][1] < TOL, err
+    assert err["bf16"][0] < BF16_TOL_AT_TRAINED_GATES, err
+
+
+@pytest.mark.parametrize("gate_std", [0.3, 1.0])
+def test_guided_forward_at_trained_scale_gates(gate_std):
+    """forward_with_cfg (latte.py:379-398) at CFG 7.0 with trained-scale gates: the guidance combination amplifies the two
+    halves' operand rounding; f16 (default type) stays under 1e-3 on the guided output, XL/2 at the headline latent size."""
+    from oracle import latte_oracle as lo
+    name, kw = "Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2)
+    cfg = lo.preset_config(name, **kw)
+    sd = lo.init_state_dict(cfg, seed=0, gate_std=gate_std)
+    g = torch.Generator("cpu").manual_seed(1)
+    z = torch.randn(1, 16, 4, 32, 32, generator=g)
+    x = torch.cat([z, z])
+    t = torch.tensor([500, 500])
+    y = torch.tensor([7, 101])
+    with torch.no_grad():
+        ref = lo.latte_forward_with_cfg(sd, cfg, x, t, y, 7.0)
+    m = latte_amd.Latte_models[name](max_batch=2, **kw)       # default operand type
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert m.operand_dtype(guided=True) == "f16"
+    out = m.forward_with_cfg(x.cuda(), t.cuda(), y=y.cuda(), cfg_scale=7.0)
+    e = (rel_l2(out, ref), rel_l2(out[:, :, :4], ref[:, :, :4]))
+    _record_gate(f"guided_forward::{name}::32x16::gate_std={gate_std}", {"f16": e[0], "f16_eps": e[1]})
+    print(gate_std, e)
+    assert e[0] < TOL and e[1] < TOL, e
+
+
 @pytest.mark.parametrize("cd", DTYPES)
 def test_ddim10_plumbing_config_matches_oracle(cd):
     """BASELINE.json configs[0]: Latte-S/2, 4 frames, DDIM 10 steps, batch 1 — denoised latents."""
