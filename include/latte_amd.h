@@ -241,12 +241,23 @@ int latte_trainer_num_stages(const latte_trainer_t* e);
 int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offset, int64_t* numel);
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream);
 /* clip_grad_norm_ (utils.py:72-117: total 2-norm, g *= min(max_norm / (norm + 1e-6), 1) when clip != 0) + AdamW + update_ema
- * (utils.py:191-200) on the bound buffers; step counts from 1; norm_out: optional device float[2] = {norm, applied coefficient} */
+ * (utils.py:191-200) on the bound buffers.  `step`: AdamW's bias-correction step when >= 1; 0 = the trainer's own count of APPLIED
+ * updates (what torch.optim.AdamW does: a fresh optimiser state starts at 1 even when the training-step counter continues from a
+ * checkpoint, train.py:195-196 -- the count that drives clipping and logging stays with the caller).  A NON-FINITE gradient norm
+ * (overflow of the loss-scaled f16 backward or of an f16 activation; impossible in the reference's fp32 range) skips the update:
+ * parameters, moments and EMA stay untouched, the gradients are zeroed, norm_out reports the non-finite norm with coefficient 0.
+ * norm_out: optional device float[2] = {norm, applied coefficient} */
 /* "loss_scale" (a power of two in [1, 2^24]): d loss / d model_output is multiplied by it before the backward and every finished
  * gradient slice by its inverse, so that the half-precision gradient operands stay inside the operand type's range.  Default: 1 with
  * bf16 operands, 16384 with f16 operands -- f16's 10 mantissa bits are the precision class of the TF32 matmuls the reference trains
- * with (train.py:12-14 allow_tf32), bf16 has 7; the reference itself needs no scaling because it keeps fp32 ranges. */
+ * with (train.py:12-14 allow_tf32), bf16 has 7; the reference itself needs no scaling because it keeps fp32 ranges.
+ * "dynamic_loss_scale" (0 / 1; default 1 with f16, 0 with bf16): a skipped update halves the scale (floor 1), and
+ * "loss_scale_growth_interval" (default 2000) applied updates in a row double it (cap max(initial scale, 2^16)) -- all on the
+ * device, no host round trip.  Setting "loss_scale" restarts from that value. */
 int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value);
+/* out8 (host) = {loss scale, applied updates since it changed, applied updates in total, skipped updates, last call skipped (0/1),
+ * dynamic (0/1), growth interval, largest scale}.  Synchronises the device: for logging and tests, not for the step path. */
+int latte_trainer_scaler_state(latte_trainer_t* e, double* out8);
 int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                  float clip_max_norm, int clip, float ema_decay, float* norm_out, void* stream);
 

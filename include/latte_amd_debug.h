@@ -95,6 +95,16 @@ int latte_debug_vae_trace(struct latte_vae* v, const float* z, int n_frames, flo
  * workgroup 0 (s_memtime ticks, summed over the bursts). */
 int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, int reps, void* stream);
 
+/* Kernel-choice overrides for the A/B tests (process-global; value 0 restores the library's own choice).  Every offered value
+ * selects another implementation of the SAME function (results equal up to rounding):
+ *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too
+ *   "xattn_flash"     1 = the generic flash kernel for text cross-attention instead of the whole-panel kernel
+ *   "tn_kernel"       4 = the 4-wave weight-gradient GEMM;   "tn_wn" 4 = its 256 x 128 tile
+ *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too
+ * Anything else is refused (LATTE_ERR_INVALID).  Replaces the LATTE_* environment variables round 3 read at every launch; the
+ * measurement ablations whose results are garbage (attention variants 7-9) exist only in a LATTE_DEBUG_BUILD=1 library. */
+int latte_debug_set_choice(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

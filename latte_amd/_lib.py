@@ -85,6 +85,7 @@ PROTOTYPES = {
     "latte_trainer_backward_stage": (c_int, [c_void, c_int, c_void]),
     "latte_trainer_optimizer_step": (c_int, [c_void, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_int, c_f32, c_void, c_void]),
     "latte_trainer_set_option": (c_int, [c_void, c_char, ctypes.c_double]),
+    "latte_trainer_scaler_state": (c_int, [c_void, ctypes.POINTER(ctypes.c_double)]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),
@@ -125,6 +126,7 @@ PROTOTYPES = {
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),
     "latte_debug_fill_normal": (c_int, [c_void, c_i64, c_u64, c_u64, c_void]),
     "latte_debug_tr16_probe": (c_int, [c_void, c_void]),
+    "latte_debug_set_choice": (c_int, [c_char, c_int]),
     "latte_debug_dma_probe": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
     "latte_debug_conv3x3": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void]),

@@ -440,207 +440,16 @@ __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// attn_blocks : L > 256 (the 1024-token spatial attention of Latte-1 / the 512-pixel class-conditional models,
-// latte_t2v.py:804-907).  The attn_full machinery -- LDS-DMA staging of row-major K / V images, pipelined fragment reads,
-// V^T through ds_read_b64_tr_b16, swapped QK^T with the softmax statistics in two cross-lane steps -- applied to 256-key
-// BLOCKS with an online softmax across blocks.  One workgroup = (sequence, head, 128 consecutive queries): a wave owns 32
-// queries (two 16-query MFMA column groups) for the whole key loop, so its output
-// accumulators and running (max, sum) stay in registers; per key block all four waves stage the block (2 x 40 KB, two
-// workgroups per CU: one stages while the other computes), compute S^T for it, rescale and accumulate.
-// The running maximum is kept on the RAW scores (the scale is positive), rescale factor alpha = exp2((m_old - m_new) c);
-// every block rescales unconditionally (no deferred-max threshold), so a late dominant key is exact by construction.
-template <int HD, int DT>
-__global__ void __launch_bounds__(256, 2) attn_blocks_kernel(AttnArgs a) {
-  constexpr int KS = (HD + 31) / 32;
-  constexpr int DF = (HD + 15) / 16;
-  constexpr int NCH = HD / 8;
-  constexpr int RP = 160;
-  constexpr int NKT = 16;            // 16-key tiles per 256-key block
-  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
-  char* const k_lds = smem_attn;
-  char* const v_lds = smem_attn + 256 * RP;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fl = lane & 15, g = lane >> 4;
-  const int qblocks = (a.L + 127) >> 7;
-  // block -> (sequence, head, query block): the query blocks and heads of one sequence stay on ONE XCD (K / V of a head
-  // are re-read by its L / 128 query blocks out of that XCD's L2; head slices of a token row share 128-byte lines)
-  int seq, head, qb;
-  {
-    int b = blockIdx.x;
-    const int per_seq = a.heads * qblocks;
-    if ((a.num_seq & 7) == 0) {
-      const int xcd = b & 7, slot = b >> 3;
-      seq = (slot / per_seq) * 8 + xcd;
-      b = slot % per_seq;
-    } else {
-      seq = b / per_seq;
-      b = b % per_seq;
-    }
-    head = b / qblocks;
-    qb = b % qblocks;
-  }
-  const int64_t base = seq_base_row(a, seq);
-  const size_t ld = (size_t)3 * a.D;
-  const half_t* qkv_h = a.qkv + (size_t)head * HD;
-  const int q0 = qb * 128 + wave * 32;            // first query of this wave
-  const int nkb = (a.L + 255) >> 8;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-  auto stage = [&](int kb) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int inst = wave_u * 10 + j;
-      const int idx = inst * 64 + lane;
-      const int key = idx / 10, ch = idx - key * 10;
-      const int key_ld = min(kb * 256 + key, a.L - 1), ch_ld = min(ch, NCH - 1);
-      const half_t* rowp = qkv_h + (size_t)(base + (int64_t)key_ld * a.row_stride) * ld + ch_ld * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + a.D),
-                                       (__attribute__((address_space(3))) void*)(k_lds + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + 2 * a.D),
-                                       (__attribute__((address_space(3))) void*)(v_lds + inst * 1024), 16, 0, 0);
-    }
-  };
-  stage(0);
-  // Q fragments of the two 16-query groups (B operand of S^T = K Q^T), fetched under the first staging DMA
-  u32x4 qf[2][KS];
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq) {
-    const int q_ld = min(q0 + gq * 16 + fl, a.L - 1);
-    const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int ch = g + 4 * ks;
-      qf[gq][ks] = (u32x4){0u, 0u, 0u, 0u};
-      if (ch < NCH) qf[gq][ks] = *(const u32x4*)(qrow + ch * 8);
-    }
-  }
-  const float c = a.scale * 1.4426950408889634f;
-  const char* kbase = k_lds + fl * RP + g * 16;
-  const char* vbase = v_lds + (4 * g + (fl >> 2)) * RP + (fl & 3) * 8;
-  f32x4 o[2][DF];
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-    for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
-  const bool wave_active = q0 < a.L;     // waves without queries still stage and keep the barriers
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                      // block kb has landed for everybody
-    if (wave_active) {
-      const int kleft = a.L - kb * 256;   // keys of this block that exist (ragged last block)
-      // The two 16-query groups of the wave go through the block one after the other (QK^T -> softmax -> PV each): the 64
-      // scores of ONE group are live at a time next to both groups' output accumulators, which keeps the wave inside the
-      // 256-register budget of two waves per SIMD (both groups at once, as attn_full_kernel does, spills 31 registers here).
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq) {
-        f32x4 st[NKT];
-        u32x4 kf[4][KS];
-        auto load_k = [&](int kt, u32x4 (&dst)[KS]) {
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + kt * 16 * RP + ks * 64);
-        };
-        load_k(0, kf[0]);
-        load_k(1, kf[1]);
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
-          __builtin_amdgcn_sched_barrier(0);
-          st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) st[kt] = mfma_k32<DT>(kf[kt & 3][ks], qf[gq][ks], st[kt]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kleft < 256) {
-#pragma unroll
-          for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (16 * kt + 4 * g + r >= kleft) st[kt][r] = NEG_BIG;
-        }
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[gq], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[gq] - m_new) * c);   // first block: exp2(-huge) = 0 on o = l = 0
-        const float nm = -m_new * c;
-        float ls = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c, nm));
-            st[kt][r] = p;
-            ls += p;
-          }
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
-        l_run[gq] = l_run[gq] * alpha + ls;
-        m_run[gq] = m_new;
-#pragma unroll
-        for (int d = 0; d < DF; ++d) o[gq][d] *= alpha;
-        // O^T += V^T P^T ; k-slot (8g + i) <-> key 32 ks2 + (i < 4 ? 4g + i : 16 + 4g + i - 4)
-        u32x4 vfr[2][DF];
-        auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
-#pragma unroll
-          for (int d = 0; d < DF; ++d) {
-            const u32x2 lo = lds_tr16<DT>(vbase + (32 * ks2) * RP + d * 32);
-            const u32x2 hi = lds_tr16<DT>(vbase + (32 * ks2 + 16) * RP + d * 32);
-            dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-          }
-        };
-        load_v(0, vfr[0]);
-#pragma unroll
-        for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
-          if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
-          const u32x4 pb = {pack2<DT>(st[2 * ks2][0], st[2 * ks2][1]), pack2<DT>(st[2 * ks2][2], st[2 * ks2][3]),
-                            pack2<DT>(st[2 * ks2 + 1][0], st[2 * ks2 + 1][1]), pack2<DT>(st[2 * ks2 + 1][2], st[2 * ks2 + 1][3])};
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int d = 0; d < DF; ++d) o[gq][d] = mfma_k32<DT>(vfr[ks2 & 1][d], pb, o[gq][d]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    if (kb + 1 < nkb) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();                    // everybody is done reading block kb: its LDS image may be overwritten
-      stage(kb + 1);
-    }
-  }
-#pragma unroll
-  for (int gq = 0; gq < 2; ++gq) {
-    const int q_idx = q0 + gq * 16 + fl;
-    if (q_idx < a.L) {
-      const float inv = 1.0f / l_run[gq];
-      half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
-#pragma unroll
-      for (int d = 0; d < DF; ++d) {
-        const int dd = 16 * d + 4 * g;
-        if (dd < HD) {
-          u32x2 pk = {pack2<DT>(o[gq][d][0] * inv, o[gq][d][1] * inv), pack2<DT>(o[gq][d][2] * inv, o[gq][d][3] * inv)};
-          *(u32x2*)(orow + dd) = pk;
-        }
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// attn_stream (round 3) : L > 256.  attn_blocks_kernel stages a 256-key block, waits, computes, and restages -- staging and
-// compute take turns inside a workgroup (two workgroups per CU cover part of it), and every K / V block is staged once per
-// 128-query workgroup: at Latte-1 (L = 1024) 1.3 GB of L2 -> LDS traffic per launch, 300 us for 155 GFLOP.  Here one 8-wave
+// attn_stream (round 3) : L > 256 (the 1024-token spatial attention of Latte-1 / the 512-pixel class-conditional models,
+// latte_t2v.py:804-907).  (The round-2 kernel for this shape, attn_blocks_kernel -- stage a 256-key block, wait, compute, restage,
+// 128 queries per workgroup: 1.3 GB of L2 -> LDS traffic per launch at Latte-1, 278-300 us for 155 GFLOP -- was REMOVED in round 4:
+// it was the only kernel of the library that used scratch memory, and its first launch behind a running streaming kernel ended
+// twice in an unexplained GPU memory fault; a kernel that may fault depending on queue state has no place in
+// the library, `git show 513ac9e:latte_amd/csrc/attention.hip` has it.)  Here one 8-wave
 // workgroup per CU owns 256 queries (32 per wave, two 16-query MFMA column groups sharing every fragment read) and STREAMS the
 // keys through a ring of three 128-key blocks (K image | V image, 40 KB each): the LDS DMA of blocks kb + 1 and kb + 2 is in
 // flight while block kb is multiplied (counted vmcnt, one barrier per block), and each block is staged half as often.
-// Online softmax across blocks as in attn_blocks_kernel (running max on the raw scores, unconditional rescale).
+// Online softmax across blocks: running max on the raw scores (the scale is positive), alpha = exp2((m_old - m_new) c).
 // The V^T fragments come from the transpose read in its inline-assembly form: in front of the builtin hipcc drains every LDS
 // DMA in flight (see gemm_tn.hip), which would serialise the ring again.
 template <int OFF>
@@ -1171,28 +980,22 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
   if (a0.L <= 0) return fail(LATTE_ERR_INVALID, "attention: empty sequence");
   const bool small = a0.L <= 16;
   AttnArgs a = a_in;
-  if (const char* ab = getenv("LATTE_ATTN_ABLATE")) a.variant = atoi(ab);   // measurement only (tools/attn_pmc.py)
-  // variant 1 forces the generic flash kernel (tests); variant 4 (measurement) sends 128 < L <= 256 to the block kernel
-  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1 && a.variant != 4 && a.variant != 5;
-  // L > 256: the streaming kernel (8 waves, 256 queries, ring of 128-key blocks); variant 4 keeps the stage-then-compute block
-  // kernel reachable (tests, A/B measurements), variant 5 forces the streaming kernel for 128 < L <= 256 as well
-  // (its per-lane source offsets are 32-bit: 128 rows of a block must span less than 2 GiB)
+  // kernel-choice override of the A/B tests (latte_debug_set_choice("attn_variant", v), include/latte_amd_debug.h): 1 = the generic
+  // flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 as well.  Every choice computes the same function;
+  // the measurement ablations that do not (7-9: no softmax / no waits / no staging) exist in the LATTE_DEBUG_BUILD library only.
+  if (const int ov = debug_choice(DBG_ATTN_VARIANT)) a.variant = ov;
+  const bool full = a.L > 128 && a.L <= 256 && a.variant != 1 && a.variant != 5;
+  // L > 256: the streaming kernel (8 waves, 256 queries, ring of 128-key blocks); its per-lane source offsets are 32-bit: 128 rows
+  // of a block must span less than 2 GiB, otherwise the generic flash kernel runs
   const bool stream_ok = (int64_t)a.row_stride * 3 * a.D * 2 * 128 < (1ll << 31);
-  const bool stream = stream_ok && ((a.L > 256 && a.variant != 1 && a.variant != 4) || (a.L > 128 && a.variant == 5));
-  const bool blocks = !stream && ((a.L > 256 && a.variant != 1) || (a.L > 128 && a.variant == 4));   // 256-key blocks + online softmax
+  const bool stream = stream_ok && ((a.L > 256 && a.variant != 1) || (a.L > 128 && a.variant == 5));
   constexpr int FULL_LDS = 2 * 256 * 160, STREAM_LDS = 3 * 2 * 128 * 160;
   dim3 block(stream ? 512 : 256);
   dim3 grid = small ? dim3((a.num_seq * a.heads + 3) / 4)
                     : (full && !stream ? dim3(a.num_seq * a.heads)
-                            : (stream ? dim3(a.num_seq * a.heads * ((a.L + 255) / 256))
-                               : (blocks ? dim3(a.num_seq * a.heads * ((a.L + 127) / 128)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64)))));
-#define ATTN_LAUNCH(HD, DT)                                                                                   \
-  do {                                                                                                        \
-    if (small)                                                                                                \
-      hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);                                 \
-    else if (stream) {                                                                                        \
-      static std::atomic<uint64_t> attr_done_s{0};                                                            \
-      if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
+                            : (stream ? dim3(a.num_seq * a.heads * ((a.L + 255) / 256)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64))));
+#ifdef LATTE_GEMM_ABLATE
+#define ATTN_STREAM_ABLATIONS(HD, DT)                                                                         \
       if (a.variant >= 7 && a.variant <= 9 && HD == 72 && DT == LATTE_DTYPE_F16) {                            \
         static std::atomic<uint64_t> attr_done_a[3];                                                          \
         const void* fn_ = a.variant == 7 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 7>            \
@@ -1201,16 +1004,23 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
         if (int rc_ = ensure_dynamic_lds(fn_, STREAM_LDS, attr_done_a[a.variant - 7])) return rc_;            \
         void* args_[] = {(void*)&a};                                                                          \
         LATTE_HIP(hipLaunchKernel(fn_, grid, block, args_, STREAM_LDS, st));                                  \
-      } else                                                                                                  \
+      } else
+#else
+#define ATTN_STREAM_ABLATIONS(HD, DT)
+#endif
+#define ATTN_LAUNCH(HD, DT)                                                                                   \
+  do {                                                                                                        \
+    if (small)                                                                                                \
+      hipLaunchKernelGGL((attn_small_kernel<HD, DT>), grid, block, 0, st, a);                                 \
+    else if (stream) {                                                                                        \
+      static std::atomic<uint64_t> attr_done_s{0};                                                            \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
+      ATTN_STREAM_ABLATIONS(HD, DT)                                                                           \
       hipLaunchKernelGGL((attn_stream_kernel<HD, DT>), grid, block, STREAM_LDS, st, a);                       \
     } else if (full) {                                                                                          \
       static std::atomic<uint64_t> attr_done{0};                                                              \
       if (int rc_ = ensure_dynamic_lds((const void*)attn_full_kernel<HD, DT>, FULL_LDS, attr_done)) return rc_; \
       hipLaunchKernelGGL((attn_full_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                           \
-    } else if (blocks) {                                                                                      \
-      static std::atomic<uint64_t> attr_done_b{0};                                                            \
-      if (int rc_ = ensure_dynamic_lds((const void*)attn_blocks_kernel<HD, DT>, FULL_LDS, attr_done_b)) return rc_; \
-      hipLaunchKernelGGL((attn_blocks_kernel<HD, DT>), grid, block, FULL_LDS, st, a);                         \
     } else                                                                                                    \
       hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);                                 \
   } while (0)
@@ -1222,6 +1032,7 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
     return fail(LATTE_ERR_INVALID, "attention: unknown dtype");
   }
 #undef ATTN_LAUNCH
+#undef ATTN_STREAM_ABLATIONS
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -1229,10 +1040,9 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
 int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st) {
   if (a.hd != 64 && a.hd != 72) return fail(LATTE_ERR_INVALID, "cross attention: head_dim must be 64 or 72");
   if (a.L <= 0 || a.Lk <= 0 || !a.kv || a.q_ld < a.D) return fail(LATTE_ERR_INVALID, "cross attention: bad arguments");
-  // Lk <= 128 keys (Latte-1: 120) and at least half a 256-query block per sequence: the whole-panel kernel; LATTE_XATTN_FLASH=1
+  // Lk <= 128 keys (Latte-1: 120) and at least half a 256-query block per sequence: the whole-panel kernel; latte_debug_set_choice("xattn_flash", 1)
   // keeps the generic flash kernel (tests, A/B)
-  const char* force_flash = getenv("LATTE_XATTN_FLASH");
-  const bool panel = a.Lk <= 128 && a.L >= 128 && !(force_flash && atoi(force_flash) == 1);
+  const bool panel = a.Lk <= 128 && a.L >= 128 && debug_choice(DBG_XATTN_FLASH) != 1;
   constexpr int CROSS_LDS = 2 * 128 * 160 + 128 * 4;
   dim3 block(panel ? 512 : 256), grid(panel ? a.num_seq * a.heads * ((a.L + 255) / 256) : a.num_seq * a.heads * ((a.L + 63) / 64));
 #define XATTN_LAUNCH(HD, DT)                                                                                  \

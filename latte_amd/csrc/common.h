@@ -181,7 +181,15 @@ int launch_adaln_single(const float* tables /* [nblk, 6, D] */, const float* hea
 // out[b, f, c, :] = in[b, c, f, :] (to_bfc = 1) or out[b, c, f, :] = in[b, f, c, :] (to_bfc = 0); hw contiguous floats
 int launch_permute_cf(const float* in, float* out, int B, int C, int F, int hw, int to_bfc, hipStream_t st);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+// Kernel-choice overrides of the A/B tests (latte_debug_set_choice, include/latte_amd_debug.h; engine.cpp).  Process-global, 0 = the
+// library's own choice.  Every value selects another implementation of the SAME function; nothing here can change a result beyond
+// rounding.  (Round 3 read environment variables at every launch instead, among them ablations with garbage results.)
+enum DebugChoice { DBG_ATTN_VARIANT = 0, DBG_XATTN_FLASH, DBG_TN_KERNEL, DBG_TN_WN, DBG_ATTN_BWD_TILES, DBG_NUM_CHOICES };
+int debug_choice(DebugChoice c);
+int set_debug_choice(const char* name, int value);   // 0 = ok, -1 = unknown name / value not offered by this build
+
 int launch_scale_f32(float* p, float s, size_t n, hipStream_t st);   // p[i] *= s
+int launch_scale_f32_dev(float* p, const float* s_dev, int inverse, size_t n, hipStream_t st);   // p[i] *= *s_dev (or /=), factor in device memory
 // One guided DDIM step of the text-to-video loop (pipeline_latte.py:747-758 + DDIMScheduler.step, eta = 0) on x [b, C, F, HW]
 // in place: model_out is the denoiser output of the guidance pair in FRAME layout [(2b) F, Cout, HW] ([negative | prompt]):
 // eps = u + s (c - u) on the first C channels (learned sigma dropped), x0 = (x - c1 eps) / c2, x' = c3 x0 + c4 eps.
@@ -244,9 +252,9 @@ int launch_loss_grad(const float* tables, int n_steps, int mean_type, int var_ty
                      const float* noise, const float* model_out, const int64_t* t, int batch, int frames, int channels, int hw,
                      float vb_scale, float* dmodel_out, hipStream_t st);
 int sumsq_blocks();
-int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, hipStream_t st);
+int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, float* scaler, hipStream_t st);
 int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                     int step, float ema_decay, const float* stats, hipStream_t st);
+                     int step, float ema_decay, const float* stats, const float* step_dev, hipStream_t st);
 // dW[N, K] = dY[M, N]^T X[M, K] without transposed copies (gemm_tn.hip); partial: float [ceil(M / m_chunk)][N][K]
 int gemm_tn_tile_n();   // rows of dW per workgroup tile (for the caller's split heuristic)
 int gemm_tn_plan(int M, int N, int K, int* chunk);   // -> splits of the contraction, *chunk = rows per split

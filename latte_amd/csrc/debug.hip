@@ -276,6 +276,12 @@ int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const floa
   return rc;
 }
 
+int latte_debug_set_choice(const char* name, int value) {
+  if (set_debug_choice(name, value) != 0)
+    return fail(LATTE_ERR_INVALID, std::string("latte_debug_set_choice: unknown name or value not offered by this build: ") + (name ? name : "(null)"));
+  return LATTE_OK;
+}
+
 int latte_debug_tr16_probe(uint16_t* out, void* stream) {
   hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
   LATTE_HIP(hipGetLastError());

@@ -292,10 +292,9 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
 }  // namespace
 
 // The 8-wave LDS-DMA kernel takes a shape when the contraction has no ragged 64-row step and both output extents are whole
-// 128-column half-tiles (every linear of the Latte family); LATTE_TN_KERNEL=4 (measurement hook) forces the 4-wave kernel.
+// 128-column half-tiles (every linear of the Latte family); latte_debug_set_choice("tn_kernel", 4) (A/B tests) forces the 4-wave kernel.
 bool gemm_tn8_ok(int M, int N, int K) {
-  const char* e_ = getenv("LATTE_TN_KERNEL");
-  if (e_ && atoi(e_) == 4) return false;
+  if (debug_choice(DBG_TN_KERNEL) == 4) return false;
   return M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && (uint64_t)M * N * 2 < (1ull << 32) && (uint64_t)M * K * 2 < (1ull << 32);
 }
 // split of the contraction: -> number of splits, *chunk = rows per split (a multiple of 64).  8-wave kernel: one workgroup per
@@ -316,8 +315,7 @@ int gemm_tn_plan(int M, int N, int K, int* chunk) {
 
 // partial: float [splits][N][K] with splits = ceil(M / m_chunk) (m_chunk a multiple of 64); K % 128 == 0, N % 8 == 0
 int gemm_tn_tile_n() {
-  const char* e_ = getenv("LATTE_TN_WN");     // measurement hook: 4 = the 8-wave 256 x 128 tile
-  return (e_ && atoi(e_) == 4) ? 256 : 128;
+  return debug_choice(DBG_TN_WN) == 4 ? 256 : 128;     // latte_debug_set_choice("tn_wn", 4): the 8-wave 256 x 128 tile (A/B)
 }
 int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st) {
   if (K % 128 || N % 8 || m_chunk % 64 || m_chunk <= 0) return fail(LATTE_ERR_INVALID, "gemm_tn: need K % 128 == 0, N % 8 == 0, m_chunk % 64 == 0");

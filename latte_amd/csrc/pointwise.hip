@@ -923,6 +923,19 @@ int launch_scale_f32(float* p, float s, size_t n, hipStream_t st) {
   return LATTE_OK;
 }
 
+// p[i] *= *s or p[i] /= *s with the factor read from DEVICE memory (the trainer's loss scale, which its optimiser step may halve
+// or double without a host round trip); *s is a power of two, so the division is exact
+__global__ void scale_f32_dev_kernel(float* __restrict__ p, const float* __restrict__ s, int inverse, size_t n) {
+  const float f = inverse ? 1.0f / s[0] : s[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] *= f;
+}
+
+int launch_scale_f32_dev(float* p, const float* s_dev, int inverse, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_f32_dev_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, s_dev, inverse, n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, v, n);
   LATTE_HIP(hipGetLastError());

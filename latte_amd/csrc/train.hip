@@ -551,22 +551,61 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-// stats[0] = total 2-norm, stats[1] = coefficient the optimiser multiplies every gradient with (utils.py:108-114)
-__global__ void gradnorm_finalize_kernel(const double* __restrict__ partial, int blocks, float max_norm, int clip, float* __restrict__ stats) {
+// stats[0] = total 2-norm, stats[1] = coefficient the optimiser multiplies every gradient with (utils.py:108-114), stats[2] = 1 when
+// the update must be SKIPPED (non-finite gradient norm: an overflow of the loss-scaled half-precision backward or of an f16 forward
+// activation; the reference trains in fp32 range and cannot produce one).  scaler (device float[8], optional) is the trainer's
+// loss-scaling state, advanced here so that no host round trip is needed:
+//   [0] loss scale (power of two)  [1] applied steps since the scale last changed  [2] applied optimiser updates (AdamW's `step`)
+//   [3] skipped updates in total   [4] 1 if this call skipped                      [5] dynamic scaling on / off
+//   [6] growth interval            [7] largest scale
+// On a skip with dynamic scaling the scale halves (floor 1); after [6] consecutive applied updates it doubles (cap [7]).
+__global__ void gradnorm_finalize_kernel(const double* __restrict__ partial, int blocks, float max_norm, int clip, float* __restrict__ stats,
+                                         float* __restrict__ scaler) {
   double a = 0.0;
   for (int k = 0; k < blocks; ++k) a += partial[k];
   const float norm = (float)sqrt(a);
+  const bool ok = isfinite(norm);
   stats[0] = norm;
-  stats[1] = clip ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  stats[1] = !ok ? 0.0f : clip ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  stats[2] = ok ? 0.0f : 1.0f;
+  if (scaler) {
+    if (ok) {
+      scaler[2] += 1.0f;
+      scaler[1] += 1.0f;
+      scaler[4] = 0.0f;
+      if (scaler[5] != 0.0f && scaler[1] >= scaler[6]) {
+        scaler[0] = fminf(scaler[0] * 2.0f, scaler[7]);
+        scaler[1] = 0.0f;
+      }
+    } else {
+      scaler[3] += 1.0f;
+      scaler[4] = 1.0f;
+      scaler[1] = 0.0f;
+      if (scaler[5] != 0.0f) scaler[0] = fmaxf(scaler[0] * 0.5f, 1.0f);
+    }
+  }
 }
-// torch.optim.AdamW single-tensor update + update_ema; g is multiplied by stats[1] first (clipping) and zeroed afterwards
+// torch.optim.AdamW single-tensor update + update_ema; g is multiplied by stats[1] first (clipping) and zeroed afterwards.
+// stats[2] != 0: the update is skipped (parameters, moments and EMA untouched, gradients still zeroed).  step_dev != nullptr: the
+// bias corrections come from the trainer's own count of APPLIED updates (scaler[2], already advanced for this call) instead of the
+// host's step -- a fresh optimiser state starts at 1 whatever the training-step counter says (torch.optim.AdamW counts its own steps)
 __global__ void __launch_bounds__(256) adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ ema, size_t n, float lr, float b1,
                                                         float b2, float eps, float wd, float bc1, float sqrt_bc2, float ema_decay,
-                                                        const float* __restrict__ stats) {
+                                                        const float* __restrict__ stats, const float* __restrict__ step_dev) {
 #pragma clang fp contract(off)
   const float coef = stats ? stats[1] : 1.0f;
+  const bool skip = stats && stats[2] != 0.0f;
+  if (step_dev) {
+    const double st = (double)step_dev[0];
+    bc1 = 1.0f - (float)pow((double)b1, st);
+    sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (skip) {
+      g[i] = 0.f;
+      continue;
+    }
     const float gi = g[i] * coef;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = m[i] * b1 + gi * (1.0f - b1);
@@ -767,19 +806,20 @@ int launch_loss_grad(const float* tables, int n_steps, int mean_type, int var_ty
 
 constexpr int SUMSQ_BLOCKS = 1024;
 int sumsq_blocks() { return SUMSQ_BLOCKS; }
-// stats: float[2] = {norm, clip coefficient};  partial: double [sumsq_blocks()]
-int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, hipStream_t st) {
+// stats: float[4] = {norm, clip coefficient, skip flag, -};  partial: double [sumsq_blocks()];  scaler: device float[8] or nullptr
+int launch_grad_norm(const float* g, size_t n, double* partial, float max_norm, int clip, float* stats, float* scaler, hipStream_t st) {
   hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, g, n, partial);
-  hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(1), 0, st, partial, SUMSQ_BLOCKS, max_norm, clip, stats);
+  hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(1), 0, st, partial, SUMSQ_BLOCKS, max_norm, clip, stats, scaler);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
 int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                     int step, float ema_decay, const float* stats, hipStream_t st) {
-  const float bc1 = 1.0f - (float)std::pow((double)b1, (double)step);
-  const float sqrt_bc2 = (float)std::sqrt(1.0 - std::pow((double)b2, (double)step));
+                     int step, float ema_decay, const float* stats, const float* step_dev, hipStream_t st) {
+  // step >= 1: the caller's AdamW step; step == 0: the device-side count of applied updates (step_dev)
+  const float bc1 = step >= 1 ? 1.0f - (float)std::pow((double)b1, (double)step) : 1.0f;
+  const float sqrt_bc2 = step >= 1 ? (float)std::sqrt(1.0 - std::pow((double)b2, (double)step)) : 1.0f;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks_for(n, 8192)), dim3(256), 0, st, p, g, m, v, ema, n, lr, b1, b2, eps, wd, bc1, sqrt_bc2,
-                     ema_decay, stats);
+                     ema_decay, stats, step >= 1 ? nullptr : step_dev);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -485,10 +485,7 @@ int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout,
   a.num_seq = num_seq; a.L = L; a.heads = heads; a.hd = hd; a.D = heads * hd; a.U = U;
   a.sample_stride = sample_stride; a.seq_stride = seq_stride; a.row_stride = row_stride;
   a.scale = 1.0f / sqrtf((float)hd);
-  {
-    const char* e_ = getenv("LATTE_ATTN_BWD_TILES");
-    a.force_tiles = e_ && atoi(e_) == 1;
-  }
+  a.force_tiles = debug_choice(DBG_ATTN_BWD_TILES) == 1;   // latte_debug_set_choice("attn_bwd_tiles", 1): the tiled kernels for L = 16 too (A/B tests)
   if (dtype != LATTE_DTYPE_BF16 && dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "attention_bwd: unknown dtype");
 #define CASE(HD)                                                                                         \
   case HD:                                                                                               \

@@ -42,7 +42,16 @@ struct latte_trainer {
   // of the gradient buffer by 1 / loss_scale -- the backward is linear in that seed, the scale is a power of two, so the result is
   // the unscaled gradient exactly unless something leaves f16's range.  Per-token gradients of this model are 1e-7 ... 1e-4
   // (Latte-B/2, batch 5): x 2^14 puts them at 1.6e-3 ... 1.6, inside f16's normal range (6e-5 ... 65504).  bf16: 1 (fp32's range).
-  float loss_scale = 1.0f;
+  // Round 4: the scale lives in DEVICE memory (`scaler`, float[8], layout at gradnorm_finalize_kernel in train.hip) so that the
+  // optimiser step can react to an overflow without a host round trip: a non-finite gradient norm SKIPS the update (parameters,
+  // AdamW moments, EMA untouched) and, with dynamic scaling (the f16 default), halves the scale; 2000 applied updates in a row double
+  // it again (cap 2^16 -- the largest of the three scales validated bit-exact in tests/test_training_step.py).  The same array
+  // counts the APPLIED updates: AdamW's bias-correction step is that count (a fresh optimiser state starts at 1 whatever the
+  // training-step counter of a continued run says; torch.optim.AdamW keeps its own count too).
+  float loss_scale = 1.0f;       // initial / static value (host copy; the live value is scaler[0])
+  int dynamic_scale = 0;
+  float growth_interval = 2000.0f;
+  float* scaler = nullptr;
   std::vector<ParamInfo> params;
   std::map<std::string, int> index;
   int64_t total = 0;
@@ -109,6 +118,20 @@ int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int
   return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
 }
 
+// loss-scale state -> device.  reset: also clear the counters (create).  Synchronous (an option call, not on the step path).
+int upload_scaler(latte_trainer* e, bool reset) {
+  float h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!reset) LATTE_HIP(hipMemcpy(h, e->scaler, sizeof(h), hipMemcpyDeviceToHost));
+  h[0] = e->loss_scale;
+  h[1] = 0.0f;
+  h[5] = (float)e->dynamic_scale;
+  h[6] = e->growth_interval;
+  h[7] = std::max(e->loss_scale, 65536.0f);
+  LATTE_HIP(hipMemcpy(e->scaler, h, sizeof(h), hipMemcpyHostToDevice));
+  return LATTE_OK;
+}
+bool scaling_active(const latte_trainer* e) { return e->loss_scale != 1.0f || e->dynamic_scale; }
+
 }  // namespace
 
 extern "C" {
@@ -131,6 +154,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   e->P = c.patch_size * c.patch_size * e->Cout; e->KPE = c.in_channels * c.patch_size * c.patch_size;
   e->Hm = c.mlp_hidden; e->hd = hd; e->dt = c.compute_dtype;
   e->loss_scale = c.compute_dtype == LATTE_DTYPE_F16 ? 16384.0f : 1.0f;
+  e->dynamic_scale = c.compute_dtype == LATTE_DTYPE_F16 ? 1 : 0;
   e->nmod = c.depth * 6 * e->D + 2 * e->D;
   if ((e->F * e->T) % 64) { delete e; return fail(LATTE_ERR_INVALID, "trainer: frames * tokens per sample must be a multiple of 64"); }
   e->rows_max = (int64_t)max_batch * e->F * e->T;
@@ -205,9 +229,11 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   e->loss_ws_floats = latte_training_workspace_floats(max_batch, (int64_t)e->F * e->Cin * e->H * e->H) + 3 * max_batch;
   A(&e->loss_ws, (size_t)e->loss_ws_floats);
   A(&e->stats, 4);
+  A(&e->scaler, 8);
   A(&e->sumsq, (size_t)sumsq_blocks());
   A(&e->dyD, R * D); A(&e->dhH, R * Hm); A(&e->dxnH, R * D); A(&e->dqkvH, R * 3 * D); A(&e->xnh, R * D);
   if (!rc) rc = launch_fill_f32(e->ones, 1.0f, R, nullptr);
+  if (!rc) rc = upload_scaler(e, true);
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(LATTE_ERR_HIP, "trainer_create: device error");
   if (rc) { latte_trainer_destroy(e); return rc; }
   *out = e;
@@ -352,7 +378,7 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
                                   e->loss_ws_floats - 3 * e->max_batch, terms_out + B, terms_out + 2 * B, terms_out, stream))) return rc;
   if ((rc = launch_loss_grad(tab, s->num_timesteps, s->mean_type, s->var_type, x_start, e->x_t, noise, e->model_out, t, B, F, e->Cin, hw,
                              vb_scale, e->dmodel_out, st))) return rc;
-  if (e->loss_scale != 1.0f && (rc = launch_scale_f32(e->dmodel_out, e->loss_scale, (size_t)B * F * e->Cout * hw, st))) return rc;
+  if (scaling_active(e) && (rc = launch_scale_f32_dev(e->dmodel_out, e->scaler, 0, (size_t)B * F * e->Cout * hw, st))) return rc;
 
   LATTE_HIP(hipMemsetAsync(e->dc, 0, sizeof(float) * (size_t)B * D, st));   // d SiLU(c), summed over the adaLN linears by the stages
   e->cur_batch = B;
@@ -400,10 +426,10 @@ int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offs
 static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream);
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream) {
   int rc = backward_stage_impl(e, stage, stream);
-  if (!rc && e->loss_scale != 1.0f) {   // the slice this stage finalised leaves the loss-scaled domain
+  if (!rc && scaling_active(e)) {   // the slice this stage finalised leaves the loss-scaled domain
     int64_t off = 0, n = 0;
     if ((rc = latte_trainer_stage_range(e, stage, &off, &n))) return rc;
-    rc = launch_scale_f32(e->Gr + off, 1.0f / e->loss_scale, (size_t)n, (hipStream_t)stream);
+    rc = launch_scale_f32_dev(e->Gr + off, e->scaler, 1, (size_t)n, (hipStream_t)stream);
   }
   return rc;
 }
@@ -415,7 +441,16 @@ int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value)
     if (!(value >= 1.0) || value > 16777216.0 || std::frexp(value, &ex) != 0.5)
       return fail(LATTE_ERR_INVALID, "loss_scale must be a power of two in [1, 2^24]");
     e->loss_scale = (float)value;
-    return LATTE_OK;
+    return upload_scaler(e, false);
+  }
+  if (std::string(name) == "dynamic_loss_scale") {   // 0: the scale stays what "loss_scale" set (overflowing steps are still skipped)
+    e->dynamic_scale = value != 0.0 ? 1 : 0;
+    return upload_scaler(e, false);
+  }
+  if (std::string(name) == "loss_scale_growth_interval") {
+    if (!(value >= 1.0) || value > 1e7) return fail(LATTE_ERR_INVALID, "loss_scale_growth_interval must be in [1, 1e7]");
+    e->growth_interval = (float)value;
+    return upload_scaler(e, false);
   }
   return fail(LATTE_ERR_INVALID, std::string("trainer_set_option: unknown option '") + name + "'");
 }
@@ -519,14 +554,25 @@ int latte_trainer_forward_backward(latte_trainer_t* e, const latte_schedule_t* s
 int latte_trainer_optimizer_step(latte_trainer_t* e, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                  float clip_max_norm, int clip, float ema_decay, float* norm_out, void* stream) {
   if (!e || !e->Pm) return fail(LATTE_ERR_STATE, "optimizer_step: bind the parameter buffers first");
-  if (step < 1) return fail(LATTE_ERR_INVALID, "optimizer_step: step counts from 1");
+  if (step < 0) return fail(LATTE_ERR_INVALID, "optimizer_step: step counts from 1 (0: the trainer's own count of applied updates)");
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((rc = launch_grad_norm(e->Gr, (size_t)e->total, e->sumsq, clip_max_norm, clip, e->stats, st))) return rc;
+  if ((rc = launch_grad_norm(e->Gr, (size_t)e->total, e->sumsq, clip_max_norm, clip, e->stats, e->scaler, st))) return rc;
   if (norm_out) LATTE_HIP(hipMemcpyAsync(norm_out, e->stats, sizeof(float) * 2, hipMemcpyDeviceToDevice, st));
   if ((rc = launch_adamw_ema(e->Pm, e->Gr, e->M1, e->V2, e->Ema, (size_t)e->total, lr, beta1, beta2, eps, weight_decay, step, ema_decay,
-                             e->stats, st))) return rc;
+                             e->stats, e->scaler + 2, st))) return rc;
   return latte_trainer_sync_weights(e, stream);
+}
+
+// {loss scale, applied steps since it changed, applied optimiser updates, skipped updates, last call skipped, dynamic, growth interval,
+// largest scale} -> host doubles (synchronises the device: logging / tests, not the step path)
+int latte_trainer_scaler_state(latte_trainer_t* e, double* out8) {
+  if (!e || !out8) return fail(LATTE_ERR_INVALID, "trainer_scaler_state: null argument");
+  float h[8];
+  LATTE_HIP(hipDeviceSynchronize());
+  LATTE_HIP(hipMemcpy(h, e->scaler, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  return LATTE_OK;
 }
 
 }  // extern "C"

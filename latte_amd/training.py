@@ -53,11 +53,17 @@ class LatteTrainer:
     gradients of 1e-7 ... 1e-4 would underflow f16 otherwise; scaling and unscaling by a power of two is exact) and has the 10
     mantissa bits of the TF32 matmuls the reference trains with (train.py:12-14) -- the default: every gradient tensor within
     3.8e-4 relative L2 of the reference's fp32 gradients (tests/test_training_step.py); "bf16" needs no scaling, has 7 bits
-    (3.2e-3) and is 1.6 % faster."""
+    (3.2e-3) and is 1.6 % faster.
+    Overflow handling (round 4): a non-finite gradient norm skips the update and, with ``dynamic_loss_scale`` (default: on for
+    f16, off for bf16), halves the loss scale; 2000 applied updates in a row double it again -- all inside the engine's optimiser
+    step, no host synchronisation (``scaler_state()`` reads the counters back for logging).  ``train_steps`` is the TRAINING-step
+    counter of train.py:195-236 (clipping starts at ``start_clip_iter``, checkpoints are numbered by it, a continued run sets it to
+    the checkpoint's step); AdamW's bias correction uses the engine's own count of applied updates, which starts at 0 with the
+    fresh moments -- as ``torch.optim.AdamW`` does in the reference."""
 
     def __init__(self, model, diffusion, max_batch, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_max_norm=0.1,
                  start_clip_iter=20000, ema_decay=0.9999, class_dropout_prob=0.1, compute_dtype="f16", process_group=None,
-                 loss_scale=None):
+                 loss_scale=None, dynamic_loss_scale=None):
         if not isinstance(model, Latte):
             raise LatteError("LatteTrainer needs a latte_amd.Latte model")
         if not isinstance(diffusion, SpacedDiffusion):
@@ -89,6 +95,8 @@ class LatteTrainer:
         self._h = h
         if loss_scale is not None:
             check(lib.latte_trainer_set_option(h, b"loss_scale", float(loss_scale)))
+        if dynamic_loss_scale is not None:
+            check(lib.latte_trainer_set_option(h, b"dynamic_loss_scale", float(bool(dynamic_loss_scale))))
         self.compute_dtype = compute_dtype
         n = lib.latte_trainer_num_params(h)
         self.layout = [(lib.latte_trainer_param_key(h, i).decode(), int(lib.latte_trainer_param_offset(h, i)),
@@ -230,12 +238,22 @@ class LatteTrainer:
         self.train_steps += 1
         clip = int(self.train_steps - 1 >= self.start_clip_iter)                  # train.py:228-231
         with torch.cuda.device(self.device):
+            # step = 0: AdamW's bias correction counts the engine's APPLIED updates (fresh moments start at 1), not train_steps
             check(load_library().latte_trainer_optimizer_step(self._h, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                              self.train_steps, self.clip_max_norm, clip, self.ema_decay,
+                                                              0, self.clip_max_norm, clip, self.ema_decay,
                                                               ptr(self._norm), stream_ptr()))
         if hasattr(self.model, "mark_weights_dirty"):
             self.model.mark_weights_dirty()
         return self._norm[0]
+
+    def scaler_state(self):
+        """Loss-scaling / update counters of the engine (synchronises): dict(loss_scale, good_steps, applied_updates,
+        skipped_updates, last_skipped, dynamic, growth_interval, max_scale)."""
+        import ctypes
+        out = (ctypes.c_double * 8)()
+        check(load_library().latte_trainer_scaler_state(self._h, out))
+        keys = ("loss_scale", "good_steps", "applied_updates", "skipped_updates", "last_skipped", "dynamic", "growth_interval", "max_scale")
+        return dict(zip(keys, [float(v) for v in out]))
 
     def train_step(self, x_start, y=None, t=None, noise=None, drop_mask=None):
         """train.py:197-236 for one micro-batch (gradient_accumulation_steps = 1)."""

@@ -16,6 +16,19 @@ def dev():
     return torch.device("cuda")
 
 
+@pytest.fixture
+def kernel_choice(lib):
+    """latte_debug_set_choice for the duration of a test (include/latte_amd_debug.h: another implementation of the same function)."""
+    used = []
+
+    def choose(name, value):
+        check(lib.latte_debug_set_choice(name.encode(), int(value)))
+        used.append(name)
+    yield choose
+    for name in used:
+        check(lib.latte_debug_set_choice(name.encode(), 0))
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608), (700, 384, 64),
@@ -126,12 +139,20 @@ def test_attention(lib, dev, dt, case, mode):
 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] > 128])
-@pytest.mark.parametrize("variant", [4, 5])
-def test_attention_long_sequence_kernels_forced(lib, dev, dt, case, variant, monkeypatch):
-    """The spatial cases with more than 128 tokens through the kernels the default choice does not take for them: 4 = the 256-key
-    block kernel, 5 = the streaming kernel (also for 128 < L <= 256, where the single-block kernel is the default)."""
-    monkeypatch.setenv("LATTE_ATTN_ABLATE", str(variant))
+@pytest.mark.parametrize("variant", [1, 5])
+def test_attention_long_sequence_kernels_forced(lib, dev, dt, case, variant, kernel_choice):
+    """The spatial cases with more than 128 tokens through the kernels the default choice does not take for them: 1 = the generic
+    flash kernel, 5 = the streaming kernel (also for 128 < L <= 256, where the single-block kernel is the default)."""
+    kernel_choice("attn_variant", variant)
     _attention_case(lib, dev, dt, case, "spatial")
+
+
+def test_debug_choice_refuses_what_is_not_offered(lib):
+    """Round-3 advisor finding: a stray environment variable could route production launches to ablation kernels with garbage
+    results.  The overrides are an explicit debug entry now, and the production library refuses the ablation values outright."""
+    for name, v in (("attn_variant", 4), ("attn_variant", 7), ("attn_variant", 9), ("no_such_choice", 1), ("tn_kernel", 3)):
+        assert lib.latte_debug_set_choice(name.encode(), v) != 0, (name, v)
+    assert lib.latte_debug_set_choice(b"attn_variant", 5) == 0 and lib.latte_debug_set_choice(b"attn_variant", 0) == 0
 
 
 def _attention_case(lib, dev, dt, case, mode):
@@ -151,7 +172,6 @@ def _attention_case(lib, dev, dt, case, mode):
         want = a.permute(0, 3, 1, 2, 4).reshape(rows, D)
         args = (B * T, F, H, hd, T, F * T, 1, T)
     out = torch.zeros(rows, D, dtype=TD[dt], device=dev)
-    torch.cuda.synchronize()    # (the block kernel needs scratch memory: its first launch must not queue behind running work)
     check(lib.latte_debug_attention(ptr(qh), ptr(out), *args, dt, stream_ptr()))
     torch.cuda.synchronize()
     rel = float((out.float() - want).norm() / want.norm())
@@ -175,13 +195,13 @@ def test_attention_forced_rescale(lib, dev):
 
 
 @pytest.mark.parametrize("hd,spike_key", [(72, 900), (64, 300), (72, 1023)])
-@pytest.mark.parametrize("kernel", ["stream", "blocks"])
-def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key, kernel, monkeypatch):
-    """The online-softmax kernels for L > 256 (L = 1024: the streaming kernel with its ring of 128-key blocks, and the 256-key
-    stage-then-compute block kernel, LATTE_ATTN_ABLATE=4): a key in a LATE block dominates one query, so the running maximum
-    jumps and the accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
-    if kernel == "blocks":
-        monkeypatch.setenv("LATTE_ATTN_ABLATE", "4")
+@pytest.mark.parametrize("kernel", ["stream", "flash"])
+def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key, kernel, kernel_choice):
+    """The online-softmax kernels for L > 256 (L = 1024: the streaming kernel with its ring of 128-key blocks, and the generic
+    64-key-tile flash kernel it falls back to): a key in a LATE block dominates one query, so the running maximum jumps and
+    the accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
+    if kernel == "flash":
+        kernel_choice("attn_variant", 1)
     T, dt = 1024, 1
     g = torch.Generator("cpu").manual_seed(spike_key)
     qkv = torch.randn(T, 3 * hd, generator=g)
@@ -316,9 +336,9 @@ TN_CASES = [(1024, 768, 768), (2048, 2304, 768), (1536, 768, 3072), (1280, 1152,
 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("shape", TN_CASES)
-def test_weight_gradient_gemm_tn(lib, dev, dt, shape, monkeypatch):
+def test_weight_gradient_gemm_tn(lib, dev, dt, shape, kernel_choice):
     """dW = dY^T X (csrc/gemm_tn.hip: the 8-wave LDS-DMA kernel where the shape allows it, else the 4-wave one) against fp32
-    torch on the same half operands, and the two kernels against each other (LATTE_TN_KERNEL=4 forces the 4-wave kernel)."""
+    torch on the same half operands, and the two kernels against each other (debug choice tn_kernel = 4 forces the 4-wave kernel)."""
     M, N, K = shape
     g = torch.Generator("cpu").manual_seed(M + N + K)
     dY = torch.randn(M, N, generator=g).to(dev).to(TD[dt])
@@ -328,7 +348,7 @@ def test_weight_gradient_gemm_tn(lib, dev, dt, shape, monkeypatch):
     outs = []
     for force4 in (False, True):
         if force4:
-            monkeypatch.setenv("LATTE_TN_KERNEL", "4")
+            kernel_choice("tn_kernel", 4)
         dW = torch.full((N, K), float("nan"), device=dev)
         check(lib.latte_debug_gemm_tn(ptr(dY), ptr(X), ptr(dW), ptr(ws), ws.numel(), M, N, K, dt, stream_ptr()))
         torch.cuda.synchronize()
@@ -344,7 +364,7 @@ ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("case", ATTN_BWD_CASES)
 @pytest.mark.parametrize("mode", ["spatial", "temporal"])
-def test_attention_backward(lib, dev, dt, case, mode, monkeypatch):
+def test_attention_backward(lib, dev, dt, case, mode, kernel_choice):
     """dq, dk, dv of the attention core (csrc/train_attn.hip) against torch autograd on the same half q / k / v / dout, for the
     strided sequence layouts of both block kinds; where L <= 16 the one-wave kernel AND the tile passes (forced) are checked."""
     B, F, T, H, hd = case
@@ -367,7 +387,7 @@ def test_attention_backward(lib, dev, dt, case, mode, monkeypatch):
     stats = torch.zeros(args[0] * H * L * 3 + 16, device=dev)
     for force in ([False, True] if L <= 16 else [False]):
         if force:
-            monkeypatch.setenv("LATTE_ATTN_BWD_TILES", "1")
+            kernel_choice("attn_bwd_tiles", 1)
         got = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
         check(lib.latte_debug_attention_bwd(ptr(qkv), ptr(oh), ptr(dout), ptr(got), ptr(stats), *args, dt, stream_ptr()))
         torch.cuda.synchronize()

@@ -104,9 +104,12 @@ def test_t2v_forward_matches_oracle(case, monkeypatch):
     m.set_engine_option("fuse_qkv_attn", 3)
     # text cross-attention: sequences of >= 128 tokens with <= 128 text tokens run the whole-panel kernel (attn_cross_kernel);
     # the generic flash kernel agrees with it to rounding (exact softmax against two key tiles with an online rescale)
-    monkeypatch.setenv("LATTE_XATTN_FLASH", "1")
-    flash = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
-    monkeypatch.delenv("LATTE_XATTN_FLASH")
+    from latte_amd._lib import check, load_library
+    check(load_library().latte_debug_set_choice(b"xattn_flash", 1))
+    try:
+        flash = m(x.cuda(), t.cuda(), enc.cuda(), encoder_attention_mask=mask.cuda()).sample
+    finally:
+        check(load_library().latte_debug_set_choice(b"xattn_flash", 0))
     assert rel_l2(flash, want) < TOL and rel_l2(flash, got) < 2e-4
     # default operand type of LatteT2V = f16, the type the reference runs this transformer in (sample_t2x.py:29)
     md = _model(cfg, sd, None, max_batch=B).to("cuda")

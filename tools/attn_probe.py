@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Interleaved A/B of the self-attention kernels on one shape (both in ONE process, alternating, so clock drift and box variance
-cancel): LATTE_ATTN_ABLATE is read per launch.  Default shape = Latte-1 T2V spatial attention (32 sequences x 1024 tokens,
+cancel): latte_debug_set_choice("attn_variant", v) switches per launch.  Default shape = Latte-1 T2V spatial attention (32 sequences x 1024 tokens,
 16 heads x 72).  Variants: 0 default choice, 1 generic flash kernel, 4 256-key block kernel, 5 streaming kernel also for
 128 < L <= 256, 7 / 8 / 9 streaming kernel without DMA issue in the loop / without softmax / without barrier (results garbage).
 --sync: synchronise after every warm-up launch (the FIRST launch of a kernel that needs scratch memory, e.g. the block kernel,
@@ -34,7 +34,7 @@ def main():
     flop = 4.0 * a.seqs * a.heads * a.L * a.L * a.hd
 
     def run(v):
-        os.environ["LATTE_ATTN_ABLATE"] = str(v)
+        assert lib.latte_debug_set_choice(b"attn_variant", int(v)) == 0, f"variant {v} is not offered by this build (7-9: LATTE_DEBUG_BUILD=1)"
         rc = lib.latte_debug_attention(qkv.data_ptr(), out.data_ptr(), a.seqs, a.L, a.heads, a.hd, 1, a.L, a.L, 1, 1, st)
         assert rc == 0, rc
 

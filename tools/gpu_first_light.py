@@ -388,10 +388,7 @@ def attn_variants():
         args = (B * F, T, H, hd, F, F * T, T, 1) if mode == "spatial" else (B * T, F, H, hd, T, F * T, 1, T)
         if mode == "temporal_adjacent":   # the 16 frames of a token as 16 ADJACENT rows (a (b, t, f) row order): layout probe
             args = (B * T, F, H, hd, T, F * T, F, 1)
-        if env is None:
-            os.environ.pop("LATTE_ATTN_ABLATE", None)
-        else:
-            os.environ["LATTE_ATTN_ABLATE"] = str(env)
+        check(lib.latte_debug_set_choice(b"attn_variant", 0 if env is None else int(env)))
         for _ in range(3):
             check(lib.latte_debug_attention(ptr(qkv), ptr(out), *args, 0, stream_ptr()))
         torch.cuda.synchronize()
@@ -401,13 +398,13 @@ def attn_variants():
             check(lib.latte_debug_attention(ptr(qkv), ptr(out), *args, 0, stream_ptr()))
         e1.record()
         torch.cuda.synchronize()
-        os.environ.pop("LATTE_ATTN_ABLATE", None)
+        check(lib.latte_debug_set_choice(b"attn_variant", 0))
         us = e0.elapsed_time(e1) * 1e3 / 20
         fl = 4.0 * B * F * T * T * D if mode == "spatial" else 4.0 * B * T * F * F * D
         return us, fl / us / 1e6, out.float()
     for (B, F, T, nm) in [(8, 16, 256, "XL/2 spatial L=256 B=8"), (2, 16, 1024, "Latte-1 spatial L=1024 B=2")]:
         row, ref = [], None
-        for env, name in ((None, "default"), (4, "blocks"), (1, "flash")):
+        for env, name in ((None, "default"), (5, "stream"), (1, "flash")):
             us, tf, o = run(B, F, T, "spatial", env)
             ref = o if ref is None else ref
             row.append(f"{name}: {us:7.1f}us {tf:5.0f}TF d={float((o - ref).abs().max()):.1e}")

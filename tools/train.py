@@ -93,7 +93,9 @@ def main():
     first_step = 0
     if args.get("pretrained"):
         # train.py:195-196: the step counter continues from the checkpoint's file name (0100000.pt -> 100000), so gradient clipping
-        # (start_clip_iter) and the checkpoint numbering carry on instead of restarting
+        # (start_clip_iter) and the checkpoint numbering carry on instead of restarting.  Only THAT counter: the checkpoint holds
+        # model and ema, no optimiser state, so AdamW's moments start at zero and its bias correction at step 1 -- the engine
+        # counts its applied updates itself (LatteTrainer docstring), as the reference's fresh torch.optim.AdamW does
         stem = os.path.basename(str(args.pretrained)).split(".")[0]
         if stem.isdigit():
             first_step = int(stem)
