@@ -74,6 +74,34 @@ enum GemmEpi : int {
   EPI_ABLATE_DMA_B = 11,    // only the B operand is DMA'd in the loop
   EPI_ABLATE_TRACE = 12,    // full loop, no stores; workgroup 0 writes per-wave phase times (s_memtime ticks) to `out`:
                             // int64 [8 waves][8] = {L, barrier-1 wait, C issue, vmcnt wait, barrier-2 wait, DMA issue, total, K tiles}
+  // LayerNorm fusion (round 4; `LnFuse` below)
+  EPI_GATE_RES_LN = 13,     // EPI_GATE_RES_F32 + the NEXT LayerNorm-modulate's operand: half x_new (1 + scale) and row sums (12-wave kernel)
+  EPI_LN_GELU_H16 = 14,     // out(half) = gelu_tanh(r (acc - mu u[s][n]) + v[s][n]): the consumer of an EPI_GATE_RES_LN operand (fc1)
+  EPI_LN_H16 = 15,          // out(half) = r (acc - mu u[s][n]) + v[s][n]                                        (un-fused qkv)
+};
+// LayerNorm + modulate (latte.py:28-29,166,168,179-180) folded into the GEMMs on either side of it.  The reference computes
+//     y = Linear(LN(x) (1 + sc) + sh),   LN(x) = (x - mu) r,  r = rsqrt(var + eps)        (per row; sc, sh per sample)
+// which is, exactly,   y[n] = r (sum_k x_k (1 + sc_k) W[n,k]  -  mu u[n]) + v[n],   u = (1 + sc) W^T,  v = sh W^T + b.
+// So the GEMM that PRODUCES x (the gated residual update) also writes the half operand a = x (1 + sc) (it holds the fp32 row
+// patch in registers anyway) and adds its tile's share of sum x, sum x^2 into a per-row accumulator; the GEMM that CONSUMES it
+// multiplies a W^T as before and applies r, mu, u, v in its epilogue.  The separate LN pass (read 4 B + write 2 B per element,
+// 56 launches, 8 % of the XL/2 step) disappears.  The row sums are 64-bit FIXED-POINT integers added with atomics: integer
+// addition is associative, so the result does not depend on the order in which the six column tiles of a row arrive
+// (bit-reproducible runs), unlike float atomics.
+constexpr double LN_SUM_SCALE = 4294967296.0;   // 2^32: sum x    (|partial| < 2^31: no realistic activation gets near)
+constexpr double LN_SQ_SCALE = 268435456.0;     // 2^28: sum x^2  (a 48-column partial may reach 3.4e10: rms |x| < 2.6e4)
+struct LnFuse {
+  // producer (EPI_GATE_RES_LN)
+  half_t* xn;              // [Mpad, N] half: x_new (1 + scale[sample]); nullptr = emit nothing (only `zero` is serviced)
+  const float* scale;      // the next modulate's scale vector, per sample: scale + sample * gate_stride
+  long long* acc;          // [Mpad][2]: += sum x_new 2^32, += sum x_new^2 2^28 over the tile's columns (must be zero before the launch)
+  long long* zero;         // [Mpad][2]: the accumulator the previous consumer has finished with; the tn == 0 tiles clear their rows
+  // consumer (EPI_LN_GELU_H16 / EPI_LN_H16, and the fused qkv + attention kernel)
+  const long long* stats;  // [Mpad][2] as accumulated by the producer
+  const float* u;          // per sample [N]: (1 + scale) W^T    (row stride uv_stride floats; fp32 sums over the HALF weights)
+  const float* v;          // per sample [N]: shift W^T + bias
+  int uv_stride;
+  float inv_n, eps;        // 1 / (row length of the LayerNorm), 1e-6
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -91,6 +119,7 @@ struct GemmArgs {
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
   int k_chunk;        // plain kernels (variants 1-3) only: > 0 splits the contraction, grid.y = ceil(K / k_chunk) partial products
   long split_stride;  // ... written to (float*)out + blockIdx.y * split_stride (use EPI_BIAS_F32 with a zero bias)
+  LnFuse ln;          // EPI_GATE_RES_LN / EPI_LN_*: LayerNorm fusion operands (zero-initialised = unused)
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
@@ -144,8 +173,11 @@ struct QkvAttnArgs {
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
+  LnFuse ln;           // ln.stats != nullptr: xn is the un-normalised operand x (1 + scale) of a producer GEMM and the image-write
+                       // phase applies r (acc - mu u) + v (u, v: [3 D] per sample, v includes the bias) -- `bias` is unused then
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
+bool ln_fusable_shape(int D, int Hm, int heads, int hd, int F, int T, int M);   // engine.cpp: every kernel of a block has its LayerNorm-fused form
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 
 // ---- pointwise / small kernels ------------------------------------------------------------------
@@ -169,6 +201,18 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
 // text_embedding_projection of the extras == 78 variant (latte.py:238-242): out[B,N] = Linear(SiLU(text[B,K]))
 int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K, hipStream_t st);
 int launch_iota(int64_t* p, int n, hipStream_t st);
+// LayerNorm fusion: u / v vectors of the linears that follow a LayerNorm-modulate (pointwise.hip: modvec_kernel).  One table entry
+// per linear; conditioning row r reads scale / shift at mod + r * mod_stride + {scale_off, shift_off} and writes
+// uv + r * uv_stride + uv_off: [u (N floats) | v (N floats)]
+struct ModvecEntry {
+  const half_t* W;      // [N, K] half weights (the MFMA operand)
+  const float* bias;    // [N]
+  int N;
+  int scale_off, shift_off;   // float offsets inside a conditioning row
+  long uv_off;                // float offset inside an output row
+};
+int launch_modvec(const ModvecEntry* tab_dev, int entries, int max_n, const float* mod, long mod_stride, int R, float* uv, long uv_stride,
+                  int K, int dtype, hipStream_t st);
 // x[M, N] += gate[m / rows_per_sample, :] * (sum of `splits` fp32 partial products (slab stride `stride`) + bias): the reduction
 // of a split-K gated GEMM (engine.cpp: gated_gemm)
 int launch_gated_split_reduce(float* x, const float* ws, int splits, size_t stride, const float* bias, const float* gate,

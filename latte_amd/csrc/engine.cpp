@@ -66,6 +66,17 @@ struct Prof {
   std::vector<int> cls;
 };
 
+// LayerNorm fusion applies when every kernel of the block has its LN-aware form for this shape: the fused qkv + attention kernel
+// for both block kinds, the rolling 12-wave kernel for the two gated GEMMs, the 256-wide persistent kernel for fc1, and 256-row
+// tiles that stay inside one sample with whole-tile M.  (Pure host logic; latte_debug_ln_fusable exposes it to the CPU tests.)
+bool ln_fusable_shape(int D, int Hm, int heads, int hd, int F, int T, int M) {
+  const int rps = F * T;
+  if (M <= 0 || rps % 256 != 0 || M % 256 != 0 || (uint64_t)M * D * 4 >= (1ull << 32) || D % 8 != 0) return false;
+  if (!qkv_attention_fusable(D, heads, hd, F, T, 0, M) || !qkv_attention_fusable(D, heads, hd, F, T, 1, M)) return false;
+  if (gemm_resolve_variant(M, D, D, EPI_GATE_RES_F32) != 11 || gemm_resolve_variant(M, D, Hm, EPI_GATE_RES_F32) != 11) return false;
+  return gemm_resolve_variant(M, Hm, D, EPI_BIAS_GELU_H16) == 9;
+}
+
 }  // namespace latte
 
 using namespace latte;
@@ -82,6 +93,15 @@ struct latte_engine {
                                            // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair;
                                            // bits 2, 3: QkvAttnArgs::flags (schedule variants, same results)
   int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
+  // LayerNorm fusion (round 4, common.h: LnFuse): 1 = wherever ln_fusable() allows it, the LayerNorm + modulate
+  // between a gated GEMM and the linear that follows it lives in the two GEMMs' epilogues instead of its own HBM pass; 0 = the
+  // separate ln_modulate kernel everywhere
+  int fuse_ln = 1;
+  long long* lnstat = nullptr;             // [2][rows_pad][2] fixed-point row sums: [0] LN2 (proj -> fc1), [1] LN1 (fc2 -> next qkv)
+  float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]
+  int64_t uv_all_cap = 0;
+  int64_t uv_row = 0;                      // depth * 2 * (3 D + Hm) floats: per block [u_qkv | v_qkv | u_fc1 | v_fc1]
+  ModvecEntry* modvec_tab = nullptr;       // device table: 2 entries per block (qkv, fc1)
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
@@ -192,7 +212,8 @@ int gated_gemm(latte_engine* e, const GemmArgs& g, int dt, int variant, hipStrea
 // mod_override != nullptr: the adaLN outputs of this step were precomputed ([B or 1 rows, nmod], row stride mod_stride;
 // stride 0 = one row shared by every sample) and the conditioning launches are skipped.
 int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t* y, int B, bool cfg_dup, float* out,
-                hipStream_t st, Prof* prof, const float* mod_override = nullptr, int mod_stride_override = 0) {
+                hipStream_t st, Prof* prof, const float* mod_override = nullptr, int mod_stride_override = 0,
+                const float* uv_override = nullptr) {
   const auto& c = e->cfg;
   if (B <= 0 || B > e->max_batch) return fail(LATTE_ERR_STATE, "forward: batch exceeds max_batch of the engine");
   if (c.extras == 2 && y == nullptr && !mod_override) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
@@ -228,6 +249,18 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
                                     e->mod + fo, B, 2 * D, D, e->nmod, st))) return rc;
     }
   }
+  // --- LayerNorm fusion: is it on for this call, and the u / v vectors of the linears behind a LayerNorm (once per conditioning row)
+  const bool lnf = e->fuse_ln && (e->fuse_qkv_attn & 3) == 3 && e->gemm_variant == 0 && !e->gemm_variant_of[1] && !e->gemm_variant_of[2] &&
+                   !e->gemm_variant_of[3] && c.depth >= 2 && ln_fusable_shape(D, e->Hm, c.num_heads, e->hd, F, T, M);
+  const float* uvp = uv_override;
+  const int uv_stride = mstride == 0 ? 0 : (int)e->uv_row;
+  if (lnf && !uvp) {
+    if ((rc = launch_modvec(e->modvec_tab, 2 * c.depth, std::max(3 * D, e->Hm), modp, mstride, mstride == 0 ? 1 : B, e->uv, e->uv_row, D, dt, st)))
+      return rc;
+    uvp = e->uv;
+  }
+  long long* const acc_ln2 = e->lnstat;                              // proj -> fc1
+  long long* const acc_ln1 = e->lnstat + (size_t)e->rows_pad * 2;    // fc2 -> the next block's qkv
   tm.mark(C_COND);
   // --- patch embed + pos_embed (latte.py:330-331)
   if (cfg_dup) {
@@ -246,8 +279,14 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     const float* mb = modp + (size_t)i * 6 * D;  // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     // x + temp_embed once, after the first spatial block (latte.py:357-358)
     const float* te = (i == 1) ? e->temp : nullptr;
-    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
-    tm.mark(C_LN);
+    // LayerNorm fusion (lnf): LN1 of blocks >= 2 was folded into the previous block's fc2 (operand x (1 + scale_msa) in xn, row sums in
+    // acc_ln1); blocks 0 and 1 run the separate kernel (block 0 follows the patch embed, block 1's LayerNorm adds temp_embed first)
+    const bool ln1_fused = lnf && i >= 2;
+    const float* ub = lnf ? uvp + (size_t)i * 2 * (3 * D + e->Hm) : nullptr;   // this block's [u_qkv | v_qkv | u_fc1 | v_fc1] of sample 0
+    if (!ln1_fused) {
+      if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
+      tm.mark(C_LN);
+    }
     GemmArgs g{};
     g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
     const half_t* attn_out = e->xn;
@@ -257,7 +296,10 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       QkvAttnArgs qa{};
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
-      qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-3 switch the default schedule features OFF (A/B hook)
+      qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-4 switch the default schedule features OFF (A/B hook)
+      if (ln1_fused) {
+        qa.ln.stats = acc_ln1; qa.ln.u = ub; qa.ln.v = ub + 3 * D; qa.ln.uv_stride = uv_stride; qa.ln.inv_n = 1.0f / (float)D; qa.ln.eps = 1e-6f;
+      }
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
       attn_out = e->qkv;
@@ -274,6 +316,27 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     }
     g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
+    if (lnf) {
+      // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), row
+      // sums -> acc_ln2; its tn == 0 tiles clear acc_ln1, which this block's qkv has finished with
+      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.acc = acc_ln2; g.ln.zero = acc_ln1;
+      if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
+      tm.mark(C_PROJ);
+      g.ln = LnFuse{};
+      g.ln.stats = acc_ln2; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride; g.ln.inv_n = 1.0f / (float)D; g.ln.eps = 1e-6f;
+      g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
+      if ((rc = launch_gemm(g, EPI_LN_GELU_H16, dt, 0, st))) return rc;
+      tm.mark(C_FC1);
+      // fc2: x += gate_mlp (.), and the NEXT block's LN1 operand x (1 + scale_msa[i + 1]) -> xn, row sums -> acc_ln1 -- unless the next
+      // LayerNorm is not a fused one (block 1: temp_embed first; after the last block: the final layer's own); clears acc_ln2
+      g.ln = LnFuse{};
+      const bool emit = i >= 1 && i + 1 < c.depth;
+      g.ln.xn = emit ? e->xn : nullptr; g.ln.scale = emit ? mb + 6 * D + D : nullptr; g.ln.acc = acc_ln1; g.ln.zero = acc_ln2;
+      g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
+      if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
+      tm.mark(C_FC2);
+      continue;
+    }
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
@@ -476,6 +539,24 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   TRY(dev_alloc(e, &e->cvec, (size_t)max_batch * D));
   TRY(dev_alloc(e, &e->model_out, (size_t)max_batch * e->F * e->Cout * e->H * e->H));
   TRY(dev_alloc(e, &e->noise_buf, (size_t)max_batch * e->F * e->Cin * e->H * e->H));
+  {  // LayerNorm fusion: row-sum accumulators (zero = their idle state), u / v vectors, the table of the linears they belong to
+    e->uv_row = (int64_t)c.depth * 2 * (3 * D + e->Hm);
+    TRY(dev_alloc(e, &e->lnstat, (size_t)2 * e->rows_pad * 2));
+    TRY(dev_alloc(e, &e->uv, (size_t)max_batch * e->uv_row));
+    std::vector<ModvecEntry> tab;
+    for (int i = 0; i < c.depth; ++i) {
+      const BlockW& w = e->blocks[i];
+      const int mo = i * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+      const long uo = (long)i * 2 * (3 * D + e->Hm);
+      tab.push_back(ModvecEntry{w.qkv_w, w.qkv_b, 3 * D, mo + D, mo, uo});
+      tab.push_back(ModvecEntry{w.fc1_w, w.fc1_b, e->Hm, mo + 4 * D, mo + 3 * D, uo + 2 * 3 * D});
+    }
+    TRY(dev_alloc(e, &e->modvec_tab, tab.size()));
+    if (hipMemcpy(e->modvec_tab, tab.data(), tab.size() * sizeof(ModvecEntry), hipMemcpyHostToDevice) != hipSuccess) {
+      latte_engine_destroy(e);
+      return fail(LATTE_ERR_HIP, "engine_create: modvec table upload");
+    }
+  }
 #undef TRY
   *out = e;
   return LATTE_OK;
@@ -521,6 +602,11 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     if (value < 0 || value > 31)
       return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..31)");
     e->fuse_qkv_attn = (int)value;
+    return LATTE_OK;
+  }
+  if (k == "fuse_ln") {
+    if (value < 0 || value > 1) return fail(LATTE_ERR_INVALID, "fuse_ln: 0 (separate LayerNorm-modulate kernel) or 1 (folded into the GEMM epilogues where the shape allows it)");
+    e->fuse_ln = (int)value;
     return LATTE_OK;
   }
   if (k == "seed") {
@@ -708,6 +794,13 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
   if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_chunk * D))) return rc;
   if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_chunk * e->nmod))) return rc;
   if (ex == 78 && (rc = grow(e, &e->cond_rows_t, &e->cond_t_cap, rows_chunk * D))) return rc;
+  // LayerNorm fusion: the u / v vectors of a conditioning row depend on (timestep, label) only, like the row itself -- computed per
+  // chunk next to the adaLN outputs (run_forward's own rule decides whether they are used)
+  const int Mrun = batch * e->F * e->T;
+  const bool chain_lnf = e->fuse_ln && (e->fuse_qkv_attn & 3) == 3 && e->gemm_variant == 0 && !e->gemm_variant_of[1] && !e->gemm_variant_of[2] &&
+                         !e->gemm_variant_of[3] && e->cfg.depth >= 2 &&
+                         ln_fusable_shape(D, e->Hm, e->cfg.num_heads, e->hd, e->F, e->T, Mrun);
+  if (chain_lnf && (rc = grow(e, &e->uv_all, &e->uv_all_cap, rows_chunk * e->uv_row))) return rc;
   const size_t fo = (size_t)e->cfg.depth * 6 * D;
   // conditioning of respaced steps [lo, lo + cnt): rows ordered by index ascending, row (i - lo) * bu + b
   auto chain_conditioning = [&](int lo, int cnt) -> int {
@@ -725,6 +818,8 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
           (r2 = launch_small_linear(IN_PLAIN, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
                                     nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return r2;
     }
+    if (chain_lnf && (r2 = launch_modvec(e->modvec_tab, 2 * e->cfg.depth, std::max(3 * D, e->Hm), e->mod_all, e->nmod, (int)rows_all, e->uv_all,
+                                         e->uv_row, D, e->cfg.compute_dtype, st))) return r2;
     return LATTE_OK;
   };
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
@@ -736,7 +831,8 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
       if ((rc = chain_conditioning(chunk_lo, i - chunk_lo + 1))) return rc;
     }
     const float* mod_i = e->mod_all + (size_t)(i - chunk_lo) * bu * e->nmod;
-    if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod))) return rc;
+    const float* uv_i = chain_lnf ? e->uv_all + (size_t)(i - chunk_lo) * bu * e->uv_row : nullptr;
+    if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod, uv_i))) return rc;
     SamplerCoefs c = make_coefs(s, method, i, eta, clip_denoised);
     c.cfg_scale = cfg_scale;
     const bool need_noise = (method == LATTE_METHOD_DDPM) ? (i != 0) : (c.sigma != 0.0f && i != 0);

@@ -540,6 +540,75 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       }
       return;
     }
+    if constexpr (EPI == EPI_GATE_RES_LN) {
+      // EPI_GATE_RES_F32 + the next LayerNorm-modulate's operand (common.h: LnFuse).  The wave holds the NEW residual values of
+      // 128 rows x 48 columns in registers: it also stores a = x_new (1 + scale) as half (8 B per lane and fragment) and adds
+      // each row's sum x_new, sum x_new^2 over these 48 columns to the row's fixed-point accumulator (lanes 0-15: one row each,
+      // two 64-bit integer atomics per fragment row -- order-independent, so reruns are bit-identical).  The launcher guarantees
+      // rows_per_sample % 256 == 0, M % 256 == 0 (no row guards) and M N 4 < 4 GiB.  All global accesses are BUFFER operations on
+      // one per-lane byte offset plus scalar offsets: per-fragment 64-bit pointers (two VGPRs each, hoisted by the compiler) do
+      // not fit the 168 registers a wave of this kernel has next to its 96 accumulators.
+      const unsigned nbytes = (unsigned)g.M * (unsigned)g.N * 4u;
+      const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, nbytes, 0x00020000);
+      const bool emit = g.ln.xn != nullptr;
+      const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(emit ? g.ln.xn : (half_t*)g.out), 0, nbytes >> 1, 0x00020000);
+      const unsigned voff = ((unsigned)fr * (unsigned)g.N + (unsigned)((le >> 4) * 4)) * 4u;                        // lane part
+      const unsigned sbase = ((unsigned)(tm_ * BM + grp * 128) * (unsigned)g.N + (unsigned)(tn_ * BN + wn * WTN)) * 4u;   // wave part
+      const unsigned srow16 = 16u * (unsigned)g.N * 4u;
+      const size_t srow = (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
+      float4 b4[FN], g1[FN], s4[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        b4[j] = *(const float4*)(g.bias + ncol + j * 16);
+        g1[j] = *(const float4*)(g.gate + srow + j * 16);
+        s4[j] = emit ? *(const float4*)(g.ln.scale + srow + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (g.ln.zero != nullptr && tn_ == 0 && wn == 0) {   // this tile row's 128-row half of the accumulator the last consumer is done with
+        u32x4* z = (u32x4*)(g.ln.zero + (size_t)(tm_ * BM + grp * 128) * 2);
+        z[le] = (u32x4){0u, 0u, 0u, 0u};
+        z[le + 64] = (u32x4){0u, 0u, 0u, 0u};
+      }
+      constexpr int NF = 8 * FN, AHEAD = 2;
+      auto soff = [&](int f) -> unsigned { return sbase + (unsigned)(f / FN) * srow16 + (unsigned)((f % FN) * 64); };
+      u32x4 qa[AHEAD];
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a) qa[a] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(a), 0);
+      float p1 = 0.f, p2 = 0.f;
+      long long* const accp = g.ln.acc + (size_t)mbase * 2;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        f32x4 rr = __builtin_bit_cast(f32x4, qa[f % AHEAD]);
+        if (f + AHEAD < NF) qa[f % AHEAD] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(f + AHEAD), 0);
+        asm volatile("" ::: "memory");
+        const int i = f / FN, j = f % FN;
+        rr[0] += g1[j].x * (acc[i][j][0] + b4[j].x);
+        rr[1] += g1[j].y * (acc[i][j][1] + b4[j].y);
+        rr[2] += g1[j].z * (acc[i][j][2] + b4[j].z);
+        rr[3] += g1[j].w * (acc[i][j][3] + b4[j].w);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rr), rsO, voff, soff(f), 0);
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (emit) {
+          const u32x2 pk = {pack2<DT>(__builtin_fmaf(rr[0], s4[j].x, rr[0]), __builtin_fmaf(rr[1], s4[j].y, rr[1])),
+                            pack2<DT>(__builtin_fmaf(rr[2], s4[j].z, rr[2]), __builtin_fmaf(rr[3], s4[j].w, rr[3]))};
+          __builtin_amdgcn_raw_buffer_store_b64(pk, rsX, voff >> 1, soff(f) >> 1, 0);
+          p1 += (rr[0] + rr[1]) + (rr[2] + rr[3]);
+          p2 += (rr[0] * rr[0] + rr[1] * rr[1]) + (rr[2] * rr[2] + rr[3] * rr[3]);
+          if (j == FN - 1) {   // fragment row complete: the row's 48 columns sit in lanes fr, fr + 16, fr + 32, fr + 48
+            p1 += __shfl_xor(p1, 16, 64);
+            p2 += __shfl_xor(p2, 16, 64);
+            p1 += __shfl_xor(p1, 32, 64);
+            p2 += __shfl_xor(p2, 32, 64);
+            if (le < 16) {
+              __hip_atomic_fetch_add(accp + i * 32, (long long)((double)p1 * LN_SUM_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(accp + i * 32 + 1, (long long)((double)p2 * LN_SQ_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            p1 = 0.f;
+            p2 = 0.f;
+          }
+        }
+      }
+      return;
+    }
     if constexpr (EPI == EPI_GATE_RES_F32) {
       if ((g.rows_per_sample % BM) == 0) {
         float* const outp = (float*)g.out;
@@ -714,7 +783,12 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
       hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                             \
     }                                                                                                \
   }
-  if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
+  if (epi == EPI_GATE_RES_LN) {
+    if (!roll || a.rows_per_sample % 256 != 0 || a.M % 256 != 0 || a.ln.acc == nullptr || (a.ln.xn != nullptr && a.ln.scale == nullptr))
+      return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue needs the rolling 12-wave kernel, whole 256-row tiles inside a sample and an accumulator");
+    if ((uint64_t)a.M * a.N * 4 >= (1ull << 32)) return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue addresses its output through 32-bit buffer offsets (M N 4 < 4 GiB)");
+    if (a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_LN, 1) else LATTE_PW_CASE(EPI_GATE_RES_LN, 0)
+  } else if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
   else if (epi == EPI_GATE_RES_F32) LATTE_PW_CASE(EPI_GATE_RES_F32, 0)
   else if (epi == EPI_BIAS_F32) LATTE_PW_CASE(EPI_BIAS_F32, 0)
   else if (epi == EPI_BIAS_H16) LATTE_PW_CASE(EPI_BIAS_H16, 0)

@@ -118,15 +118,22 @@ int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int
   return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
 }
 
-// loss-scale state -> device.  reset: also clear the counters (create).  Synchronous (an option call, not on the step path).
-int upload_scaler(latte_trainer* e, bool reset) {
+// loss-scale state -> device.  what: 0 = everything incl. the counters (create), 1 = a new scale (restarts the growth count),
+// 2 = the policy fields only (dynamic on / off, growth interval): the live scale and the counters stay.  Synchronous (an option
+// call, not on the step path).
+int upload_scaler(latte_trainer* e, int what) {
   float h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (!reset) LATTE_HIP(hipMemcpy(h, e->scaler, sizeof(h), hipMemcpyDeviceToHost));
-  h[0] = e->loss_scale;
-  h[1] = 0.0f;
+  if (what != 0) {
+    LATTE_HIP(hipDeviceSynchronize());
+    LATTE_HIP(hipMemcpy(h, e->scaler, sizeof(h), hipMemcpyDeviceToHost));
+  }
+  if (what != 2) {
+    h[0] = e->loss_scale;
+    h[1] = 0.0f;
+  }
   h[5] = (float)e->dynamic_scale;
   h[6] = e->growth_interval;
-  h[7] = std::max(e->loss_scale, 65536.0f);
+  h[7] = std::max(std::max(e->loss_scale, h[0]), 65536.0f);
   LATTE_HIP(hipMemcpy(e->scaler, h, sizeof(h), hipMemcpyHostToDevice));
   return LATTE_OK;
 }
@@ -233,7 +240,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   A(&e->sumsq, (size_t)sumsq_blocks());
   A(&e->dyD, R * D); A(&e->dhH, R * Hm); A(&e->dxnH, R * D); A(&e->dqkvH, R * 3 * D); A(&e->xnh, R * D);
   if (!rc) rc = launch_fill_f32(e->ones, 1.0f, R, nullptr);
-  if (!rc) rc = upload_scaler(e, true);
+  if (!rc) rc = upload_scaler(e, 0);
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(LATTE_ERR_HIP, "trainer_create: device error");
   if (rc) { latte_trainer_destroy(e); return rc; }
   *out = e;
@@ -441,16 +448,16 @@ int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value)
     if (!(value >= 1.0) || value > 16777216.0 || std::frexp(value, &ex) != 0.5)
       return fail(LATTE_ERR_INVALID, "loss_scale must be a power of two in [1, 2^24]");
     e->loss_scale = (float)value;
-    return upload_scaler(e, false);
+    return upload_scaler(e, 1);
   }
   if (std::string(name) == "dynamic_loss_scale") {   // 0: the scale stays what "loss_scale" set (overflowing steps are still skipped)
     e->dynamic_scale = value != 0.0 ? 1 : 0;
-    return upload_scaler(e, false);
+    return upload_scaler(e, 2);
   }
   if (std::string(name) == "loss_scale_growth_interval") {
     if (!(value >= 1.0) || value > 1e7) return fail(LATTE_ERR_INVALID, "loss_scale_growth_interval must be in [1, 1e7]");
     e->growth_interval = (float)value;
-    return upload_scaler(e, false);
+    return upload_scaler(e, 2);
   }
   return fail(LATTE_ERR_INVALID, std::string("trainer_set_option: unknown option '") + name + "'");
 }
