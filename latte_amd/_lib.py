@@ -153,11 +153,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LATTE_AMD_LIB") or LIB_PATH     # LATTE_AMD_LIB: the measurement build (latte_amd/build.py), tools only
+    if not os.path.exists(path):
         raise LatteError(
-            f"{LIB_PATH} not found: build it with `python -m latte_amd.build` (hipcc, gfx950). "
+            f"{path} not found: build it with `python -m latte_amd.build` (hipcc, gfx950). "
             "latte_amd has no CPU or PyTorch fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)

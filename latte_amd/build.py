@@ -10,15 +10,18 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
+DEBUG_BUILD = bool(os.environ.get("LATTE_DEBUG_BUILD"))
+# the measurement build (ablation instantiations, LnFuse::dbg, "ln_dbg" engine option) lives beside the product library and is only
+# ever loaded when LATTE_AMD_LIB names it (tools/, never tests or bench defaults)
+OBJ = os.path.join(HERE, "build_dbg" if DEBUG_BUILD else "build")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "liblatte_amd.so")
+LIB = os.path.join(LIBDIR, "liblatte_amd_dbg.so" if DEBUG_BUILD else "liblatte_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["gemm.hip", "gemm_pw.hip", "gemm_tn.hip", "train.hip", "train_attn.hip", "attention.hip", "qkv_attn.hip", "pointwise.hip", "debug.hip", "vae.hip", "engine.cpp", "train_engine.cpp", "vae_engine.cpp", "t2v_engine.cpp", "schedule.cpp"]
 COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-if os.environ.get("LATTE_DEBUG_BUILD"):   # measurement build: main-loop / epilogue ablation instantiations of the GEMM
+if DEBUG_BUILD:   # measurement build: main-loop / epilogue ablation instantiations of the GEMM
     COMMON.append("-DLATTE_GEMM_ABLATE")
 FLAGS = {
     ".hip": COMMON + ["-O3"],

@@ -102,6 +102,9 @@ struct LnFuse {
   const float* v;          // per sample [N]: shift W^T + bias
   int uv_stride;
   float inv_n, eps;        // 1 / (row length of the LayerNorm), 1e-6
+  int dbg;                 // measurement build (LATTE_DEBUG_BUILD=1) only, results garbage: bit 0 = producer skips the row-sum atomics,
+                           // bit 1 = producer skips the operand stores, bit 2 = plain 8-byte stores in place of the atomics,
+                           // bit 3 = consumers skip the statistics loads
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)

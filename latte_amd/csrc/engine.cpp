@@ -97,6 +97,7 @@ struct latte_engine {
   // between a gated GEMM and the linear that follows it lives in the two GEMMs' epilogues instead of its own HBM pass; 0 = the
   // separate ln_modulate kernel everywhere
   int fuse_ln = 1;
+  int ln_dbg = 0;                          // measurement build only: LnFuse::dbg of every launch (ablations, results garbage)
   long long* lnstat = nullptr;             // [2][rows_pad][2] fixed-point row sums: [0] LN2 (proj -> fc1), [1] LN1 (fc2 -> next qkv)
   float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]
   int64_t uv_all_cap = 0;
@@ -319,11 +320,11 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     if (lnf) {
       // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), row
       // sums -> acc_ln2; its tn == 0 tiles clear acc_ln1, which this block's qkv has finished with
-      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.acc = acc_ln2; g.ln.zero = acc_ln1;
+      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.acc = acc_ln2; g.ln.zero = acc_ln1; g.ln.dbg = e->ln_dbg;
       if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
       tm.mark(C_PROJ);
       g.ln = LnFuse{};
-      g.ln.stats = acc_ln2; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride; g.ln.inv_n = 1.0f / (float)D; g.ln.eps = 1e-6f;
+      g.ln.stats = acc_ln2; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride; g.ln.inv_n = 1.0f / (float)D; g.ln.eps = 1e-6f; g.ln.dbg = e->ln_dbg;
       g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
       if ((rc = launch_gemm(g, EPI_LN_GELU_H16, dt, 0, st))) return rc;
       tm.mark(C_FC1);
@@ -331,7 +332,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       // LayerNorm is not a fused one (block 1: temp_embed first; after the last block: the final layer's own); clears acc_ln2
       g.ln = LnFuse{};
       const bool emit = i >= 1 && i + 1 < c.depth;
-      g.ln.xn = emit ? e->xn : nullptr; g.ln.scale = emit ? mb + 6 * D + D : nullptr; g.ln.acc = acc_ln1; g.ln.zero = acc_ln2;
+      g.ln.xn = emit ? e->xn : nullptr; g.ln.scale = emit ? mb + 6 * D + D : nullptr; g.ln.acc = acc_ln1; g.ln.zero = acc_ln2; g.ln.dbg = e->ln_dbg;
       g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
       if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
       tm.mark(C_FC2);
@@ -541,7 +542,7 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   TRY(dev_alloc(e, &e->noise_buf, (size_t)max_batch * e->F * e->Cin * e->H * e->H));
   {  // LayerNorm fusion: row-sum accumulators (zero = their idle state), u / v vectors, the table of the linears they belong to
     e->uv_row = (int64_t)c.depth * 2 * (3 * D + e->Hm);
-    TRY(dev_alloc(e, &e->lnstat, (size_t)2 * e->rows_pad * 2));
+    TRY(dev_alloc(e, &e->lnstat, (size_t)(2 * 2 + 24) * e->rows_pad));   // (+ 24 rows_pad: the slot-store cost model of the measurement build)
     TRY(dev_alloc(e, &e->uv, (size_t)max_batch * e->uv_row));
     std::vector<ModvecEntry> tab;
     for (int i = 0; i < c.depth; ++i) {
@@ -609,6 +610,12 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     e->fuse_ln = (int)value;
     return LATTE_OK;
   }
+#ifdef LATTE_GEMM_ABLATE
+  if (k == "ln_dbg") {
+    e->ln_dbg = (int)value;
+    return LATTE_OK;
+  }
+#endif
   if (k == "seed") {
     e->seed = (uint64_t)value;
     e->rng_offset = 0;

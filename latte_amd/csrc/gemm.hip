@@ -707,6 +707,12 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) st8[i] = *(const u32x4*)(g.ln.stats + (size_t)min(mrow0 + i * 16 + fr, g.M - 1) * 2);
+#ifdef LATTE_GEMM_ABLATE
+        if (g.ln.dbg & 8) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) st8[i] = (u32x4){(unsigned)le, 0u, 1u << 28, 0u};
+        }
+#endif
       } else {
 #pragma unroll
         for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);

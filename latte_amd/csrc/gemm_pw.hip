@@ -575,6 +575,15 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       for (int a = 0; a < AHEAD; ++a) qa[a] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(a), 0);
       float p1 = 0.f, p2 = 0.f;
       long long* const accp = g.ln.acc + (size_t)mbase * 2;
+      // the half operand goes through the wave-private LDS patch (16 rows, pitch 112 B: the half-output epilogue's) so that the
+      // global stores are 16 B per lane on contiguous 96-byte row segments -- 1.5 store instructions per fragment row instead of
+      // three 8-byte ones on 32-byte pieces: the epilogue burst of this kernel is bound by the NUMBER of memory requests
+      // (profiles/r4_ln_fusion_ablation.log), not by their bytes
+      char* const patch = smem + B_BASE + 2 * B_BYTES + wave * PATCH_BYTES;
+      const int gq = le >> 4;
+      const int r0 = le / 6, p0 = le - r0 * 6;               // piece le      -> (row, 16-byte piece) of the 16 x 6 grid
+      const int r1 = (le + 64) / 6, p1_ = (le + 64) - r1 * 6; // piece le + 64 (lanes 0-31)
+      const unsigned vx0 = ((unsigned)r0 * (unsigned)g.N + (unsigned)(p0 * 8)) * 2u, vx1 = ((unsigned)r1 * (unsigned)g.N + (unsigned)(p1_ * 8)) * 2u;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         f32x4 rr = __builtin_bit_cast(f32x4, qa[f % AHEAD]);
@@ -590,7 +599,28 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
         if (emit) {
           const u32x2 pk = {pack2<DT>(__builtin_fmaf(rr[0], s4[j].x, rr[0]), __builtin_fmaf(rr[1], s4[j].y, rr[1])),
                             pack2<DT>(__builtin_fmaf(rr[2], s4[j].z, rr[2]), __builtin_fmaf(rr[3], s4[j].w, rr[3]))};
-          __builtin_amdgcn_raw_buffer_store_b64(pk, rsX, voff >> 1, soff(f) >> 1, 0);
+#ifdef LATTE_GEMM_ABLATE
+          if (g.ln.dbg & 16) {   // the direct form: 8 B per lane
+            if (!(g.ln.dbg & 2)) __builtin_amdgcn_raw_buffer_store_b64(pk, rsX, voff >> 1, soff(f) >> 1, 0);
+          } else
+#endif
+          {
+            *(u32x2*)(patch + fr * 112 + j * 32 + gq * 8) = pk;
+            if (j == FN - 1) {
+              const unsigned sx = (sbase + (unsigned)i * srow16) >> 1;
+              const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
+#ifdef LATTE_GEMM_ABLATE
+              if (!(g.ln.dbg & 2))
+#endif
+              {
+                __builtin_amdgcn_raw_buffer_store_b128(w0, rsX, vx0, sx, 0);
+                if (le < 32) {
+                  const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1_ * 16);
+                  __builtin_amdgcn_raw_buffer_store_b128(w1, rsX, vx1, sx, 0);
+                }
+              }
+            }
+          }
           p1 += (rr[0] + rr[1]) + (rr[2] + rr[3]);
           p2 += (rr[0] * rr[0] + rr[1] * rr[1]) + (rr[2] * rr[2] + rr[3] * rr[3]);
           if (j == FN - 1) {   // fragment row complete: the row's 48 columns sit in lanes fr, fr + 16, fr + 32, fr + 48
@@ -598,6 +628,11 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
             p2 += __shfl_xor(p2, 16, 64);
             p1 += __shfl_xor(p1, 32, 64);
             p2 += __shfl_xor(p2, 32, 64);
+#ifdef LATTE_GEMM_ABLATE
+            if (g.ln.dbg & 4) {
+              if (le < 16) *(float2*)(accp + i * 32 + (tn_ * 4 + wn) * (size_t)g.M) = make_float2(p1, p2);   // slot-store cost model (acc must hold 24 x M x 8 B)
+            } else if (!(g.ln.dbg & 1))
+#endif
             if (le < 16) {
               __hip_atomic_fetch_add(accp + i * 32, (long long)((double)p1 * LN_SUM_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_fetch_add(accp + i * 32 + 1, (long long)((double)p2 * LN_SQ_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

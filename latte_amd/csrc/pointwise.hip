@@ -933,10 +933,11 @@ __device__ __forceinline__ void unpack8(const mv_u32x4 w, float (&f)[8]) {
       f[2 * i] = __uint_as_float(w[i] << 16);
       f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
     } else {
-      typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
-      const f16x2_ h = __builtin_bit_cast(f16x2_, w[i]);
-      f[2 * i] = (float)h[0];
-      f[2 * i + 1] = (float)h[1];
+      // (scalar copy and 16-bit pieces: bit-casting the vector element to an f16 pair was miscompiled into re-using element 0,
+      //  the issue documented at gemm.hip's EPI_BIAS_RES_H16)
+      const unsigned int u = w[i];
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
     }
   }
 }

@@ -186,10 +186,15 @@ __device__ __forceinline__ void load_oct(const void* x, size_t oct_index, float 
   }
 }
 
+// Round 4: the pass streams (four independent 16 / 32-byte loads in flight per thread) and its workgroup reduction is two short
+// fixed-order steps -- (pixel lanes -> one sum per half-octet column, then columns -> groups) -- instead of 32 threads each walking
+// all 256 per-thread partials with a division per step: that serial tail and one load in flight per thread held the pass at
+// 2.2 TB/s on the 128 x 256 x 256 map (537 MB fp32 per 16 frames; profiles/r3_kernel_stats_forward_B8_plus_vae_decode.csv).
 template <int DT, bool IN32>
 __global__ void __launch_bounds__(256) gn_partial_kernel(const void* __restrict__ x, float* __restrict__ partial, int HW,
                                                          int C, int slabs) {
   __shared__ float red[256 * 4];
+  __shared__ float col[128 * 2];
   const int n = blockIdx.y, slab = blockIdx.x;
   const int oct_per_px = C >> 3;               // threads per pixel
   const int px_per_it = 256 / oct_per_px;      // C in {128, 256, 512} -> 16, 8, 4 pixels per iteration
@@ -197,28 +202,49 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const void* __restrict_
   const int per = (HW + slabs - 1) / slabs;
   const int p0 = slab * per, p1 = min(HW, p0 + per);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;   // channels [8 oct, +4) and [8 oct + 4, +4)
-  for (int p = p0 + pl; p < p1; p += px_per_it) {
-    float f[8];
-    load_oct<DT, IN32>(x, ((size_t)n * HW + p) * oct_per_px + oct, f);
+  auto add = [&](const float (&f)[8]) {
     s0 += f[0] + f[1]; q0 += f[0] * f[0] + f[1] * f[1];
     s0 += f[2] + f[3]; q0 += f[2] * f[2] + f[3] * f[3];
     s1 += f[4] + f[5]; q1 += f[4] * f[4] + f[5] * f[5];
     s1 += f[6] + f[7]; q1 += f[6] * f[6] + f[7] * f[7];
+  };
+  const size_t base = (size_t)n * HW;
+  int p = p0 + pl;
+  for (; p + 3 * px_per_it < p1; p += 4 * px_per_it) {   // same pixel order per thread as a one-by-one walk: same sums
+    float f0[8], f1[8], f2[8], f3[8];
+    load_oct<DT, IN32>(x, (base + p) * oct_per_px + oct, f0);
+    load_oct<DT, IN32>(x, (base + p + px_per_it) * oct_per_px + oct, f1);
+    load_oct<DT, IN32>(x, (base + p + 2 * px_per_it) * oct_per_px + oct, f2);
+    load_oct<DT, IN32>(x, (base + p + 3 * px_per_it) * oct_per_px + oct, f3);
+    add(f0); add(f1); add(f2); add(f3);
+  }
+  for (; p < p1; p += px_per_it) {
+    float f[8];
+    load_oct<DT, IN32>(x, (base + p) * oct_per_px + oct, f);
+    add(f);
   }
   red[threadIdx.x * 4 + 0] = s0; red[threadIdx.x * 4 + 1] = q0;
   red[threadIdx.x * 4 + 2] = s1; red[threadIdx.x * 4 + 3] = q1;
   __syncthreads();
-  if (threadIdx.x < 32) {
-    const int gi = threadIdx.x, cpg = C >> 5;    // channels per group: 4, 8, 16
+  // column j = 2 oct + h (4 consecutive channels): sum over the pixel lanes, in lane order
+  const int ncol = 2 * oct_per_px;              // 32, 64, 128
+  if ((int)threadIdx.x < ncol) {
+    const int o = threadIdx.x >> 1, h = threadIdx.x & 1;
     float s = 0.f, q = 0.f;
-    for (int t = 0; t < 256; ++t) {
-      const int o = t % oct_per_px;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if ((o * 8 + h * 4) / cpg == gi) {
-          s += red[t * 4 + 2 * h];
-          q += red[t * 4 + 2 * h + 1];
-        }
+    for (int l = 0; l < px_per_it; ++l) {
+      s += red[(l * oct_per_px + o) * 4 + 2 * h];
+      q += red[(l * oct_per_px + o) * 4 + 2 * h + 1];
+    }
+    col[threadIdx.x * 2] = s;
+    col[threadIdx.x * 2 + 1] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int gi = threadIdx.x, cpc = ncol >> 5;   // columns per group: 1, 2, 4
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < cpc; ++k) {
+      s += col[(gi * cpc + k) * 2];
+      q += col[(gi * cpc + k) * 2 + 1];
     }
     float* out = partial + (((size_t)n * slabs + slab) * 32 + gi) * 2;
     out[0] = s;
