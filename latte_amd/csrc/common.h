@@ -83,28 +83,26 @@ enum GemmEpi : int {
 //     y = Linear(LN(x) (1 + sc) + sh),   LN(x) = (x - mu) r,  r = rsqrt(var + eps)        (per row; sc, sh per sample)
 // which is, exactly,   y[n] = r (sum_k x_k (1 + sc_k) W[n,k]  -  mu u[n]) + v[n],   u = (1 + sc) W^T,  v = sh W^T + b.
 // So the GEMM that PRODUCES x (the gated residual update) also writes the half operand a = x (1 + sc) (it holds the fp32 row
-// patch in registers anyway) and adds its tile's share of sum x, sum x^2 into a per-row accumulator; the GEMM that CONSUMES it
-// multiplies a W^T as before and applies r, mu, u, v in its epilogue.  The separate LN pass (read 4 B + write 2 B per element,
-// 56 launches, 8 % of the XL/2 step) disappears.  The row sums are 64-bit FIXED-POINT integers added with atomics: integer
-// addition is associative, so the result does not depend on the order in which the six column tiles of a row arrive
-// (bit-reproducible runs), unlike float atomics.
-constexpr double LN_SUM_SCALE = 4294967296.0;   // 2^32: sum x    (|partial| < 2^31: no realistic activation gets near)
-constexpr double LN_SQ_SCALE = 268435456.0;     // 2^28: sum x^2  (a 48-column partial may reach 3.4e10: rms |x| < 2.6e4)
+// patch in registers anyway) and, per wave, its 48 columns' share of sum x, sum x^2 of every row into that wave's own SLOT
+// (slot = column tile * 4 + wave column: plain 8-byte stores, nothing is accumulated in memory, no state survives a launch);
+// ln_rowstat_kernel adds a row's slots in a fixed order (fp64) and leaves (r, r mu) per row; the GEMM that CONSUMES the operand
+// multiplies a W^T as before and applies r, r mu, u, v in its epilogue.  The separate LN pass (read 4 B + write 2 B per element,
+// 56 launches, 8 % of the XL/2 step) becomes a 6 MB pass.  (First version, measured and replaced: 64-bit fixed-point atomics
+// instead of slots -- order-independent too, but 14 us per launch in the producers' request-bound epilogue burst and fp64
+// conversions in every consumer tile; profiles/r4_ln_fusion_ablation_v1_atomics.log.)
 struct LnFuse {
   // producer (EPI_GATE_RES_LN)
-  half_t* xn;              // [Mpad, N] half: x_new (1 + scale[sample]); nullptr = emit nothing (only `zero` is serviced)
+  half_t* xn;              // [Mpad, N] half: x_new (1 + scale[sample]); nullptr = emit nothing
   const float* scale;      // the next modulate's scale vector, per sample: scale + sample * gate_stride
-  long long* acc;          // [Mpad][2]: += sum x_new 2^32, += sum x_new^2 2^28 over the tile's columns (must be zero before the launch)
-  long long* zero;         // [Mpad][2]: the accumulator the previous consumer has finished with; the tn == 0 tiles clear their rows
+  float* slots;            // [N / 48][M][2]: (sum, sum of squares) of x_new over the wave's 48 columns
   // consumer (EPI_LN_GELU_H16 / EPI_LN_H16, and the fused qkv + attention kernel)
-  const long long* stats;  // [Mpad][2] as accumulated by the producer
+  const float* r;          // [Mpad] rsqrt(var + eps) of the row              (ln_rowstat_kernel)
+  const float* rm;         // [Mpad] r * mean
   const float* u;          // per sample [N]: (1 + scale) W^T    (row stride uv_stride floats; fp32 sums over the HALF weights)
   const float* v;          // per sample [N]: shift W^T + bias
   int uv_stride;
-  float inv_n, eps;        // 1 / (row length of the LayerNorm), 1e-6
-  int dbg;                 // measurement build (LATTE_DEBUG_BUILD=1) only, results garbage: bit 0 = producer skips the row-sum atomics,
-                           // bit 1 = producer skips the operand stores, bit 2 = plain 8-byte stores in place of the atomics,
-                           // bit 3 = consumers skip the statistics loads
+  int dbg;                 // measurement build (LATTE_DEBUG_BUILD=1) only, results garbage: bit 0 = producer skips the slot stores,
+                           // bit 1 = producer skips the operand stores, bit 4 = operand stores as direct 8-byte stores
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -176,7 +174,7 @@ struct QkvAttnArgs {
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
-  LnFuse ln;           // ln.stats != nullptr: xn is the un-normalised operand x (1 + scale) of a producer GEMM and the image-write
+  LnFuse ln;           // ln.r != nullptr: xn is the un-normalised operand x (1 + scale) of a producer GEMM and the image-write
                        // phase applies r (acc - mu u) + v (u, v: [3 D] per sample, v includes the bias) -- `bias` is unused then
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
@@ -214,6 +212,8 @@ struct ModvecEntry {
   int scale_off, shift_off;   // float offsets inside a conditioning row
   long uv_off;                // float offset inside an output row
 };
+// (r, r mean) of every row from the producer's slots: slots [nslots][M][2], sums in slot order (fp64), row length n_cols
+int launch_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, hipStream_t st);
 int launch_modvec(const ModvecEntry* tab_dev, int entries, int max_n, const float* mod, long mod_stride, int R, float* uv, long uv_stride,
                   int K, int dtype, hipStream_t st);
 // x[M, N] += gate[m / rows_per_sample, :] * (sum of `splits` fp32 partial products (slab stride `stride`) + bias): the reduction

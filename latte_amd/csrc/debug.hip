@@ -192,20 +192,23 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
 
 // ---- LayerNorm fusion pieces (common.h: LnFuse)
 int latte_debug_gemm_gate_ln(const void* A, const void* W, const float* bias, float* res, const float* gate, const float* scale, int vec_stride,
-                             void* xn_out, long long* acc, long long* zero, int M, int N, int K, int rows_per_sample, int tag, int dtype,
-                             void* stream) {
+                             void* xn_out, float* slots, int M, int N, int K, int rows_per_sample, int tag, int dtype, void* stream) {
   GemmArgs g{};
   g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = res; g.gate = gate; g.M = M; g.N = N; g.K = K;
   g.gate_stride = vec_stride; g.rows_per_sample = rows_per_sample; g.tag = tag;
-  g.ln.xn = (half_t*)xn_out; g.ln.scale = scale; g.ln.acc = acc; g.ln.zero = zero;
+  g.ln.xn = (half_t*)xn_out; g.ln.scale = scale; g.ln.slots = slots;
   return launch_gemm(g, EPI_GATE_RES_LN, dtype, 0, (hipStream_t)stream);
 }
 
-int latte_debug_gemm_ln_consume(const void* A, const void* W, const long long* stats, const float* u, const float* v, int uv_stride, void* out,
-                                int M, int N, int K, int rows_per_sample, int gelu, float eps, int dtype, void* stream) {
+int latte_debug_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, void* stream) {
+  return launch_ln_rowstat(slots, nslots, M, n_cols, eps, r, rm, (hipStream_t)stream);
+}
+
+int latte_debug_gemm_ln_consume(const void* A, const void* W, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
+                                void* out, int M, int N, int K, int rows_per_sample, int gelu, int dtype, void* stream) {
   GemmArgs g{};
   g.A = (const half_t*)A; g.W = (const half_t*)W; g.out = out; g.M = M; g.N = N; g.K = K; g.rows_per_sample = rows_per_sample;
-  g.ln.stats = stats; g.ln.u = u; g.ln.v = v; g.ln.uv_stride = uv_stride; g.ln.inv_n = 1.0f / (float)K; g.ln.eps = eps;
+  g.ln.r = r; g.ln.rm = rm; g.ln.u = u; g.ln.v = v; g.ln.uv_stride = uv_stride;
   return launch_gemm(g, gelu ? EPI_LN_GELU_H16 : EPI_LN_H16, dtype, 0, (hipStream_t)stream);
 }
 
@@ -222,14 +225,14 @@ int latte_debug_modvec(const void* W, const float* bias, int N, int K, const flo
   return rc;
 }
 
-int latte_debug_qkv_attention_ln(const void* xn, const void* w, const long long* stats, const float* u, const float* v, int uv_stride, void* out,
-                                 void* dbg_qkv, int B, int F, int T, int D, int heads, int mode, float eps, int dtype, void* stream) {
+int latte_debug_qkv_attention_ln(const void* xn, const void* w, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
+                                 void* out, void* dbg_qkv, int B, int F, int T, int D, int heads, int mode, int dtype, void* stream) {
   if (heads <= 0 || D % heads) return fail(LATTE_ERR_INVALID, "qkv_attention: D must be a multiple of heads");
   QkvAttnArgs a{};
   a.xn = (const half_t*)xn; a.w = (const half_t*)w; a.out = (half_t*)out; a.dbg_qkv = (half_t*)dbg_qkv;
   a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = 7;
   a.scale = 1.0f / sqrtf((float)a.hd);
-  a.ln.stats = stats; a.ln.u = u; a.ln.v = v; a.ln.uv_stride = uv_stride; a.ln.inv_n = 1.0f / (float)D; a.ln.eps = eps;
+  a.ln.r = r; a.ln.rm = rm; a.ln.u = u; a.ln.v = v; a.ln.uv_stride = uv_stride;
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);
 }
 

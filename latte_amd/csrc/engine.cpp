@@ -98,7 +98,7 @@ struct latte_engine {
   // separate ln_modulate kernel everywhere
   int fuse_ln = 1;
   int ln_dbg = 0;                          // measurement build only: LnFuse::dbg of every launch (ablations, results garbage)
-  long long* lnstat = nullptr;             // [2][rows_pad][2] fixed-point row sums: [0] LN2 (proj -> fc1), [1] LN1 (fc2 -> next qkv)
+  float *ln_slots = nullptr, *ln_r = nullptr, *ln_rm = nullptr;   // the producers' row-sum slots [D / 48][rows_pad][2], (r, r mu) per row
   float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]
   int64_t uv_all_cap = 0;
   int64_t uv_row = 0;                      // depth * 2 * (3 D + Hm) floats: per block [u_qkv | v_qkv | u_fc1 | v_fc1]
@@ -260,8 +260,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       return rc;
     uvp = e->uv;
   }
-  long long* const acc_ln2 = e->lnstat;                              // proj -> fc1
-  long long* const acc_ln1 = e->lnstat + (size_t)e->rows_pad * 2;    // fc2 -> the next block's qkv
   tm.mark(C_COND);
   // --- patch embed + pos_embed (latte.py:330-331)
   if (cfg_dup) {
@@ -299,7 +297,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
       qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-4 switch the default schedule features OFF (A/B hook)
       if (ln1_fused) {
-        qa.ln.stats = acc_ln1; qa.ln.u = ub; qa.ln.v = ub + 3 * D; qa.ln.uv_stride = uv_stride; qa.ln.inv_n = 1.0f / (float)D; qa.ln.eps = 1e-6f;
+        qa.ln.r = e->ln_r; qa.ln.rm = e->ln_rm; qa.ln.u = ub; qa.ln.v = ub + 3 * D; qa.ln.uv_stride = uv_stride;
       }
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
@@ -318,24 +316,32 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     }
     g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
     if (lnf) {
-      // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), row
-      // sums -> acc_ln2; its tn == 0 tiles clear acc_ln1, which this block's qkv has finished with
-      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.acc = acc_ln2; g.ln.zero = acc_ln1; g.ln.dbg = e->ln_dbg;
+      // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), the
+      // row-sum slots; ln_rowstat turns them into (r, r mu) (its few microseconds are booked with the LayerNorm class)
+      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.slots = e->ln_slots; g.ln.dbg = e->ln_dbg;
       if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
       tm.mark(C_PROJ);
+      if ((rc = launch_ln_rowstat(e->ln_slots, D / 48, M, D, 1e-6f, e->ln_r, e->ln_rm, st))) return rc;
+      tm.mark(C_LN);
       g.ln = LnFuse{};
-      g.ln.stats = acc_ln2; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride; g.ln.inv_n = 1.0f / (float)D; g.ln.eps = 1e-6f; g.ln.dbg = e->ln_dbg;
+      g.ln.r = e->ln_r; g.ln.rm = e->ln_rm; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride;
       g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
       if ((rc = launch_gemm(g, EPI_LN_GELU_H16, dt, 0, st))) return rc;
       tm.mark(C_FC1);
-      // fc2: x += gate_mlp (.), and the NEXT block's LN1 operand x (1 + scale_msa[i + 1]) -> xn, row sums -> acc_ln1 -- unless the next
-      // LayerNorm is not a fused one (block 1: temp_embed first; after the last block: the final layer's own); clears acc_ln2
+      // fc2: x += gate_mlp (.), and the NEXT block's LN1 operand x (1 + scale_msa[i + 1]) -> xn with its slots -- unless the next
+      // LayerNorm is not a fused one (block 1: temp_embed first; after the last block: the final layer's own): the plain epilogue then
       g.ln = LnFuse{};
-      const bool emit = i >= 1 && i + 1 < c.depth;
-      g.ln.xn = emit ? e->xn : nullptr; g.ln.scale = emit ? mb + 6 * D + D : nullptr; g.ln.acc = acc_ln1; g.ln.zero = acc_ln2; g.ln.dbg = e->ln_dbg;
       g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
-      if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
-      tm.mark(C_FC2);
+      if (i >= 1 && i + 1 < c.depth) {
+        g.ln.xn = e->xn; g.ln.scale = mb + 6 * D + D; g.ln.slots = e->ln_slots; g.ln.dbg = e->ln_dbg;
+        if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
+        tm.mark(C_FC2);
+        if ((rc = launch_ln_rowstat(e->ln_slots, D / 48, M, D, 1e-6f, e->ln_r, e->ln_rm, st))) return rc;
+        tm.mark(C_LN);
+      } else {
+        if ((rc = gated_gemm(e, g, dt, 0, st))) return rc;
+        tm.mark(C_FC2);
+      }
       continue;
     }
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
@@ -540,9 +546,11 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   TRY(dev_alloc(e, &e->cvec, (size_t)max_batch * D));
   TRY(dev_alloc(e, &e->model_out, (size_t)max_batch * e->F * e->Cout * e->H * e->H));
   TRY(dev_alloc(e, &e->noise_buf, (size_t)max_batch * e->F * e->Cin * e->H * e->H));
-  {  // LayerNorm fusion: row-sum accumulators (zero = their idle state), u / v vectors, the table of the linears they belong to
+  {  // LayerNorm fusion: the producers' slots, row statistics, u / v vectors, the table of the linears they belong to
     e->uv_row = (int64_t)c.depth * 2 * (3 * D + e->Hm);
-    TRY(dev_alloc(e, &e->lnstat, (size_t)(2 * 2 + 24) * e->rows_pad));   // (+ 24 rows_pad: the slot-store cost model of the measurement build)
+    TRY(dev_alloc(e, &e->ln_slots, (size_t)(D / 48 + 1) * e->rows_pad * 2));
+    TRY(dev_alloc(e, &e->ln_r, (size_t)e->rows_pad));
+    TRY(dev_alloc(e, &e->ln_rm, (size_t)e->rows_pad));
     TRY(dev_alloc(e, &e->uv, (size_t)max_batch * e->uv_row));
     std::vector<ModvecEntry> tab;
     for (int i = 0; i < c.depth; ++i) {

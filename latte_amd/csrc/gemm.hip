@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
       const int gq = le >> 4;
       float4 b4[FN], u4[LN_EPI ? FN : 1];
       const int mrow0 = tm_ * BM + grp * 128;
-      u32x4 st8[LN_EPI ? 8 : 1];   // LN_EPI: the fixed-point row sums of this lane's 8 rows (mrow0 + 16 i + fr), all fetched up front
+      float rs8[LN_EPI ? 8 : 1], rm8[LN_EPI ? 8 : 1];   // LN_EPI: (r, r mu) of this lane's 8 rows (mrow0 + 16 i + fr), fetched up front
       if constexpr (LN_EPI) {
         const size_t so = (size_t)((tm_ * BM) / g.rows_per_sample) * g.ln.uv_stride + ncol0 + gq * 4;   // tiles lie inside one sample
 #pragma unroll
@@ -706,13 +706,11 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
           u4[j] = *(const float4*)(g.ln.u + so + j * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) st8[i] = *(const u32x4*)(g.ln.stats + (size_t)min(mrow0 + i * 16 + fr, g.M - 1) * 2);
-#ifdef LATTE_GEMM_ABLATE
-        if (g.ln.dbg & 8) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) st8[i] = (u32x4){(unsigned)le, 0u, 1u << 28, 0u};
+        for (int i = 0; i < 8; ++i) {
+          const int m = min(mrow0 + i * 16 + fr, g.M - 1);
+          rs8[i] = g.ln.r[m];
+          rm8[i] = g.ln.rm[m];
         }
-#endif
       } else {
 #pragma unroll
         for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);
@@ -725,13 +723,8 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
           const int row = ii * 16 + fr;
           float rs = 1.0f, rm = 0.0f;   // r, r mu of this fragment row's LayerNorm
           if constexpr (LN_EPI) {
-            const double s1 = (double)(long long)(((unsigned long long)st8[i][1] << 32) | st8[i][0]) * (1.0 / LN_SUM_SCALE);
-            const double s2 = (double)(long long)(((unsigned long long)st8[i][3] << 32) | st8[i][2]) * (1.0 / LN_SQ_SCALE);
-            const double mu = s1 * (double)g.ln.inv_n;
-            const float var = (float)__builtin_fmax(s2 * (double)g.ln.inv_n - mu * mu, 0.0);
-            rs = __builtin_amdgcn_rsqf(var + g.ln.eps);
-            rs = rs * (1.5f - 0.5f * (var + g.ln.eps) * rs * rs);       // one Newton step: v_rsq_f32 is 1 ulp, the oracle's rsqrt exact
-            rm = rs * (float)mu;
+            rs = rs8[i];
+            rm = rm8[i];
           }
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
@@ -1015,7 +1008,7 @@ int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
   }
   if constexpr (BN == 256) {   // LayerNorm-consuming epilogues (common.h: LnFuse): 256-wide tile, tiles inside one sample
     if (epi == EPI_LN_GELU_H16 || epi == EPI_LN_H16) {
-      if (a.rows_per_sample % 256 != 0 || !a.ln.stats || !a.ln.u || !a.ln.v)
+      if (a.rows_per_sample % 256 != 0 || !a.ln.r || !a.ln.rm || !a.ln.u || !a.ln.v)
         return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-consuming epilogue needs row statistics, u / v vectors and rows_per_sample % 256 == 0");
       switch (epi) {
         LATTE_GEMM_CASE(EPI_LN_GELU_H16)

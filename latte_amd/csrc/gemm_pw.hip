@@ -542,12 +542,11 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     }
     if constexpr (EPI == EPI_GATE_RES_LN) {
       // EPI_GATE_RES_F32 + the next LayerNorm-modulate's operand (common.h: LnFuse).  The wave holds the NEW residual values of
-      // 128 rows x 48 columns in registers: it also stores a = x_new (1 + scale) as half (8 B per lane and fragment) and adds
-      // each row's sum x_new, sum x_new^2 over these 48 columns to the row's fixed-point accumulator (lanes 0-15: one row each,
-      // two 64-bit integer atomics per fragment row -- order-independent, so reruns are bit-identical).  The launcher guarantees
-      // rows_per_sample % 256 == 0, M % 256 == 0 (no row guards) and M N 4 < 4 GiB.  All global accesses are BUFFER operations on
-      // one per-lane byte offset plus scalar offsets: per-fragment 64-bit pointers (two VGPRs each, hoisted by the compiler) do
-      // not fit the 168 registers a wave of this kernel has next to its 96 accumulators.
+      // 128 rows x 48 columns in registers: it also stores a = x_new (1 + scale) as half and each row's sum x_new, sum x_new^2 over
+      // these 48 columns into the wave's own slot (lanes 0-15: one row each, one 8-byte store per fragment row).  The launcher
+      // guarantees rows_per_sample % 256 == 0, M % 256 == 0 (no row guards) and M N 4 < 4 GiB.  All global accesses are BUFFER
+      // operations on one per-lane byte offset plus scalar offsets: per-fragment 64-bit pointers (two VGPRs each, hoisted by the
+      // compiler) do not fit the 168 registers a wave of this kernel has next to its 96 accumulators.
       const unsigned nbytes = (unsigned)g.M * (unsigned)g.N * 4u;
       const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, nbytes, 0x00020000);
       const bool emit = g.ln.xn != nullptr;
@@ -563,18 +562,13 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
         g1[j] = *(const float4*)(g.gate + srow + j * 16);
         s4[j] = emit ? *(const float4*)(g.ln.scale + srow + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (g.ln.zero != nullptr && tn_ == 0 && wn == 0) {   // this tile row's 128-row half of the accumulator the last consumer is done with
-        u32x4* z = (u32x4*)(g.ln.zero + (size_t)(tm_ * BM + grp * 128) * 2);
-        z[le] = (u32x4){0u, 0u, 0u, 0u};
-        z[le + 64] = (u32x4){0u, 0u, 0u, 0u};
-      }
       constexpr int NF = 8 * FN, AHEAD = 2;
       auto soff = [&](int f) -> unsigned { return sbase + (unsigned)(f / FN) * srow16 + (unsigned)((f % FN) * 64); };
       u32x4 qa[AHEAD];
 #pragma unroll
       for (int a = 0; a < AHEAD; ++a) qa[a] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(a), 0);
       float p1 = 0.f, p2 = 0.f;
-      long long* const accp = g.ln.acc + (size_t)mbase * 2;
+      float* const slotp = g.ln.slots + ((size_t)(tn_ * 4 + wn) * g.M + mbase) * 2;   // this wave's slot, this lane's first row
       // the half operand goes through the wave-private LDS patch (16 rows, pitch 112 B: the half-output epilogue's) so that the
       // global stores are 16 B per lane on contiguous 96-byte row segments -- 1.5 store instructions per fragment row instead of
       // three 8-byte ones on 32-byte pieces: the epilogue burst of this kernel is bound by the NUMBER of memory requests
@@ -600,7 +594,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
           const u32x2 pk = {pack2<DT>(__builtin_fmaf(rr[0], s4[j].x, rr[0]), __builtin_fmaf(rr[1], s4[j].y, rr[1])),
                             pack2<DT>(__builtin_fmaf(rr[2], s4[j].z, rr[2]), __builtin_fmaf(rr[3], s4[j].w, rr[3]))};
 #ifdef LATTE_GEMM_ABLATE
-          if (g.ln.dbg & 16) {   // the direct form: 8 B per lane
+          if (g.ln.dbg & 16) {   // the direct form: 8 B per lane (measured: +12 us per launch against the patch route)
             if (!(g.ln.dbg & 2)) __builtin_amdgcn_raw_buffer_store_b64(pk, rsX, voff >> 1, soff(f) >> 1, 0);
           } else
 #endif
@@ -629,14 +623,9 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
             p1 += __shfl_xor(p1, 32, 64);
             p2 += __shfl_xor(p2, 32, 64);
 #ifdef LATTE_GEMM_ABLATE
-            if (g.ln.dbg & 4) {
-              if (le < 16) *(float2*)(accp + i * 32 + (tn_ * 4 + wn) * (size_t)g.M) = make_float2(p1, p2);   // slot-store cost model (acc must hold 24 x M x 8 B)
-            } else if (!(g.ln.dbg & 1))
+            if (!(g.ln.dbg & 1))
 #endif
-            if (le < 16) {
-              __hip_atomic_fetch_add(accp + i * 32, (long long)((double)p1 * LN_SUM_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_fetch_add(accp + i * 32 + 1, (long long)((double)p2 * LN_SQ_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (le < 16) *(float2*)(slotp + i * 32) = make_float2(p1, p2);
             p1 = 0.f;
             p2 = 0.f;
           }
@@ -819,8 +808,8 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     }                                                                                                \
   }
   if (epi == EPI_GATE_RES_LN) {
-    if (!roll || a.rows_per_sample % 256 != 0 || a.M % 256 != 0 || a.ln.acc == nullptr || (a.ln.xn != nullptr && a.ln.scale == nullptr))
-      return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue needs the rolling 12-wave kernel, whole 256-row tiles inside a sample and an accumulator");
+    if (!roll || a.rows_per_sample % 256 != 0 || a.M % 256 != 0 || (a.ln.xn != nullptr && (a.ln.scale == nullptr || a.ln.slots == nullptr)))
+      return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue needs the rolling 12-wave kernel, whole 256-row tiles inside a sample and a slot buffer");
     if ((uint64_t)a.M * a.N * 4 >= (1ull << 32)) return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue addresses its output through 32-bit buffer offsets (M N 4 < 4 GiB)");
     if (a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_LN, 1) else LATTE_PW_CASE(EPI_GATE_RES_LN, 0)
   } else if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)

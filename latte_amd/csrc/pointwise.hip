@@ -983,6 +983,35 @@ __global__ void __launch_bounds__(64) modvec_kernel(const ModvecEntry* __restric
   }
 }
 
+// (r, r mu) of every row from the slots a LayerNorm-emitting gated GEMM wrote (common.h: LnFuse): slot s holds the row's
+// (sum, sum of squares) over columns [48 s, 48 s + 48); added here in slot order in fp64 -- deterministic whatever order the column
+// tiles ran in -- then mu = S1 / n, var = S2 / n - mu^2, r = rsqrt(var + eps) (latte.py:166,168: eps 1e-6, biased variance).
+__global__ void __launch_bounds__(256) ln_rowstat_kernel(const float2* __restrict__ slots, int nslots, int M, double inv_n, double eps,
+                                                         float* __restrict__ r, float* __restrict__ rm) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+  for (int s = 0; s < nslots; ++s) {
+    const float2 p = slots[(size_t)s * M + m];
+    s1 += (double)p.x;
+    s2 += (double)p.y;
+  }
+  const double mu = s1 * inv_n;
+  double var = s2 * inv_n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float rs = (float)(1.0 / sqrt(var + eps));
+  r[m] = rs;
+  rm[m] = rs * (float)mu;
+}
+
+int launch_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, hipStream_t st) {
+  if (nslots <= 0 || M <= 0 || n_cols <= 0) return fail(LATTE_ERR_INVALID, "ln_rowstat: bad shape");
+  hipLaunchKernelGGL(ln_rowstat_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float2*)slots, nslots, M, 1.0 / (double)n_cols, (double)eps, r, rm);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
 int launch_modvec(const ModvecEntry* tab_dev, int entries, int max_n, const float* mod, long mod_stride, int R, float* uv, long uv_stride,
                   int K, int dtype, hipStream_t st) {
   if (K % 8 || R <= 0) return fail(LATTE_ERR_INVALID, "modvec: K % 8 != 0 or no rows");

@@ -321,10 +321,12 @@ def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
 
 # ---- LayerNorm fusion (include/latte_amd_debug.h): the `modulate(norm(x), shift, scale)` of latte.py:28-29,
 # 179-180 folded into the gated GEMM that produces x and the linear that consumes LN(x)
-def _ln_stats_fixed_point(x):
-    """What the producer accumulates for fp32 rows x: int64 {sum x 2^32, sum x^2 2^28} (exact sums in fp64, then scaled)."""
+def _ln_rowstats(x, eps=1e-6):
+    """(r, r mean) of fp32 rows x, in fp64 (what ln_rowstat_kernel leaves per row)."""
     xd = x.double()
-    return torch.stack([(xd.sum(1) * 2.0 ** 32).round().long(), ((xd * xd).sum(1) * 2.0 ** 28).round().long()], dim=1).contiguous()
+    mu = xd.mean(1)
+    r = torch.rsqrt(xd.var(1, unbiased=False) + eps)
+    return r.float().contiguous(), (r * mu).float().contiguous()
 
 
 # (M, N, K, rows_per_sample): the XL/2 out-projection and fc2 shapes on a few tile rows, S/2 width, several samples per launch
@@ -335,7 +337,8 @@ LN_PRODUCER_CASES = [(1024, 1152, 1152, 512), (512, 1152, 4608, 256), (768, 384,
 @pytest.mark.parametrize("shape", LN_PRODUCER_CASES)
 def test_gated_gemm_emits_the_next_layernorm_operand(lib, dev, dt, shape):
     """EPI_GATE_RES_LN (csrc/gemm_pw.hip): the residual update of latte.py:179-180 plus, from the same registers, the next
-    modulate's operand x_new (1 + scale) in half and the row sums of x_new in 64-bit fixed point."""
+    modulate's operand x_new (1 + scale) in half and every wave's 48-column share of the row sums; ln_rowstat_kernel turns the
+    slots into (r, r mean)."""
     M, N, K, rps = shape
     g = torch.Generator("cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
@@ -347,54 +350,45 @@ def test_gated_gemm_emits_the_next_layernorm_operand(lib, dev, dt, shape):
     res0 = (torch.randn(M, N, generator=g) * 2 + 0.3).to(dev)
     si = torch.arange(M, device=dev) // rps
     want = res0 + gate[si] * (A.float() @ W.float().t() + bias)
-    for tag in (0, 1):
+    nslots = N // 48
+    runs = []
+    for tag in (0, 1, 0):
         res = res0.clone()
         xn = torch.full((M, N), float("nan"), dtype=TD[dt], device=dev)
-        acc = torch.zeros(M, 2, dtype=torch.int64, device=dev)
-        zero = torch.full((M, 2), 0x7F7F7F7F7F7F, dtype=torch.int64, device=dev)
-        check(lib.latte_debug_gemm_gate_ln(ptr(A), ptr(W), ptr(bias), ptr(res), ptr(gate), ptr(scale), N, ptr(xn), ptr(acc), ptr(zero),
+        slots = torch.full((nslots, M, 2), float("nan"), device=dev)
+        check(lib.latte_debug_gemm_gate_ln(ptr(A), ptr(W), ptr(bias), ptr(res), ptr(gate), ptr(scale), N, ptr(xn), ptr(slots),
                                            M, N, K, rps, tag, dt, stream_ptr()))
+        r = torch.full((M,), float("nan"), device=dev)
+        rm = torch.full((M,), float("nan"), device=dev)
+        check(lib.latte_debug_ln_rowstat(ptr(slots), nslots, M, N, 1e-6, ptr(r), ptr(rm), stream_ptr()))
         torch.cuda.synchronize()
         assert float((res - want).norm() / want.norm()) < 2e-5
-        assert float(zero.abs().max()) == 0                                            # the other accumulator is cleared
         # the operand is the half rounding of the kernel's OWN fp32 result times (1 + scale)
         ref_xn = torch.addcmul(res, res, scale[si])                                     # fma(x, s, x) up to one fp32 rounding
         assert float((xn.float() - ref_xn).norm() / ref_xn.norm()) < (4e-3 if dt == 0 else 5e-4)
-        # row sums: the fixed-point accumulator against fp64 sums of the kernel's own result (24 partial sums of 48 fp32 values each)
-        ref = _ln_stats_fixed_point(res)
-        s1, s1r = acc[:, 0].double() / 2.0 ** 32, ref[:, 0].double() / 2.0 ** 32
-        s2, s2r = acc[:, 1].double() / 2.0 ** 28, ref[:, 1].double() / 2.0 ** 28
-        assert float((s1 - s1r).abs().max()) < 1e-5 * float(res.abs().sum(1).max())
-        assert float(((s2 - s2r) / s2r).abs().max()) < 1e-5
-        # no operand requested (the next LayerNorm is not a fused one): only the update and the clearing
-        res2 = res0.clone()
-        acc.zero_()
-        zero.fill_(77)
-        check(lib.latte_debug_gemm_gate_ln(ptr(A), ptr(W), ptr(bias), ptr(res2), ptr(gate), None, N, None, ptr(acc), ptr(zero), M, N, K, rps,
-                                           tag, dt, stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(res2, res) and float(acc.abs().max()) == 0 and float(zero.abs().max()) == 0
-    # bit-reproducible: integer atomics do not care about the order the six column tiles of a row arrive in
-    runs = []
-    for _ in range(2):
-        res = res0.clone()
-        acc = torch.zeros(M, 2, dtype=torch.int64, device=dev)
-        check(lib.latte_debug_gemm_gate_ln(ptr(A), ptr(W), ptr(bias), ptr(res), ptr(gate), ptr(scale), N, ptr(xn), ptr(acc), None, M, N, K, rps,
-                                           0, dt, stream_ptr()))
-        torch.cuda.synchronize()
-        runs.append((res, acc, xn.clone()))
-    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2].view(torch.int16), runs[1][2].view(torch.int16))
+        # slots: fp32 sums of 48 values each, against fp64 sums of the kernel's own result
+        chunks = res.double().view(M, nslots, 48)
+        s1, s2 = chunks.sum(2).t(), (chunks * chunks).sum(2).t()
+        assert float((slots[:, :, 0].double() - s1).abs().max()) < 1e-5 * float(chunks.abs().sum(2).max())
+        assert float(((slots[:, :, 1].double() - s2) / s2).abs().max()) < 1e-5
+        r_ref, rm_ref = _ln_rowstats(res)
+        assert float(((r - r_ref) / r_ref).abs().max()) < 1e-5 and float((rm - rm_ref).abs().max()) < 1e-5 * float(rm_ref.abs().max()) + 1e-6
+        runs.append((res, slots, xn.clone(), r, rm))
+    # bit-reproducible and independent of the kernel symbol (tag): nothing is accumulated in memory, the slot order is fixed
+    for k in (1, 2):
+        assert torch.equal(runs[0][0], runs[k][0]) and torch.equal(runs[0][1], runs[k][1]) and torch.equal(runs[0][3], runs[k][3])
+        assert torch.equal(runs[0][2].view(torch.int16), runs[k][2].view(torch.int16)) and torch.equal(runs[0][4], runs[k][4])
 
 
 def _ln_operands(M, K, rps, g, dev, dt, mean_shift=0.7):
-    """Rows x with a non-trivial mean and spread, per-sample modulation, the half operand a = x (1 + scale) and the fixed-point sums."""
+    """Rows x with a non-trivial mean and spread, per-sample modulation, the half operand a = x (1 + scale) and (r, r mean)."""
     S = M // rps
     x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3) + mean_shift * torch.randn(M, 1, generator=g)).to(dev)
     scale = (torch.randn(S, K, generator=g) * 0.5).to(dev)
     shift = (torch.randn(S, K, generator=g) * 0.5).to(dev)
     si = torch.arange(M, device=dev) // rps
     a = (x * (1 + scale[si])).to(TD[dt])
-    return x, scale, shift, si, a, _ln_stats_fixed_point(x).to(dev)
+    return x, scale, shift, si, a, _ln_rowstats(x)
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -402,7 +396,8 @@ def _ln_operands(M, K, rps, g, dev, dt, mean_shift=0.7):
 @pytest.mark.parametrize("shape", [(1024, 4608, 1152, 512), (512, 1536, 384, 256), (768, 3072, 768, 256)])
 def test_gemm_consumes_a_layernorm_operand(lib, dev, dt, gelu, shape):
     """EPI_LN_[GELU_]H16 (csrc/gemm.hip): out = f(r (a W^T - mu u) + v) is the reference's Linear(modulate(LN(x), shift, scale))
-    (latte.py:28-29,171,180) -- against fp32 torch on the same half operands, and against the plain LayerNorm formula."""
+    (latte.py:28-29,171,180) with (r, r mean) per row from ln_rowstat_kernel -- against fp32 torch on the same half operands, and
+    against the plain LayerNorm formula."""
     M, N, K, rps = shape
     g = torch.Generator("cpu").manual_seed(M + N + K + gelu)
     x, scale, shift, si, a, stats = _ln_operands(M, K, rps, g, dev, dt)
@@ -417,8 +412,8 @@ def test_gemm_consumes_a_layernorm_operand(lib, dev, dt, gelu, shape):
     assert float((uv[:, :N].double() - u_ref).abs().max()) < 2e-5 * float(u_ref.abs().max()) + 2e-5
     assert float((uv[:, N:].double() - v_ref).abs().max()) < 2e-5 * float(v_ref.abs().max()) + 2e-5
     out = torch.full((M, N), float("nan"), dtype=TD[dt], device=dev)
-    check(lib.latte_debug_gemm_ln_consume(ptr(a), ptr(W), ptr(stats), ptr(uv), ptr(uv[:, N:]), 2 * N, ptr(out), M, N, K, rps, gelu, 1e-6, dt,
-                                          stream_ptr()))
+    check(lib.latte_debug_gemm_ln_consume(ptr(a), ptr(W), ptr(stats[0]), ptr(stats[1]), ptr(uv), ptr(uv[:, N:]), 2 * N, ptr(out), M, N, K, rps,
+                                          gelu, dt, stream_ptr()))
     torch.cuda.synchronize()
     mu = x.double().mean(1, keepdim=True)
     r = torch.rsqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-6)
@@ -436,7 +431,7 @@ def test_gemm_consumes_a_layernorm_operand(lib, dev, dt, gelu, shape):
 @pytest.mark.parametrize("mode", [0, 1], ids=["spatial", "temporal"])
 def test_fused_qkv_attention_consumes_a_layernorm_operand(lib, dev, dt, case, mode):
     """csrc/qkv_attn.hip in its LayerNorm-consuming mode: q | k | v = r (a W^T - mu u) + v in the image-write phase (the unit's row
-    sums and the head's u / v slices arrive by LDS DMA one unit ahead), then the same attention core."""
+    statistics and the head's u / v slices arrive by LDS DMA one unit ahead), then the same attention core."""
     B, F, T, H, hd = case
     if mode == 0 and T != 256:
         pytest.skip("spatial units are the 256 tokens of a frame")
@@ -451,8 +446,8 @@ def test_fused_qkv_attention_consumes_a_layernorm_operand(lib, dev, dt, case, mo
     out = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
     dbg = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
     for _ in range(2):   # twice: warm LDS / caches (stale side-data screen)
-        check(lib.latte_debug_qkv_attention_ln(ptr(a), ptr(W), ptr(stats), ptr(uv), ptr(uv[:, 3 * D:]), 6 * D, ptr(out), ptr(dbg), B, F, T, D, H,
-                                               mode, 1e-6, dt, stream_ptr()))
+        check(lib.latte_debug_qkv_attention_ln(ptr(a), ptr(W), ptr(stats[0]), ptr(stats[1]), ptr(uv), ptr(uv[:, 3 * D:]), 6 * D, ptr(out), ptr(dbg),
+                                               B, F, T, D, H, mode, dt, stream_ptr()))
         torch.cuda.synchronize()
     mu = x.double().mean(1, keepdim=True)
     r = torch.rsqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-6)

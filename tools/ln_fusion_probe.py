@@ -4,8 +4,8 @@
 
 XL/2 forward at B (default 8), f16, per-class kernel time by HIP events (latte_profile_forward, best of 6 interleaved rounds) for:
 the separate LayerNorm kernel (fuse_ln = 0), the fusion as shipped, and its ablations (LnFuse::dbg bits, results garbage):
-1 = no row-sum atomics, 2 = no operand stores, 4 = plain 8-byte slot stores instead of the atomics, 8 = consumers skip the statistics
-loads, 16 = operand stores as direct 8-byte stores instead of through the LDS patch."""
+1 = no row-sum slot stores, 2 = no operand stores, 16 = operand stores as direct 8-byte stores instead of through the LDS patch.
+(profiles/r4_ln_fusion_ablation_v1_atomics.log is this probe on the first version, whose row sums were 64-bit atomics.)"""
 import os
 import sys
 
@@ -25,9 +25,8 @@ with torch.no_grad():
 m = m.to("cuda").eval()
 x = torch.randn(B, 16, 4, 32, 32, generator=g).cuda()
 t = torch.full((B,), 500, device="cuda", dtype=torch.int64)
-SETTINGS = [("separate LN kernel", 0, 0), ("fused", 1, 0), ("fused, no atomics", 1, 1), ("fused, no operand stores", 1, 2),
-            ("fused, neither", 1, 3), ("fused, slot stores for atomics", 1, 4), ("fused, consumers skip stats loads", 1, 8),
-            ("fused, direct 8-byte operand stores", 1, 16), ("fused, direct stores, no atomics", 1, 17)]
+SETTINGS = [("separate LN kernel", 0, 0), ("fused", 1, 0), ("fused, no slot stores", 1, 1), ("fused, no operand stores", 1, 2),
+            ("fused, neither", 1, 3), ("fused, direct 8-byte operand stores", 1, 16)]
 has_dbg = True
 best = {}
 for rnd in range(6):
