@@ -247,6 +247,33 @@ def vae_decoder_flops(h):
     return f + conv(H, 128, 3)
 
 
+def vae_decoder_work(h):
+    """Per frame of AutoencoderKL.decode at an h x h latent: (FLOPs of the 3x3 convolutions that run on the MFMA implicit-GEMM kernel,
+    algorithmic bytes of the GroupNorm statistics passes = every GroupNorm input read once (fp32 stream), algorithmic bytes of the
+    GroupNorm apply passes = that input read once more + the half operand written).  30 GroupNorms: 2 per resnet (14 resnets:
+    2 mid + 12 up), mid attention, conv_norm_out."""
+    conv3 = lambda H, cin, cout: 2 * H * H * cin * cout * 9
+    fl, gn_in = 0, 0
+    gn = lambda H, c: H * H * c * 4
+    fl += 0   # conv_in (4 -> 512) is a small direct kernel, not the MFMA kernel
+    for _ in range(2):                       # mid resnets
+        fl += 2 * conv3(h, 512, 512)
+        gn_in += 2 * gn(h, 512)
+    gn_in += gn(h, 512)                      # mid attention's norm
+    H, prev = h, 512
+    for i, c in enumerate((512, 512, 256, 128)):
+        for r in range(3):
+            cin = prev if r == 0 else c
+            fl += conv3(H, cin, c) + conv3(H, c, c)
+            gn_in += gn(H, cin) + gn(H, c)
+        prev = c
+        if i < 3:
+            H *= 2
+            fl += conv3(H, c, c)
+    gn_in += gn(H, 128)                      # conv_norm_out
+    return fl, gn_in, gn_in + gn_in // 2
+
+
 def vae_decode_rate(device):
     """VAE decode of one 16-frame video (latents 16x4x32x32 -> 16x256x256x3 uint8), random sd-vae-ft-shaped weights;
     reported beside the headline, outside its timed region (decode is ~1.5 % of a 250-step chain)."""
@@ -264,10 +291,35 @@ def vae_decode_rate(device):
         out = vae.decode_video_uint8(lat)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    # per kernel class, HIP events behind every launch of one decode (latte_vae_profile_decode): the convolutions against the MFMA
+    # peak with the FLOPs of the layer shapes, the two GroupNorm passes against the HBM peak with their algorithmic bytes
+    z = (lat[0] / 0.18215).contiguous()
+    vae.profile_decode(z)
+    prof = vae.profile_decode(z)
+    conv_fl, gn_stats_b, gn_apply_b = (16 * v for v in vae_decoder_work(32))
+    total = sum(v[0] for v in prof.values())
+    table = []
+    for k, (ms, n) in prof.items():
+        row = {"class": k, "launches": n, "ms_per_video": round(ms, 3), "share_of_decode": round(ms / total, 4)}
+        if k == "conv3x3":
+            ach = conv_fl / (ms * 1e-3) / 1e12
+            row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "algorithmic_flops": conv_fl,
+                        "kernel": "conv3x3_kernel: implicit-GEMM 3x3 convolution (+ nearest-2x upsample in the gather), f16 operands"})
+        elif k in ("groupnorm_stats", "groupnorm_apply"):
+            by = gn_stats_b if k == "groupnorm_stats" else gn_apply_b
+            ach = by / (ms * 1e-3) / 1e9
+            row.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes": by,
+                        "kernel": "gn_partial_kernel + gn_finalize_kernel: GroupNorm(32) statistics over the fp32 stream" if k == "groupnorm_stats"
+                                  else "gn_apply_kernel: normalise + affine + SiLU, fp32 in, half operand out"})
+        table.append(row)
+    table.sort(key=lambda r: -r["share_of_decode"])
     return {"ms_per_video": round(dt * 1e3, 2), "frames_per_sec": round(16 / dt, 1), "dtype": "f16",
             "algorithmic_tflops_per_s": round(16 * vae_decoder_flops(32) / 1e12 / dt, 1),
             "algorithmic_tflop_per_frame": round(vae_decoder_flops(32) / 1e12, 4),
-            "finite_and_nonconstant": bool(out.float().std() > 0)}
+            "finite_and_nonconstant": bool(out.float().std() > 0),
+            "roofline_table": table, "decode_ms_eager_events": round(total, 3)}
 
 
 def config4_rate(device, n_steps=4):
@@ -477,6 +529,13 @@ def main():
         n3 = min(args.steps, 10)
         dt3 = timed_steps(lib, m3, diffusion, x3, n3, args.method, 16, y=y3, cfg_scale=7.0, guided=True)
         side["config3"] = {"ms_per_step": dt3 * 1e3, "steps": n3}
+        # the same per-kernel roofline table at config 3's M = 65 536 rows (16 sequences): what each kernel class does with twice the rows
+        t3 = torch.full((16,), 500, device=device, dtype=torch.int64)
+        m3.profile_forward(x3, t3, y=y3)
+        tab3, tot3 = roofline_table(m3.profile_forward(x3, t3, y=y3), 16, "f16")
+        side["config3"]["roofline_table"] = [{k: r[k] for k in ("class", "launches_per_forward", "avg_launch_ms", "share_of_forward", "bound",
+                                                               "achieved", "unit", "frac") if k in r} for r in tab3]
+        side["config3"]["forward_ms_eager_events"] = round(tot3, 3)
         del m3
         torch.cuda.empty_cache()
         # BASELINE config 5's per-GPU share: one optimisation step (train.py:197-236) of Latte-B/2, local batch 5
@@ -542,7 +601,8 @@ def main():
                                               "forward_with_cfg, 8 samples = 16 sequences per GPU, f16 operands",
                                   "value": round(sps, 3), "unit": "guided sample-steps/s", "ms_per_step": round(v["ms_per_step"], 3),
                                   "steps": v["steps"], "global_batch": 8 * world,
-                                  "model_mfma_frac": round(2 * sps / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+                                  "model_mfma_frac": round(2 * sps / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                                  "roofline_table": v.get("roofline_table"), "forward_ms_eager_events": v.get("forward_ms_eager_events")}
             elif k == "config5":
                 tb, D5, dep5, M5 = 5, 768, 12, 5 * 16 * 256
                 fwd5 = dep5 * 2.0 * M5 * 12 * D5 * D5 + (dep5 // 2) * (4.0 * tb * 16 * 256 * 256 * D5 + 4.0 * tb * 256 * 16 * 16 * D5)

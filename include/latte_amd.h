@@ -290,6 +290,12 @@ int latte_vae_check_weights(latte_vae_t* v);
  * [N,8h,8w,3] = ((x*0.5+0.5)*255+0.5).clamp(0,255) of sample.py:122 fused into the last convolution. */
 int latte_vae_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out,
                      void* stream);
+/* Measurement hook beside latte_profile_forward: ONE decode with a HIP event behind every launch.  ms_out[c] / launches_out[c]
+ * (n >= 5 entries) per kernel class c: 0 = conv3x3 (implicit GEMM on the MFMA pipe), 1 = GroupNorm statistics, 2 = GroupNorm
+ * apply (+ SiLU), 3 = mid-block attention and the 1x1 shortcut GEMMs, 4 = the small kernels (post_quant_conv, conv_in, conv_out,
+ * fp32 -> half copies).  Synchronises the stream; bench.py's `vae_decode.roofline_table` is built from it. */
+int latte_vae_profile_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, float* ms_out,
+                             int* launches_out, int n, void* stream);
 
 /* ------------------------------------------------------------------ LatteT2V denoiser (Latte-1 text-to-video)
  * LatteT2V.forward, /root/reference/models/latte_t2v.py:677-941 (constructor :475-672).

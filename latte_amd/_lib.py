@@ -106,6 +106,7 @@ PROTOTYPES = {
     "latte_vae_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
     "latte_vae_check_weights": (c_int, [c_void]),
     "latte_vae_decode": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void]),
+    "latte_vae_profile_decode": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_void, c_int, c_void]),
     # test hooks
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),

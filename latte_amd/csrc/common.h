@@ -57,6 +57,11 @@ inline int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& 
 // 16-bit storage element (bf16 or f16 bit pattern depending on the engine's compute dtype)
 typedef uint16_t half_t;
 
+// ---- per-class kernel timing of the VAE decoder (latte_vae_profile_decode, vae_engine.cpp): when a profile is armed on this
+// thread, every launcher records a HIP event on its stream after its launch; the time since the previous event goes to `cls`
+enum VaeKernelClass : int { VC_CONV3 = 0, VC_GN_STATS, VC_GN_APPLY, VC_ATTN, VC_SMALL, VC_NUM_CLASSES, VC_START = -1 };
+void kprof_mark(int cls, hipStream_t st);
+
 // ---- GEMM  C[M,N] = A[M,K] · W[N,K]^T, fused epilogues ----------------------------------------
 enum GemmEpi : int {
   EPI_BIAS_H16 = 0,       // out(half) = acc + bias

@@ -93,10 +93,14 @@ struct latte_engine {
                                            // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair;
                                            // bits 2, 3: QkvAttnArgs::flags (schedule variants, same results)
   int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
-  // LayerNorm fusion (round 4, common.h: LnFuse): 1 = wherever ln_fusable() allows it, the LayerNorm + modulate
-  // between a gated GEMM and the linear that follows it lives in the two GEMMs' epilogues instead of its own HBM pass; 0 = the
-  // separate ln_modulate kernel everywhere
-  int fuse_ln = 1;
+  // LayerNorm fusion (round 4, common.h: LnFuse): 1 = wherever ln_fusable_shape() allows it, the LayerNorm +
+  // modulate between a gated GEMM and the linear that follows it lives in the two GEMMs' epilogues instead of its own HBM pass.
+  // Built, parity-green (same 1e-3 budget: 4.75e-4 against 4.72e-4 on XL/2 at trained-scale gates) and measured: it TIES the
+  // separate kernel in the forward and loses 1 % in the loop (263.2 against 266.1 sample-steps/s, same box) -- the half operand
+  // still has to be written (75 MB per launch, 17 us inside the producers' bandwidth-bound epilogue burst against 38 us for the
+  // whole separate pass), and shuffles / row statistics / the consumers' extra epilogue work eat the 4-byte read it saves
+  // (profiles/r4_ln_fusion_ablation_v2_slots.log).  So the default is 0 = the separate ln_modulate kernel; the option stays for A/B.
+  int fuse_ln = 0;
   int ln_dbg = 0;                          // measurement build only: LnFuse::dbg of every launch (ablations, results garbage)
   float *ln_slots = nullptr, *ln_r = nullptr, *ln_rm = nullptr;   // the producers' row-sum slots [D / 48][rows_pad][2], (r, r mu) per row
   float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]

@@ -548,6 +548,7 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   static std::atomic<uint64_t> attr_f16{0};
   if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, LDS, attr_f16)) return rc_;
   hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);
+  kprof_mark(VC_CONV3, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -563,11 +564,13 @@ int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma,
   if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), eps);
+  kprof_mark(VC_GN_STATS, st);
   const dim3 grid(grid_for(total_oct, 256));
 #define GN_APPLY(S, I) hipLaunchKernelGGL((gn_apply_kernel<LATTE_DTYPE_F16, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct, y_lo)
   if (silu) { if (x_is_f32) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else      { if (x_is_f32) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY
+  kprof_mark(VC_GN_APPLY, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -575,12 +578,14 @@ int groupnorm_max_slabs() { return 64; }
 
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st) {
   hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((size_t)N * hw, 256)), dim3(256), 0, st, z, w, b, out, N, hw, z_scale);
+  kprof_mark(VC_SMALL, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
 
 int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st) {
   hipLaunchKernelGGL(conv_in_kernel, dim3(N * H * W), dim3(256), 0, st, x, wt, bias, out, N, H, W, Cout);
+  kprof_mark(VC_SMALL, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -591,6 +596,7 @@ int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* o
   const size_t lds = (size_t)27 * C * sizeof(float);
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv_out: the VAE kernels are built for f16 operands only");
   hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
+  kprof_mark(VC_SMALL, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -598,6 +604,7 @@ int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* o
 int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st) {
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "softmax_rows: the VAE kernels are built for f16 operands only");
   hipLaunchKernelGGL(softmax_rows_kernel<LATTE_DTYPE_F16>, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
+  kprof_mark(VC_ATTN, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -624,6 +631,7 @@ int launch_scale_by_sigmoid(const float* in, float* out, int n, const float* mix
 }
 int launch_time_conv_out(const float* in, const float* w, const float* bias, void* out, int T, int HW, int out_mode, hipStream_t st) {
   hipLaunchKernelGGL(time_conv_out_kernel, dim3(grid_for((size_t)T * HW, 256)), dim3(256), 0, st, in, w, bias, out, T, HW, out_mode);
+  kprof_mark(VC_SMALL, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -20,6 +20,25 @@
 using namespace latte;
 
 namespace {
+struct KProf {
+  std::vector<hipEvent_t> ev;
+  std::vector<int> cls;
+};
+thread_local KProf* g_kprof = nullptr;
+}  // namespace
+
+namespace latte {
+void kprof_mark(int cls, hipStream_t st) {
+  if (!g_kprof) return;
+  hipEvent_t ev;
+  (void)hipEventCreate(&ev);
+  (void)hipEventRecord(ev, st);
+  g_kprof->ev.push_back(ev);
+  g_kprof->cls.push_back(cls);
+}
+}  // namespace latte
+
+namespace {
 
 enum VPack { VP_F32, VP_CONV3, VP_LINEAR_H16, VP_SMALL_T, VP_SMALL, VP_CONVT };
 struct VSlot {
@@ -144,7 +163,9 @@ int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, con
              int dtype, hipStream_t st) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.res = res; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M;
-  return launch_gemm(g, epi, dtype, 1, st);   // plain 128 x 128 kernel: small, oddly shaped problems
+  const int rc_ = launch_gemm(g, epi, dtype, 1, st);   // plain 128 x 128 kernel: small, oddly shaped problems
+  kprof_mark(VC_ATTN, st);                              // (only the mid-block attention and the 1x1 shortcuts come through here)
+  return rc_;
 }
 
 // ResnetBlock2D on the fp32 stream: x = *s -> *s (in place when cin == cout, else through *s2 and the two are swapped);
@@ -164,6 +185,7 @@ int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, 
   if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
     float* y = *s2;
     if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
+    kprof_mark(VC_SMALL, st);
     if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
     if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     if (lo && (rc = launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
@@ -370,6 +392,28 @@ int latte_vae_check_weights(latte_vae_t* v) {
 static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, void* stream,
                            int stop_after, float* trace_out, int64_t* trace_numel, int* trace_dims);
 
+// One decode with a HIP event behind every launch: ms_out[c] / launches_out[c] per VaeKernelClass (conv3x3, GroupNorm statistics,
+// GroupNorm apply, mid-block attention + 1x1 shortcut GEMMs, small kernels).  Synchronises the stream.
+int latte_vae_profile_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, float* ms_out,
+                             int* launches_out, int n, void* stream) {
+  if (!ms_out || !launches_out || n < VC_NUM_CLASSES) return fail(LATTE_ERR_INVALID, "vae_profile_decode: bad arguments");
+  KProf prof;
+  g_kprof = &prof;
+  kprof_mark(VC_START, (hipStream_t)stream);
+  int rc = vae_decode_impl(v, z, n_frames, z_scale, out_mode, out, stream, -1, nullptr, nullptr, nullptr);
+  g_kprof = nullptr;
+  if (!rc && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = fail(LATTE_ERR_HIP, "vae_profile_decode: device error");
+  for (int i = 0; i < n; ++i) { ms_out[i] = 0.f; launches_out[i] = 0; }
+  for (size_t i = 1; !rc && i < prof.ev.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, prof.ev[i - 1], prof.ev[i]) != hipSuccess) { rc = fail(LATTE_ERR_HIP, "vae_profile_decode: event"); break; }
+    const int c = prof.cls[i];
+    if (c >= 0 && c < n) { ms_out[c] += ms; launches_out[c] += 1; }
+  }
+  for (auto ev : prof.ev) (void)hipEventDestroy(ev);
+  return rc;
+}
+
 int latte_vae_decode(latte_vae_t* v, const float* z, int n_frames, float z_scale, int out_mode, void* out, void* stream) {
   return vae_decode_impl(v, z, n_frames, z_scale, out_mode, out, stream, -1, nullptr, nullptr, nullptr);
 }
@@ -449,6 +493,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
       g.A = o; g.W = v->ao_w; g.bias = v->ao_b_eff; g.out = a; g.gate = v->ones; g.gate_stride = 0;
       g.M = N * L; g.N = top; g.K = top; g.rows_per_sample = N * L;
       if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, 1, st))) return rc;
+      kprof_mark(VC_ATTN, st);
     }
   }
   if (traced(rc)) return rc;
@@ -465,6 +510,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     if (i < 3) {  // Upsample2D: nearest x2 folded into the conv's gather (on a half copy of the stream), fp32 result
       const int cch = v->ch[3 - i];
       if ((rc = launch_convert_f32_to_h16(a, d, (int64_t)N * H * W * cch, dt, st))) return rc;
+      kprof_mark(VC_SMALL, st);
       if ((rc = launch_conv3x3(d, v->upc_w[i], v->upc_b[i], nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, nullptr, a2))) return rc;
       std::swap(a, a2);
       H *= 2;

@@ -171,6 +171,22 @@ class AutoencoderKL:
                 check(lib.latte_vae_decode(eng, ptr(z32[s:s + m]), m, float(z_scale), out_mode, ptr(out[s:s + m]), stream_ptr()))
         return out
 
+    KERNEL_CLASSES = ("conv3x3", "groupnorm_stats", "groupnorm_apply", "attention_and_1x1", "small")
+
+    def profile_decode(self, z, z_scale=1.0):
+        """Measurement hook (bench.py): one decode of z [N <= max_frames, 4, h, w] with a HIP event behind every launch ->
+        {class: (milliseconds, launches)} for KERNEL_CLASSES."""
+        import ctypes
+        n, _, h, _ = z.shape
+        z32 = z.to(device=self._device, dtype=torch.float32).contiguous()
+        eng = self._engine(n, h)
+        out = torch.empty(n, 3, 8 * h, 8 * h, device=self._device, dtype=torch.float32)
+        k = len(self.KERNEL_CLASSES)
+        ms, cnt = (ctypes.c_float * k)(), (ctypes.c_int * k)()
+        with torch.cuda.device(self._device):
+            check(load_library().latte_vae_profile_decode(eng, ptr(z32), n, float(z_scale), 0, ptr(out), ms, cnt, k, stream_ptr()))
+        return {c: (float(ms[i]), int(cnt[i])) for i, c in enumerate(self.KERNEL_CLASSES)}
+
     def decode(self, z, return_dict=True):
         """``AutoencoderKL.decode``: z [N,4,h,w] (already divided by scaling_factor) -> ``.sample`` fp32 [N,3,8h,8w]."""
         out = self._run(z, 1.0, 0)

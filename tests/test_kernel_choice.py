@@ -73,7 +73,7 @@ def test_weight_gradient_split_plan(shape):
 
 
 def test_layernorm_fusion_rule(lib):
-    """engine.cpp: ln_fusable_shape -- the LayerNorms are folded into the GEMM epilogues exactly where every kernel of a block has
+    """engine.cpp: ln_fusable_shape -- with the engine option fuse_ln = 1 the LayerNorms are folded into the GEMM epilogues exactly where every kernel of a block has
     its LN-aware form: 256-token x 16-frame configs (both block kinds on the fused qkv + attention kernel), gated GEMMs on the
     rolling 12-wave kernel, fc1 on the 256-wide persistent kernel.  XL/2: the benchmarked B = 8 and config 3's 16 sequences."""
     xl = dict(D=1152, Hm=4608, heads=16)

@@ -36,6 +36,12 @@ def classify(name):
         return "attn_temporal"
     if "ln_modulate_kernel" in n:
         return "ln_modulate"
+    if "conv3x3_kernel" in n:
+        return "vae_conv3x3"
+    if "gn_partial_kernel" in n:
+        return "vae_groupnorm_stats"
+    if "gn_apply_kernel" in n:
+        return "vae_groupnorm_apply"
     return None
 
 
@@ -63,6 +69,37 @@ for d in sorted(glob.glob(os.path.join(OUT, f"{TAG}_pmc*"))):
                 acc[c][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"]),
                                                     int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
 res = {}
+VAE_ALG = None
+try:
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    _fl, _gs, _ga = _bench.vae_decoder_work(32)
+    VAE_ALG = {"vae_conv3x3": ("flops", 16 * _fl), "vae_groupnorm_stats": ("bytes", 16 * _gs), "vae_groupnorm_apply": ("bytes", 16 * _ga)}
+except Exception as exc:   # torch-free environments: the VAE rows are skipped
+    print("vae rows skipped:", exc)
+for c in [k for k in acc if k.startswith("vae_")]:
+    ctrs = acc.pop(c)
+    rec = {"kernel": names[c], "unit": "one 16-frame decode (second of two; sums over its launches)", "counters_sum_per_decode": {}, "launches_per_decode": {}}
+    for k, vals in ctrs.items():
+        vals.sort()
+        use = vals[len(vals) // 2:]
+        rec["counters_sum_per_decode"][k] = sum(v for _, v, _ in use)
+        rec["launches_per_decode"][k] = len(use)
+        if k == "GRBM_GUI_ACTIVE":
+            rec["ns_per_decode_in_pmc_pass"] = sum(t for _, _, t in use)
+    cs = rec["counters_sum_per_decode"]
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        rec["hbm_bytes_per_decode"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
+        if VAE_ALG and VAE_ALG[c][0] == "bytes":
+            rec["algorithmic_bytes_per_decode"] = VAE_ALG[c][1]
+            rec["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_decode"] / VAE_ALG[c][1], 3)
+    if VAE_ALG and VAE_ALG[c][0] == "flops":
+        rec["algorithmic_flops_per_decode"] = VAE_ALG[c][1]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cs.get("GRBM_GUI_ACTIVE", 0) > 0:
+        rec["mfma_busy_frac_of_simd_cycles"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (cs["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+    if cs.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in cs:
+        rec["SQ_WAIT_ANY_frac_of_wave_cycles"] = round(cs["SQ_WAIT_ANY"] / cs["SQ_WAVE_CYCLES"], 4)
+    res[f"{c}:frames=16"] = rec
 for c, ctrs in acc.items():
     rec = {"kernel": names[c], "M": M, "algorithmic_bytes_per_launch": ALG[c], "counters_avg_per_launch": {}, "launches_sampled": {}}
     for k, vals in ctrs.items():
