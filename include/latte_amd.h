@@ -89,8 +89,13 @@ void latte_engine_destroy(latte_engine_t* e);
  * CUs, and which the 128x144 tile does not take, runs as 2..4 partial products + one reduction into the residual stream; 1 = never; 2..4 = force that many),
  * "fuse_qkv_attn" (bit 0: spatial blocks, bit 1: temporal blocks run the QKV projection and the attention core of
  * latte.py:48-70 as ONE kernel with q / k / v held in LDS -- csrc/qkv_attn.hip -- wherever the shape allows it: 256 tokens per
- * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; bits 2-3 select schedule
- * variants of the fused kernel; every setting gives the same bits),
+ * frame / 16 frames, head_dim 64 | 72; default 3, 0 = the separate qkv GEMM + attention kernels; values 0..31: bits 2, 3, 4 switch
+ * OFF one default schedule feature of the fused kernel each -- the next unit's first operand tile fetched under the attention
+ * phase, the attention-phase issue priority of wave group 0, the four-heads-per-XCD unit order of 16-head models (A/B hooks);
+ * every setting gives the same bits),
+ * "fuse_ln" (0 | 1, default 0: with 1 the LayerNorm + modulate of latte.py:179-180 between a gated GEMM and the linear behind it is
+ * folded into the two GEMMs' epilogues wherever every kernel of the block has that form -- XL/2 at batch >= 8; parity-tested at
+ * 1e-3 like the default path, measured without gain),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);

@@ -35,9 +35,9 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
  * out[B F T, D] = attention(xn[B F T, D] W[3D, D]^T + bias[3D]) per (sequence, head), rows in the canonical [B, F, T] order.
  * mode 0: spatial sequences (needs T == 256), mode 1: temporal sequences (needs F == 16, T % 16 == 0); head_dim D / heads
  * must be 64 or 72.  dbg_qkv (may be NULL): half [B F T, 3D] receives the q | k | v values the kernel holds in LDS (what the
- * un-fused qkv GEMM would have written).  xn must not alias out.  flags: schedule variants with identical results (bit 0:
- * the next unit's first operand tile is fetched under the attention phase; bit 1: a wave's two query groups run one after
- * the other, spatial only). */
+ * un-fused qkv GEMM would have written).  xn must not alias out.  flags = QkvAttnArgs::flags, schedule variants with identical
+ * results: bit 0 = the next unit's first operand tile is fetched under the attention phase, bit 1 = attention-phase issue priority
+ * for wave group 0 (spatial mode), bit 2 = four heads per XCD instead of all heads of every eighth sequence group (16 heads). */
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T,
                               int D, int heads, int mode, int flags, int dtype, void* stream);
 /* The same launch with a phase trace (measurement): trace = int64 [8 waves][4] receives workgroup 0's shader-clock ticks in

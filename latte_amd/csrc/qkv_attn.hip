@@ -445,40 +445,35 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
           for (int d = 0; d < DF; ++d) o[gq][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // V^T fragments through the transpose read in its INLINE-ASSEMBLY form with hand-counted lgkmcnt (round 4): in front of the
-        // builtin hipcc waits for every LDS DMA in flight (s_waitcnt vmcnt), i.e. for the next unit's early operand fill issued a few
-        // instructions earlier -- which cancelled that fill's gain in this mode.  One register set,
-        // refilled in place: the fragment of d-column d for the NEXT 32-key step is requested right after this step's copy of it into
-        // the MFMA operand (an asm read cannot target half of a 128-bit operand, so the operand is assembled by moves once the
-        // wait has confirmed the data; a second register set for whole-step look-ahead did not fit 256 VGPRs at hd = 72).
-        static_assert(DF <= 5, "the V fragment reads below are written out for up to five 16-wide d fragments");
-        u32x2 vlo[5], vhi[5];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler's own LDS traffic of the softmax shuffles)
-        vlo[0] = tr16_asm<0>(vbase); vhi[0] = tr16_asm<16 * RPV>(vbase);
-        vlo[1] = tr16_asm<32>(vbase); vhi[1] = tr16_asm<16 * RPV + 32>(vbase);
-        vlo[2] = tr16_asm<64>(vbase); vhi[2] = tr16_asm<16 * RPV + 64>(vbase);
-        vlo[3] = tr16_asm<96>(vbase); vhi[3] = tr16_asm<16 * RPV + 96>(vbase);
-        if constexpr (DF == 5) { vlo[4] = tr16_asm<128>(vbase); vhi[4] = tr16_asm<16 * RPV + 128>(vbase); }
+        // (Round 4: the V^T reads of this phase were moved to the inline-assembly transpose read with hand-counted lgkmcnt, as in the
+        //  temporal mode, so that hipcc's s_waitcnt vmcnt in front of the BUILTIN no longer waits for the next unit's early operand
+        //  fill.  Double-buffered whole steps did not fit 256 VGPRs at hd = 72 (an asm read cannot target half of a 128-bit MFMA
+        //  operand: 40 fragment registers + the copies); the single-buffered in-place form fitted and measured no gain -- spatial
+        //  kernel 3.88 ms per forward against 3.78-3.84 with the builtin on the boxes of the same day -- so the builtin stays.)
+        u32x4 vfr[2][DF];
+        auto load_v = [&](int ks2, u32x4 (&dst)[DF]) {
+#pragma unroll
+          for (int d = 0; d < DF; ++d) {
+            const u32x2 lo = tr16(vbase + (32 * ks2) * RPV + d * 32);
+            const u32x2 hi = tr16(vbase + (32 * ks2 + 16) * RPV + d * 32);
+            dst[d] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+        };
+        load_v(0, vfr[0]);
 #pragma unroll
         for (int ks2 = 0; ks2 < NKT / 2; ++ks2) {
+          if (ks2 + 1 < NKT / 2) load_v(ks2 + 1, vfr[(ks2 + 1) & 1]);
           u32x4 pb[NG];
 #pragma unroll
           for (int gq = 0; gq < NG; ++gq)
             pb[gq] = (u32x4){pack2<DT>(st[gq][2 * ks2][0], st[gq][2 * ks2][1]), pack2<DT>(st[gq][2 * ks2][2], st[gq][2 * ks2][3]),
                              pack2<DT>(st[gq][2 * ks2 + 1][0], st[gq][2 * ks2 + 1][1]),
                              pack2<DT>(st[gq][2 * ks2 + 1][2], st[gq][2 * ks2 + 1][3])};
-          const char* pvn = vbase + (32 * (ks2 + 1)) * RPV;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's 2 DF reads (issued during the previous step's MFMAs)
           __builtin_amdgcn_sched_barrier(0);
-#define LATTE_PV_STEP(DIDX, OFF)                                                                                 \
-          if constexpr (DIDX < DF) {                                                                               \
-            const u32x4 vfrag = {vlo[DIDX][0], vlo[DIDX][1], vhi[DIDX][0], vhi[DIDX][1]};                          \
-            asm volatile("" ::"v"(vfrag));   /* the copy exists before the registers are refilled */             \
-            if (ks2 + 1 < NKT / 2) { vlo[DIDX] = tr16_asm<OFF>(pvn); vhi[DIDX] = tr16_asm<16 * RPV + OFF>(pvn); }    \
-            _Pragma("unroll") for (int gq = 0; gq < NG; ++gq) o[gq][DIDX] = mfma16<DT>(vfrag, pb[gq], o[gq][DIDX]); \
-          }
-          LATTE_PV_STEP(0, 0) LATTE_PV_STEP(1, 32) LATTE_PV_STEP(2, 64) LATTE_PV_STEP(3, 96) LATTE_PV_STEP(4, 128)
-#undef LATTE_PV_STEP
+#pragma unroll
+          for (int d = 0; d < DF; ++d)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) o[gq][d] = mfma16<DT>(vfr[ks2 & 1][d], pb[gq], o[gq][d]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

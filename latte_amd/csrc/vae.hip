@@ -252,20 +252,35 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const void* __restrict_
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int slabs, float count,
-                                   float eps) {
-  const int n = blockIdx.x, gi = threadIdx.x;   // 32 threads
+// 256 threads per sample: thread (part = t >> 5, group = t & 31) adds slabs part, part + 8, ... in fp64, then the eight parts of a
+// group are added in part order -- a fixed order whatever the slab count (round 3: one thread per group walked all slabs, 8 us of
+// dependent loads per launch, 30 launches per decode)
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int slabs, float count,
+                                                          float eps) {
+  __shared__ double red[256 * 2];
+  const int n = blockIdx.x, gi = threadIdx.x & 31, part = threadIdx.x >> 5;
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < slabs; ++k) {
+  for (int k = part; k < slabs; k += 8) {
     const float* p = partial + (((size_t)n * slabs + k) * 32 + gi) * 2;
     s += p[0];
     q += p[1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[(n * 32 + gi) * 2] = (float)mean;
-  stats[(n * 32 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  red[threadIdx.x * 2] = s;
+  red[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    s = 0.0;
+    q = 0.0;
+    for (int k = 0; k < 8; ++k) {
+      s += red[(k * 32 + gi) * 2];
+      q += red[(k * 32 + gi) * 2 + 1];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(n * 32 + gi) * 2] = (float)mean;
+    stats[(n * 32 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <int DT, bool SILU, bool IN32>
@@ -556,14 +571,14 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
 int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
                      int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps, int max_slabs, half_t* y_lo) {
   if (C != 128 && C != 256 && C != 512) return fail(LATTE_ERR_INVALID, "groupnorm: C must be 128, 256 or 512");
-  int slabs = HW / 1024;
+  int slabs = HW / 256;   // >= 256 pixels per slab (round 3: 1024 -- the 64 x 64 and 128 x 128 maps then had 64 / 256 workgroups for 256 CUs)
   if (slabs < 1) slabs = 1;
   if (slabs > max_slabs) slabs = max_slabs;
   const size_t total_oct = (size_t)N * HW * C / 8;
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "groupnorm: the VAE kernels are built for f16 operands only");
   if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(32), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), eps);
   kprof_mark(VC_GN_STATS, st);
   const dim3 grid(grid_for(total_oct, 256));
 #define GN_APPLY(S, I) hipLaunchKernelGGL((gn_apply_kernel<LATTE_DTYPE_F16, S, I>), grid, dim3(256), 0, st, x, y, stats, gamma, beta, HW, C, total_oct, y_lo)
