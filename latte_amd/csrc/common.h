@@ -126,9 +126,6 @@ struct GemmArgs {
   int k_chunk;        // plain kernels (variants 1-3) only: > 0 splits the contraction, grid.y = ceil(K / k_chunk) partial products
   long split_stride;  // ... written to (float*)out + blockIdx.y * split_stride (use EPI_BIAS_F32 with a zero bias)
   LnFuse ln;          // EPI_GATE_RES_LN / EPI_LN_*: LayerNorm fusion operands (zero-initialised = unused)
-  int reverse;        // persistent kernels (variants 7-11): every XCD walks its chunk of the tile order from the end -- same tiles, same
-                      // results; consecutive kernels that walk the rows in opposite directions start on what the previous one touched
-                      // last, i.e. on what the 256 MB Infinity Cache still holds (engine option "walk")
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
@@ -182,7 +179,6 @@ struct QkvAttnArgs {
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
-  int reverse;         // every XCD walks its units from the end (same results; GemmArgs::reverse)
   LnFuse ln;           // ln.r != nullptr: xn is the un-normalised operand x (1 + scale) of a producer GEMM and the image-write
                        // phase applies r (acc - mu u) + v (u, v: [3 D] per sample, v includes the bias) -- `bias` is unused then
 };
@@ -195,7 +191,7 @@ int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 // If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T,
-                       int F, int dtype, hipStream_t st, int order = 0);   // order: row walk (pointwise.hip), same results
+                       int F, int dtype, hipStream_t st);
 enum SmallIn : int { IN_PLAIN = 0, IN_SILU = 1, IN_TFREQ = 2 };
 // out[b, n] = bias[n] + sum_k in(b,k) * W[n, k]  (+ add_table[add_idx[b], n]); fp32 exact.
 int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,

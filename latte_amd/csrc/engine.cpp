@@ -101,10 +101,6 @@ struct latte_engine {
   // whole separate pass), and shuffles / row statistics / the consumers' extra epilogue work eat the 4-byte read it saves
   // (profiles/r4_ln_fusion_ablation_v2_slots.log).  So the default is 0 = the separate ln_modulate kernel; the option stays for A/B.
   int fuse_ln = 0;
-  int ln_order = 0;                        // row walk of ln_modulate (pointwise.hip): 0 ascending, 1 descending, 2 descending per sample
-  // "walk" (round-4 experiment): which kernels of a block walk the rows from the END of every sample -- bit 0
-  // LN1, 1 qkv + attention, 2 out-projection, 3 LN2, 4 fc1, 5 fc2.  Same bits whatever the value; 0b101001... see the option's doc.
-  int walk = 0;
   int ln_dbg = 0;                          // measurement build only: LnFuse::dbg of every launch (ablations, results garbage)
   float *ln_slots = nullptr, *ln_r = nullptr, *ln_rm = nullptr;   // the producers' row-sum slots [D / 48][rows_pad][2], (r, r mu) per row
   float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]
@@ -291,7 +287,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     const bool ln1_fused = lnf && i >= 2;
     const float* ub = lnf ? uvp + (size_t)i * 2 * (3 * D + e->Hm) : nullptr;   // this block's [u_qkv | v_qkv | u_fc1 | v_fc1] of sample 0
     if (!ln1_fused) {
-      if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st, i == 0 ? 0 : ((e->walk & 1) ? 2 : e->ln_order)))) return rc;
+      if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
       tm.mark(C_LN);
     }
     GemmArgs g{};
@@ -304,7 +300,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
       qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-4 switch the default schedule features OFF (A/B hook)
-      qa.reverse = (e->walk >> 1) & 1;
       if (ln1_fused) {
         qa.ln.r = e->ln_r; qa.ln.rm = e->ln_rm; qa.ln.u = ub; qa.ln.v = ub + 3 * D; qa.ln.uv_stride = uv_stride;
       }
@@ -324,7 +319,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     }
     g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
-    g.reverse = (e->walk >> 2) & 1;
     if (lnf) {
       // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), the
       // row-sum slots; ln_rowstat turns them into (r, r mu) (its few microseconds are booked with the LayerNorm class)
@@ -356,14 +350,13 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     }
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
-    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st, (e->walk & 8) ? 2 : e->ln_order))) return rc;
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
     tm.mark(C_LN);
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
-    g.reverse = (e->walk >> 4) & 1;
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC1);
     g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
-    g.reverse = (e->walk >> 5) & 1;
+
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[3] ? e->gemm_variant_of[3] : e->gemm_variant, st))) return rc;
     tm.mark(C_FC2);
   }
@@ -623,16 +616,6 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     if (value < 0 || value > 31)
       return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..31)");
     e->fuse_qkv_attn = (int)value;
-    return LATTE_OK;
-  }
-  if (k == "walk") {
-    if (value < 0 || value > 63) return fail(LATTE_ERR_INVALID, "walk: bits 0-5 = LN1, qkv + attention, out-projection, LN2, fc1, fc2 walk every sample's rows from the end");
-    e->walk = (int)value;
-    return LATTE_OK;
-  }
-  if (k == "ln_order") {
-    if (value < 0 || value > 2) return fail(LATTE_ERR_INVALID, "ln_order: 0 (ascending rows), 1 (descending), 2 (descending inside every sample)");
-    e->ln_order = (int)value;
     return LATTE_OK;
   }
   if (k == "fuse_ln") {

@@ -599,7 +599,6 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   }
   const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;   // tile rows walked together (L2 reuse of the W panels)
   auto decode = [&](int wg, int& tm, int& tn) {
-    if (g.reverse) wg = 2 * chunk0 + cnt - 1 - wg;   // this XCD's chunk of the tile order walked from its end (GemmArgs::reverse)
     const int per_group = group_m * tiles_n;
     const int group = wg / per_group;
     const int first_m = group * group_m;

@@ -75,7 +75,6 @@ __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
   if (slot >= cnt) return;
   const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
   auto decode = [&](int wg, int& tm, int& tn) {
-    if (g.reverse) wg = 2 * chunk0 + cnt - 1 - wg;   // this XCD's chunk of the tile order walked from its end (GemmArgs::reverse)
     const int per_group = group_m * tiles_n;
     const int group = wg / per_group;
     const int first_m = group * group_m;
@@ -381,7 +380,6 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   if (slot >= cnt) return;
   const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
   auto decode = [&](int wg, int& tm, int& tn) {
-    if (g.reverse) wg = 2 * chunk0 + cnt - 1 - wg;   // this XCD's chunk of the tile order walked from its end (GemmArgs::reverse)
     const int per_group = group_m * tiles_n;
     const int group = wg / per_group;
     const int first_m = group * group_m;

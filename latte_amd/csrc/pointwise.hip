@@ -41,23 +41,16 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
                                                           half_t* __restrict__ y, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, int mod_stride, int M,
                                                           int rows_per_sample, const float* __restrict__ te, int T,
-                                                          int F, int order) {
+                                                          int F) {
   constexpr int D = NCH * 128;
   constexpr int NT = NCH * 32;            // float4 chunks per row
   constexpr int NQ = (NT + 63) / 64;      // chunk groups per lane
   const int lane = threadIdx.x & 63;
-  // Row order (round-4 experiment, engine option "ln_order"): the rows this pass reads were written a moment ago by a gated GEMM
-  // whose tile walk ends on the LAST rows of every sample; walking them newest-first would read what is still in the Infinity
-  // Cache.  0 = ascending rows, 1 = descending, 2 = descending inside every sample, the samples interleaved block by block.
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (Round 4 measured other row walks -- descending, descending inside every sample -- against the cache recency of what this pass
+  //  reads, together with reversed tile walks of the GEMMs around it: every combination within +-0.5 % of this one,
+  //  profiles/r4_row_walk_probe_B8.log; removed again.)
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  if (order == 1) {
-    row = M - 1 - row;
-  } else if (order == 2) {
-    const int ns = M / rows_per_sample, bps = rows_per_sample / 4;       // launcher: M % rows_per_sample == 0, rows_per_sample % 4 == 0
-    const int smp_ = blockIdx.x % ns, idx = blockIdx.x / ns;
-    row = smp_ * rows_per_sample + (bps - 1 - idx) * 4 + (threadIdx.x >> 6);
-  }
   const float4* xr = (const float4*)(x_in + (size_t)row * D);
   auto has = [&](int c) -> bool { return (c + 1) * 64 <= NT || c * 64 + lane < NT; };
   float4 v[NQ];
@@ -798,26 +791,25 @@ int launch_training_terms(const float* tables, int n_steps, int mean_type, int v
 
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T, int F,
-                       int dtype, hipStream_t st, int order) {
+                       int dtype, hipStream_t st) {
   if (D % 128 != 0) return fail(LATTE_ERR_INVALID, "ln_modulate: D % 128 != 0");
-  if (order == 2 && (rows_per_sample % 4 != 0 || M % rows_per_sample != 0)) order = 0;
   dim3 grid((M + 3) / 4), block(256);
 #define LN_LAUNCH(NCH)                                                                                         \
   do {                                                                                                         \
     if (dtype == LATTE_DTYPE_BF16) {                                                                           \
       if (temp_embed)                                                                                          \
         hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, true>), grid, block, 0, st, x_in, x_rw, y, \
-                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F, order);                    \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
       else                                                                                                     \
         hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, false>), grid, block, 0, st, x_in, x_rw, y, \
-                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F, order);                    \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
     } else {                                                                                                   \
       if (temp_embed)                                                                                          \
         hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, true>), grid, block, 0, st, x_in, x_rw, y, \
-                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F, order);                    \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
       else                                                                                                     \
         hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false>), grid, block, 0, st, x_in, x_rw, y, \
-                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F, order);                    \
+                           shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                    \
     }                                                                                                          \
   } while (0)
   LATTE_NCH_SWITCH(D, LN_LAUNCH)

@@ -152,7 +152,6 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   };
   auto decode = [&](int it_) -> Unit {
     Unit u;
-    if (a.reverse) it_ = it_end - 1 - it_;   // this XCD's units from the end (QkvAttnArgs::reverse)
     u.head = hmap ? ((xcd & 3) << 2) + (it_ & 3) : it_ % a.heads;
     const int sg = hmap ? ((it_ >> 2) << 1) + (xcd >> 2) : xmap ? (it_ / a.heads) * 8 + xcd : it_ / a.heads;
     if constexpr (MODE == 0) {
