@@ -236,7 +236,7 @@ int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
 // Kernel-choice overrides of the A/B tests (latte_debug_set_choice, include/latte_amd_debug.h; engine.cpp).  Process-global, 0 = the
 // library's own choice.  Every value selects another implementation of the SAME function; nothing here can change a result beyond
 // rounding.  (Round 3 read environment variables at every launch instead, among them ablations with garbage results.)
-enum DebugChoice { DBG_ATTN_VARIANT = 0, DBG_XATTN_FLASH, DBG_TN_KERNEL, DBG_TN_WN, DBG_ATTN_BWD_TILES, DBG_NUM_CHOICES };
+enum DebugChoice { DBG_ATTN_VARIANT = 0, DBG_XATTN_FLASH, DBG_TN_KERNEL, DBG_TN_WN, DBG_ATTN_BWD_TILES, DBG_CONV_KERNEL, DBG_NUM_CHOICES };
 int debug_choice(DebugChoice c);
 int set_debug_choice(const char* name, int value);   // 0 = ok, -1 = unknown name / value not offered by this build
 

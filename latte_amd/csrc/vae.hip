@@ -170,6 +170,162 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same implicit GEMM on the PING-PONG schedule of gemm_pp_kernel (gemm.hip): 256 pixels x BN output channels per
+// workgroup, eight waves = two groups of four (wave tile 128 x BN/4), BK = 64, two LDS stages; per K tile every wave runs a
+// fragment-read segment L and a compute segment C, group 1 one segment behind group 0, so on every SIMD one wave multiplies
+// while its partner reads.  The plain 128 x 128 kernel above has every wave issue 8 LDS-DMA instructions per 32 MFMAs -- the
+// issue holds the wave (gemm_pw.hip's header) -- and ran the decoder's convolutions at 0.31 of the MFMA peak; here it is 4 (A:
+// a group's waves gather its own 128 pixel rows) + BN/32 (B, group 0 only) per 16 BN/16 MFMAs.  The gather (zero padding,
+// nearest-2x upsample, 3-tap mode) is the per-lane source address as before; each lane keeps the (y, x, image) of its four
+// pixel rows in registers for the whole K loop.
+template <int BN, int DT>
+__global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
+  constexpr int BM = 256;
+  constexpr int WTN = BN / 4, FN = WTN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int AH_INSTR = 4;            // a group's 4 waves gather its 128 pixel rows: 8-row groups wn + 4 j
+  constexpr int BG_INSTR = BN / 8 / 4;   // W rows per wave of group 0
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int Hout = g.Hin << g.ups, Wout = g.Win << g.ups;
+  const int M = g.N * Hout * Wout;
+  const int K = (g.taps3 ? 3 : 9) * g.Cin;
+  int tm, tn;
+  tile_coords((M + BM - 1) / BM, g.Cout / BN, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const int srow = wn * 8 + lrow;                       // row inside the group's 32-row step (swizzle: 32 j and 128 grp do not move it)
+  const int schunk = cpos ^ ((srow >> 1) & 7);
+  int pyx[AH_INSTR], pbase[AH_INSTR];                   // output pixel (y << 16 | x) and image base pixel of row grp*128 + srow + 32 j
+#pragma unroll
+  for (int j = 0; j < AH_INSTR; ++j) {
+    const int m = m0 + grp * 128 + srow + 32 * j;
+    if (m < M) {
+      const int img = m / (Hout * Wout), rem = m - img * (Hout * Wout);
+      const int y = rem / Wout;
+      pyx[j] = (y << 16) | (rem - y * Wout);
+      pbase[j] = img * g.Hin * g.Win;
+    } else {
+      pyx[j] = 0x7ff0 << 16;   // every tap out of range
+      pbase[j] = 0;
+    }
+  }
+  // buffer addressing (one 32-bit per-lane offset per DMA instruction, scalar offsets for the rest; 64-bit pointers per
+  // instruction spilled at BN = 256): a padded tap gets an offset beyond the descriptor's range, which reads as zeros
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.in, 0, (unsigned)((size_t)g.N * g.Hin * g.Win * g.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (unsigned)((size_t)g.Cout * K * 2), 0x00020000);
+  const unsigned voff_b = ((unsigned)srow * (unsigned)K + (unsigned)(schunk * 8)) * 2u;
+  const unsigned b_step = 32u * (unsigned)K * 2u;
+  const int cpt = g.Cin >> 6;   // K tiles per tap
+  typedef __attribute__((address_space(3))) void lds_void_c;
+
+  auto dma_a_half = [&](int kt) {
+    char* sA = smem + (kt & 1) * STAGE + grp * 128 * 128 + wn * 1024;
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+    const int dy = g.taps3 ? tap - 1 : tap / 3 - 1, dx = g.taps3 ? 0 : tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int j = 0; j < AH_INSTR; ++j) {
+      const int yy = (pyx[j] >> 16) + dy, xx = (pyx[j] & 0xffff) + dx;
+      const bool ok = yy >= 0 && yy < Hout && xx >= 0 && xx < Wout;
+      const int sy = yy >> g.ups, sx = xx >> g.ups;
+      const unsigned voff = ok ? ((unsigned)(pbase[j] + sy * g.Win + sx) * (unsigned)g.Cin + (unsigned)(c0 + schunk * 8)) * 2u : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_c*)(sA + j * 4 * 1024), 16, voff, 0u, 0, 0);
+    }
+  };
+  auto dma_b_all = [&](int kt) {
+    char* sB = smem + (kt & 1) * STAGE + A_BYTES + wn * 1024;
+    const unsigned so = ((unsigned)n0 * (unsigned)K + (unsigned)kt * 64u) * 2u;
+#pragma unroll
+    for (int j = 0; j < BG_INSTR; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_c*)(sB + j * 4 * 1024), 16, voff_b, so + (unsigned)j * b_step, 0, 0);
+  };
+
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int chunk0 = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + frow) * 128 + chunk0;
+  const int b_off = A_BYTES + (wn * WTN + frow) * 128 + chunk0;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  dma_a_half(0);                       // prologue: K tile 0 in the main loop's own mapping
+  if (grp == 0) dma_b_all(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sbuf = smem + (kt & 1) * STAGE;
+    u32x4 bf[2][FN], af[2][8];
+    // ---- L(kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+    }
+    if (kt + 1 < nk) {
+      dma_a_half(kt + 1);
+      if (grp == 0) dma_b_all(kt + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage kt fully consumed by this wave
+    __builtin_amdgcn_s_barrier();
+    // ---- C(kt)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA of K tile kt+1 landed
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+
+  // lane holds out[pixel m = .. + (lane & 15)][co = .. + (lane >> 4) * 4 + {0..3}]  (the plain kernel's epilogue)
+  const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + grp * 128 + i * 16 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = ncol + j * 16;
+      const float4 b4 = *(const float4*)(g.bias + n);
+      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      const size_t o = (size_t)m * g.Cout + n;
+      if (g.out32 != nullptr) {
+        if (g.res32 != nullptr) {
+          const float4 r4 = *(const float4*)(g.res32 + o);
+          v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
+        }
+        *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
+        continue;
+      }
+      if (g.res != nullptr) {
+        const u32x2 r2 = *(const u32x2*)(g.res + o);
+        float r0, r1, r2f, r3;
+        unpack2<DT>(r2[0], r0, r1);
+        unpack2<DT>(r2[1], r2f, r3);
+        v0 += r0; v1 += r1; v2 += r2f; v3 += r3;
+      }
+      const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+      *(u32x2*)(g.out + o) = p;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // partial[n][slab][g] = (sum, sumsq) over the slab's pixels and the group's channels.  One thread owns 8 consecutive
 // channels of a pixel (16-byte loads); the per-thread sums are combined in a FIXED order (deterministic).
@@ -639,9 +795,29 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   if (taps3 && ups) return fail(LATTE_ERR_INVALID, "conv3x3: the 3-tap form has no upsampling");
   ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups, taps3};
   const int M = N * (Hin << ups) * (Win << ups);
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv3x3: the VAE kernels are built for f16 operands only");
+  // the ping-pong kernel (256 pixels x 128 | 256 channels) wherever its tiles fill the chip; small maps keep the 128 x 128 tile
+  // (latte_debug_set_choice("conv_kernel", 1) forces the plain kernel: A/B tests)
+  const int bn = Cout % 256 == 0 ? 256 : 128;
+  const int pp_tiles = ((M + 255) / 256) * (Cout / bn);
+  if (debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
+    if (bn == 256) {
+      constexpr int LDS_PP = 2 * (256 + 256) * 128;
+      static std::atomic<uint64_t> attr_a{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<256, LATTE_DTYPE_F16>, LDS_PP, attr_a)) return rc_;
+      hipLaunchKernelGGL((conv3x3_pp_kernel<256, LATTE_DTYPE_F16>), dim3(pp_tiles), dim3(512), LDS_PP, st, a);
+    } else {
+      constexpr int LDS_PP = 2 * (256 + 128) * 128;
+      static std::atomic<uint64_t> attr_b{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<128, LATTE_DTYPE_F16>, LDS_PP, attr_b)) return rc_;
+      hipLaunchKernelGGL((conv3x3_pp_kernel<128, LATTE_DTYPE_F16>), dim3(pp_tiles), dim3(512), LDS_PP, st, a);
+    }
+    kprof_mark(VC_CONV3, st);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   const int tiles = ((M + 127) / 128) * (Cout / 128);
   constexpr int LDS = 2 * 256 * 128;
-  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv3x3: the VAE kernels are built for f16 operands only");
   static std::atomic<uint64_t> attr_f16{0};
   if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, LDS, attr_f16)) return rc_;
   hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);

@@ -2,9 +2,9 @@
 # The closing GPU evidence of a round, one command on the GPU box (from the repo root; results under gpurun_out/):
 #   full GPU test suite, smoke, the driver's default bench line, then rocprofv3 kernel stats of the bench command and the PMC
 #   passes (tools/pmc_round.sh <tag>); fold the PMC output into profiles/ afterwards with  python tools/pmc_collect.py <tag>.
-# Usage:  bash tools/gpu_evidence_round.sh [tag]        (e.g. through gpurun: /usr/local/graft/bin/gpurun -- 'bash tools/gpu_evidence_round.sh r3')
+# Usage:  bash tools/gpu_evidence_round.sh [tag]        (e.g. through gpurun: /usr/local/graft/bin/gpurun -- 'bash tools/gpu_evidence_round.sh r4')
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
 mkdir -p $O
 cd $R

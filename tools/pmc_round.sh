@@ -4,7 +4,7 @@
 # passes (TCC slots), (3) kernel stats of a forward + one 16-frame VAE decode.  Run from the repo root on the GPU box:
 #   bash tools/pmc_round.sh r2      -> gpurun_out/<tag>_*   then   python tools/pmc_collect.py r2
 set -u
-TAG=${1:-r2}
+TAG=${1:-r4}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
