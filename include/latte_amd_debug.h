@@ -77,6 +77,11 @@ int latte_debug_groupnorm(const void* x, void* y, const float* gamma, const floa
 
 /* The forms the decoder's fp32 residual stream uses: out32[N,Ho,Wo,Cout] = conv(in half) + bias (+ res32), nothing rounded to
  * half; GroupNorm [+ SiLU] of an fp32 NHWC input to a half output. */
+/* The 3-tap form of the convolution kernels -- the temporal Conv3d (3,1,1) of AutoencoderKLTemporalDecoder on the "image"
+ * [T frames][HW pixels] of one video chunk: in half [T, HW, Cin], w_packed half [Cout, 3 * Cin] (k = ky * Cin + ci), bias [Cout],
+ * res32 (may be NULL) / out32 fp32 [T, HW, Cout].  HW may exceed 65535 (512 x 512 frames). */
+int latte_debug_conv3rows_f32(const void* in, const void* w_packed, const float* bias, const float* res32, float* out32, int T, int HW,
+                              int Cin, int Cout, int dtype, void* stream);
 int latte_debug_conv3x3_f32(const void* in, const float* w, const float* bias, const float* res32, float* out32, int N, int H,
                             int W, int Cin, int Cout, int ups, int dtype, void* stream);
 int latte_debug_groupnorm_f32(const float* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int silu,

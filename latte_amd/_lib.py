@@ -141,6 +141,7 @@ PROTOTYPES = {
     "latte_debug_conv3x3": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void]),
     "latte_debug_vae_trace": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_void, c_void]),
+    "latte_debug_conv3rows_f32": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
     "latte_debug_conv3x3_f32": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void]),
     "latte_debug_groupnorm_f32": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),

@@ -285,6 +285,20 @@ int latte_debug_conv3x3(const void* in, const float* w, const float* bias, const
 }
 
 /* The decoder's fp32-stream forms: out32 = conv(in) + bias (+ res32), and GroupNorm of an fp32 input. */
+// The 3-tap form of the convolution kernels (the temporal Conv3d (3,1,1) of AutoencoderKLTemporalDecoder on the "image" [T frames][HW
+// pixels]): in half [T, HW, Cin], w_packed half [Cout, 3 * Cin] (k = ky * Cin + ci), fp32 residual / output [T, HW, Cout].
+int latte_debug_conv3rows_f32(const void* in, const void* w_packed, const float* bias, const float* res32, float* out32, int T, int HW,
+                              int Cin, int Cout, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  half_t* zeros = nullptr;
+  LATTE_HIP(hipMalloc((void**)&zeros, 64));
+  LATTE_HIP(hipMemsetAsync(zeros, 0, 64, st));
+  int rc = launch_conv3x3((const half_t*)in, (const half_t*)w_packed, bias, nullptr, nullptr, zeros, 1, T, HW, Cin, Cout, 0, dtype, st, res32, out32, 1);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(zeros);
+  return rc;
+}
+
 int latte_debug_conv3x3_f32(const void* in, const float* w, const float* bias, const float* res32, float* out32, int N, int H,
                             int W, int Cin, int Cout, int ups, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;

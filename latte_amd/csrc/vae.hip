@@ -200,17 +200,32 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
   const int lrow = lane >> 3, cpos = lane & 7;
   const int srow = wn * 8 + lrow;                       // row inside the group's 32-row step (swizzle: 32 j and 128 grp do not move it)
   const int schunk = cpos ^ ((srow >> 1) & 7);
-  int pyx[AH_INSTR], pbase[AH_INSTR];                   // output pixel (y << 16 | x) and image base pixel of row grp*128 + srow + 32 j
+  // Per pixel row of this lane (row grp*128 + srow + 32 j): without upsampling, the byte offset of the pixel's own channel chunk and
+  // a bit mask of the taps that stay inside the image -- a tap is then ONE add of a scalar delta and a select; with the nearest-2x
+  // upsample the source pixel of a tap depends on the parities, so (y, x, image) are kept and the address is formed per tap.
+  const bool fast = g.ups == 0;
+  int pyx[AH_INSTR], pbase[AH_INSTR];                   // ups: (y << 16 | x), image base pixel;  fast: tap mask, centre byte offset
+  const int ntap = g.taps3 ? 3 : 9;
 #pragma unroll
   for (int j = 0; j < AH_INSTR; ++j) {
     const int m = m0 + grp * 128 + srow + 32 * j;
     if (m < M) {
       const int img = m / (Hout * Wout), rem = m - img * (Hout * Wout);
-      const int y = rem / Wout;
-      pyx[j] = (y << 16) | (rem - y * Wout);
-      pbase[j] = img * g.Hin * g.Win;
+      const int y = rem / Wout, x = rem - y * Wout;
+      if (fast) {
+        int mask = 0;
+        for (int tap = 0; tap < ntap; ++tap) {
+          const int yy = y + (g.taps3 ? tap - 1 : tap / 3 - 1), xx = x + (g.taps3 ? 0 : tap % 3 - 1);
+          if (yy >= 0 && yy < Hout && xx >= 0 && xx < Wout) mask |= 1 << tap;
+        }
+        pyx[j] = mask;
+        pbase[j] = (int)(((unsigned)(img * g.Hin * g.Win + y * g.Win + x) * (unsigned)g.Cin + (unsigned)(schunk * 8)) * 2u);
+      } else {
+        pyx[j] = (y << 16) | x;
+        pbase[j] = img * g.Hin * g.Win;
+      }
     } else {
-      pyx[j] = 0x7ff0 << 16;   // every tap out of range
+      pyx[j] = fast ? 0 : (0x7ff0 << 16);   // every tap out of range
       pbase[j] = 0;
     }
   }
@@ -227,6 +242,15 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
     char* sA = smem + (kt & 1) * STAGE + grp * 128 * 128 + wn * 1024;
     const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
     const int dy = g.taps3 ? tap - 1 : tap / 3 - 1, dx = g.taps3 ? 0 : tap - (tap / 3) * 3 - 1;
+    if (fast) {
+      const int delta = ((dy * g.Win + dx) * g.Cin + c0) * 2;   // wave-uniform byte step of this tap / channel tile
+#pragma unroll
+      for (int j = 0; j < AH_INSTR; ++j) {
+        const unsigned voff = ((pyx[j] >> tap) & 1) ? (unsigned)(pbase[j] + delta) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_c*)(sA + j * 4 * 1024), 16, voff, 0u, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AH_INSTR; ++j) {
       const int yy = (pyx[j] >> 16) + dy, xx = (pyx[j] & 0xffff) + dx;
@@ -800,7 +824,10 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   // (latte_debug_set_choice("conv_kernel", 1) forces the plain kernel: A/B tests)
   const int bn = Cout % 256 == 0 ? 256 : 128;
   const int pp_tiles = ((M + 255) / 256) * (Cout / bn);
-  if (debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
+  // its gather addresses the input through 32-bit buffer offsets and, with the upsample, packs (y, x) into 16 bits each
+  const bool pp_ok = (uint64_t)N * Hin * Win * Cin * 2 < (1ull << 32) && (uint64_t)Cout * 9 * Cin * 2 < (1ull << 32) &&
+                     (!ups || ((Hin << ups) < 32768 && (Win << ups) < 65536));
+  if (pp_ok && debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
     if (bn == 256) {
       constexpr int LDS_PP = 2 * (256 + 256) * 128;
       static std::atomic<uint64_t> attr_a{0};

@@ -77,6 +77,33 @@ def test_conv3x3_kernel(lib, dt, case, kernel):
         check(lib.latte_debug_set_choice(b"conv_kernel", 0))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [1, 2], ids=["plain128", "pingpong256"])
+@pytest.mark.parametrize("case", [(3, 70016, 64, 128), (14, 4096, 128, 256)])
+def test_conv3_rows_kernel_wide_images(lib, kernel, case):
+    """The 3-tap form (AutoencoderKLTemporalDecoder's Conv3d (3,1,1): frames are the rows of an "image" whose width is the frame's
+    pixel count) at a width beyond 16 bits -- a 512 x 512 frame has 262 144 pixels -- and at a chunk of 14 frames."""
+    from latte_amd._lib import check, ptr, stream_ptr
+    T, HW, Cin, Cout = case
+    dev = torch.device("cuda")
+    g = torch.Generator("cpu").manual_seed(T + HW)
+    x = torch.randn(T, HW, Cin, generator=g).half().to(dev)
+    w = (torch.randn(Cout, 3, Cin, generator=g) / (3 * Cin) ** 0.5).half().to(dev)          # [co][ky][ci] = the packed layout
+    b = torch.randn(Cout, generator=g).to(dev)
+    r32 = torch.randn(T, HW, Cout, generator=g).to(dev)
+    xp = torch.nn.functional.pad(x.float(), (0, 0, 0, 0, 1, 1))                                # zero frames before and after
+    want = r32 + b + sum(xp[ky:ky + T] @ w[:, ky].float().t() for ky in range(3))
+    out = torch.zeros(T, HW, Cout, device=dev)
+    check(lib.latte_debug_set_choice(b"conv_kernel", kernel))
+    try:
+        check(lib.latte_debug_conv3rows_f32(ptr(x), ptr(w.reshape(Cout, 3 * Cin).contiguous()), ptr(b), ptr(r32), ptr(out), T, HW, Cin, Cout, 1,
+                                            stream_ptr()))
+    finally:
+        check(lib.latte_debug_set_choice(b"conv_kernel", 0))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), want.cpu()) < 2e-5
+
+
 def _conv3x3_case(lib, dt, case):
     from latte_amd._lib import check, ptr, stream_ptr
     N, H, W, Cin, Cout, ups, use_res = case

@@ -36,7 +36,7 @@ def classify(name):
         return "attn_temporal"
     if "ln_modulate_kernel" in n:
         return "ln_modulate"
-    if "conv3x3_kernel" in n:
+    if "conv3x3_kernel" in n or "conv3x3_pp_kernel" in n:
         return "vae_conv3x3"
     if "gn_partial_kernel" in n:
         return "vae_groupnorm_stats"
