@@ -463,28 +463,32 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
   }
 }
 
+// Round 4: a thread's channel octet never changes along its grid-stride walk (the stride is a multiple of the octets per pixel), so
+// gamma / beta live in registers and the octet spans at most two groups (channels per group >= 4): per element of the walk one
+// 32-byte load, two 8-byte statistics loads and the stores -- round 3 looked the statistics up per channel (16 loads) and gamma /
+// beta per iteration (4 more) for every 32 bytes of payload.
 template <int DT, bool SILU, bool IN32>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const void* __restrict__ x, half_t* __restrict__ y,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int HW, int C, size_t total_oct,
                                                        half_t* __restrict__ y_lo) {
   const int cpg = C >> 5, oct_per_px = C >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_oct; i += (size_t)gridDim.x * blockDim.x) {
-    const int oct = (int)(i % oct_per_px);
-    const size_t px = i / oct_per_px;
-    const int n = (int)(px / HW);
-    const int c0 = oct * 8;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;   // step % oct_per_px == 0
+  const int oct = (int)(i0 % oct_per_px), c0 = oct * 8;
+  const int g0 = c0 / cpg, g1 = (c0 + 4) / cpg;
+  const float4 ga = *(const float4*)(gamma + c0), gb = *(const float4*)(gamma + c0 + 4);
+  const float4 ba = *(const float4*)(beta + c0), bb = *(const float4*)(beta + c0 + 4);
+  const float gam[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+  const float bet[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+  for (size_t i = i0; i < total_oct; i += step) {
+    const int n = (int)((i / oct_per_px) / HW);
+    const float2 s0 = *(const float2*)(stats + (n * 32 + g0) * 2), s1 = *(const float2*)(stats + (n * 32 + g1) * 2);   // (mean, rstd)
     float f[8];
     load_oct<DT, IN32>(x, i, f);
-    const float4 ga = *(const float4*)(gamma + c0), gb = *(const float4*)(gamma + c0 + 4);
-    const float4 ba = *(const float4*)(beta + c0), bb = *(const float4*)(beta + c0 + 4);
-    const float gam[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-    const float bet[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int gi = (c0 + e) / cpg;
-      const float mean = stats[(n * 32 + gi) * 2], rstd = stats[(n * 32 + gi) * 2 + 1];
+      const float mean = e < 4 ? s0.x : s1.x, rstd = e < 4 ? s0.y : s1.y;
       float t = (f[e] - mean) * rstd * gam[e] + bet[e];
       if constexpr (SILU) t = silu_f(t);
       o[e] = t;
