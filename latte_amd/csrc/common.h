@@ -266,7 +266,7 @@ int launch_scale_by_sigmoid(const float* in, float* out, int n, const float* mix
 int launch_time_conv_out(const float* in, const float* w, const float* bias, void* out, int T, int HW, int out_mode, hipStream_t st);
 // x: half [N, HW, C] or (x_is_f32) fp32; y: half
 int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
-                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps = 1e-6f, int max_slabs = 64, half_t* y_lo = nullptr);
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps = 1e-6f, int max_slabs = 256, half_t* y_lo = nullptr);   // max_slabs <= groupnorm_max_slabs() (x T frames for one T-frame sample)
 int groupnorm_max_slabs();
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st);
 int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st);

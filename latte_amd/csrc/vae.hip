@@ -390,7 +390,19 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const void* __restrict_
   };
   const size_t base = (size_t)n * HW;
   int p = p0 + pl;
-  for (; p + 3 * px_per_it < p1; p += 4 * px_per_it) {   // same pixel order per thread as a one-by-one walk: same sums
+  for (; p + 7 * px_per_it < p1; p += 8 * px_per_it) {   // same pixel order per thread as a one-by-one walk: same sums
+    float f0[8], f1[8], f2[8], f3[8], f4[8], f5[8], f6[8], f7[8];
+    load_oct<DT, IN32>(x, (base + p) * oct_per_px + oct, f0);
+    load_oct<DT, IN32>(x, (base + p + px_per_it) * oct_per_px + oct, f1);
+    load_oct<DT, IN32>(x, (base + p + 2 * px_per_it) * oct_per_px + oct, f2);
+    load_oct<DT, IN32>(x, (base + p + 3 * px_per_it) * oct_per_px + oct, f3);
+    load_oct<DT, IN32>(x, (base + p + 4 * px_per_it) * oct_per_px + oct, f4);
+    load_oct<DT, IN32>(x, (base + p + 5 * px_per_it) * oct_per_px + oct, f5);
+    load_oct<DT, IN32>(x, (base + p + 6 * px_per_it) * oct_per_px + oct, f6);
+    load_oct<DT, IN32>(x, (base + p + 7 * px_per_it) * oct_per_px + oct, f7);
+    add(f0); add(f1); add(f2); add(f3); add(f4); add(f5); add(f6); add(f7);
+  }
+  for (; p + 3 * px_per_it < p1; p += 4 * px_per_it) {
     float f0[8], f1[8], f2[8], f3[8];
     load_oct<DT, IN32>(x, (base + p) * oct_per_px + oct, f0);
     load_oct<DT, IN32>(x, (base + p + px_per_it) * oct_per_px + oct, f1);
@@ -878,7 +890,7 @@ int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma,
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
-int groupnorm_max_slabs() { return 64; }
+int groupnorm_max_slabs() { return 256; }   // (round 3: 64 -- 1024 workgroups on the largest map, 64 iterations of one load each per thread)
 
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st) {
   hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((size_t)N * hw, 256)), dim3(256), 0, st, z, w, b, out, N, hw, z_scale);

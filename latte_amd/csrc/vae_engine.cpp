@@ -178,10 +178,10 @@ int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, 
   // temporal-decoder mode: the activation operand of both 3x3 convolutions is split hi + lo (b = the f16 rounding residual of the
   // GroupNorm output) and a second pass adds conv(lo): the decoder with twice as many blocks per stage stays under the 1e-3 bar
   half_t* lo = v->temporal ? b : nullptr;
-  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st, 1e-6f, 64, lo))) return rc;
+  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
   if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, nullptr, v->tbuf))) return rc;
   if (lo && (rc = launch_conv3x3(lo, r.c1w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, v->tbuf, v->tbuf))) return rc;
-  if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st, 1e-6f, 64, lo))) return rc;
+  if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
   if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
     float* y = *s2;
     if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
@@ -206,11 +206,11 @@ int run_tresnet(latte_vae* v, const TResnet& t, float* x, half_t* c, half_t* clo
   // fp32 restatement, above the 1e-3 bar; a 3-tap convolution costs a third of a 3x3 one, so three passes cost one)
   int rc;
   const int HW = H * W, dt = v->dtype, C = t.c;
-  if ((rc = launch_groupnorm(x, 1, c, t.n1w, t.n1b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, 64 * T, clo))) return rc;
+  if ((rc = launch_groupnorm(x, 1, c, t.n1w, t.n1b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, groupnorm_max_slabs() * T, clo))) return rc;
   if ((rc = launch_conv3x3(c, t.c1w, t.c1b, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, nullptr, v->tbuf, 1))) return rc;
   if ((rc = launch_conv3x3(clo, t.c1w, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, v->tbuf, v->tbuf, 1))) return rc;
   if ((rc = launch_conv3x3(c, t.c1w_lo, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, v->tbuf, v->tbuf, 1))) return rc;
-  if ((rc = launch_groupnorm(v->tbuf, 1, c, t.n2w, t.n2b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, 64 * T, clo))) return rc;
+  if ((rc = launch_groupnorm(v->tbuf, 1, c, t.n2w, t.n2b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, groupnorm_max_slabs() * T, clo))) return rc;
   // out = x_spatial + sigmoid(mix) * (conv2 + bias): weights and bias were folded with the blend factor
   if ((rc = launch_conv3x3(c, t.c2w, t.c2b_eff, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1))) return rc;
   if ((rc = launch_conv3x3(clo, t.c2w, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1))) return rc;
