@@ -84,3 +84,27 @@ def test_layernorm_fusion_rule(lib):
     assert fus(8, 384, 1536, 6) == 1  # S/2 at 16 x 32 x 32 latents
     assert lib.latte_debug_ln_fusable(1152, 4608, 16, 16, 64, 8 * 16 * 64) == 0     # 8 x 8 tokens per frame: no fused spatial kernel
     assert lib.latte_debug_ln_fusable(1152, 4608, 16, 8, 256, 16 * 8 * 256) == 0    # 8 frames: no fused temporal kernel
+
+
+def test_debug_choice_offers_only_implementations_of_the_same_function(lib):
+    """Round-3 advisor finding: the launchers read LATTE_* environment variables per launch, among them ablation variants with
+    garbage results.  The overrides are an explicit debug entry now (include/latte_amd_debug.h); the product library refuses the
+    ablation values (attention variants 7-9, the removed block kernel's 4) and unknown names."""
+    for name, v in (("attn_variant", 4), ("attn_variant", 7), ("attn_variant", 9), ("no_such_choice", 1), ("tn_kernel", 3), ("conv_kernel", 3)):
+        assert lib.latte_debug_set_choice(name.encode(), v) != 0, (name, v)
+    for name, v in (("attn_variant", 1), ("attn_variant", 5), ("xattn_flash", 1), ("tn_kernel", 4), ("tn_wn", 4), ("attn_bwd_tiles", 1),
+                    ("conv_kernel", 1), ("conv_kernel", 2)):
+        assert lib.latte_debug_set_choice(name.encode(), v) == 0, (name, v)
+        assert lib.latte_debug_set_choice(name.encode(), 0) == 0
+
+
+def test_no_kernel_reads_the_environment_in_the_product_build():
+    """No getenv outside the measurement build (LATTE_GEMM_ABLATE) in the kernels' launchers."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "latte_amd", "csrc")
+    for fn in sorted(os.listdir(root)):
+        src = open(os.path.join(root, fn)).read()
+        # drop the #ifdef LATTE_GEMM_ABLATE ... #endif regions, then look for getenv
+        kept = re.sub(r"#ifdef LATTE_GEMM_ABLATE.*?#endif", "", src, flags=re.S)
+        assert "getenv" not in kept, fn
