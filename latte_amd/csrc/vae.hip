@@ -359,9 +359,11 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
 
   // lane holds out[pixel m = .. + (lane & 15)][co = .. + (lane >> 4) * 4 + {0..3}]  (the plain kernel's epilogue)
   const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
-  float gs[FN], gq[FN];
+  // GroupNorm partials in 64-PIXEL slabs (rows i < 4 | i >= 4 of the wave's 128), summed per lane in the plain kernel's order: the
+  // two kernels then leave the same bits, and a frame decoded alone (few tiles: plain kernel) equals the frame inside a batch
+  float gs[FN], gq[FN], gs2[FN], gq2[FN];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) gs[j] = gq[j] = 0.f;
+  for (int j = 0; j < FN; ++j) gs[j] = gq[j] = gs2[j] = gq2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + grp * 128 + i * 16 + frow;
@@ -378,8 +380,13 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
           v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
         }
         *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
-        gs[j] += (v0 + v1) + (v2 + v3);
-        gq[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        if (i < 4) {
+          gs[j] += (v0 + v1) + (v2 + v3);
+          gq[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        } else {
+          gs2[j] += (v0 + v1) + (v2 + v3);
+          gq2[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
         continue;
       }
       if (g.res != nullptr) {
@@ -393,8 +400,11 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
       *(u32x2*)(g.out + o) = p;
     }
   }
-  if (g.gn_partial != nullptr && g.out32 != nullptr)   // this wave: 128 pixels (one slab) x WTN channels
-    gn_emit<FN>(g, gs, gq, lane, n0 + wn * WTN, m0 / g.gn_hw, ((m0 % g.gn_hw) >> 8) * 2 + grp);
+  if (g.gn_partial != nullptr && g.out32 != nullptr) {   // this wave: 128 pixels (two 64-pixel slabs) x WTN channels
+    const int slab0 = ((m0 % g.gn_hw) >> 6) + grp * 2;
+    gn_emit<FN>(g, gs, gq, lane, n0 + wn * WTN, m0 / g.gn_hw, slab0);
+    gn_emit<FN>(g, gs2, gq2, lane, n0 + wn * WTN, m0 / g.gn_hw, slab0 + 1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
@@ -895,13 +905,13 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   auto want_gn = [&](int px_per_wave) -> bool {   // whole wave tiles inside a frame, the partial buffer's slab bound, 4 | 8 | 16 channels per group
     const int cpg = Cout / 32;
     if (!gn_partial || !out32 || !gn_slabs_out || taps3 || (cpg != 4 && cpg != 8 && cpg != 16)) return false;
-    if (HWo % (2 * px_per_wave) != 0 || HWo / px_per_wave > groupnorm_max_slabs()) return false;
+    if (HWo % 256 != 0 || HWo / px_per_wave > groupnorm_max_slabs()) return false;   // whole tiles of either kernel inside a frame
     a.gn_partial = gn_partial; a.gn_slabs = HWo / px_per_wave; a.gn_cpg = cpg; a.gn_hw = HWo;
     *gn_slabs_out = a.gn_slabs;
     return true;
   };
   if (pp_ok && debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
-    want_gn(128);
+    want_gn(64);   // 64-pixel slabs in both kernels
     if (bn == 256) {
       constexpr int LDS_PP = 2 * (256 + 256) * 128;
       static std::atomic<uint64_t> attr_a{0};
@@ -950,7 +960,7 @@ int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma,
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
-int groupnorm_max_slabs() { return 512; }   // (round 3: 64 -- 1024 workgroups on the largest map, 64 iterations of one load each per thread)
+int groupnorm_max_slabs() { return 1024; }   // 64-pixel slabs of a 256 x 256 map   // (round 3: 64 -- 1024 workgroups on the largest map, 64 iterations of one load each per thread)
 
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st) {
   hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((size_t)N * hw, 256)), dim3(256), 0, st, z, w, b, out, N, hw, z_scale);

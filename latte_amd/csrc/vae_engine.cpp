@@ -460,6 +460,8 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   hipStream_t st = (hipStream_t)stream;
   const int N = n_frames, dt = v->dtype, top = v->ch[3];
   int H = v->h, W = v->h;
+  v->gn_ready = 0;            // nothing is handed over between decodes (a traced decode stops right behind a convolution)
+  v->gn_ready_ptr = nullptr;
   if (!v->bias_folded) {
     // softmax rows sum to 1, so  to_out(P (V0 + 1 bv^T)) = to_out(P V0) + (Wo bv + bo): the value bias is folded into
     // the output bias and V^T is produced directly by a GEMM (no transpose kernel)
