@@ -259,18 +259,14 @@ int launch_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, hip
 // out32 != nullptr: fp32 output  out32 = conv + bias (+ res32)  (the decoder's residual stream is fp32); else half `out` (+ res)
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
                    const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
-                   const float* res32 = nullptr, float* out32 = nullptr, int taps3 = 0, float* gn_partial = nullptr,
-                   int* gn_slabs_out = nullptr);
-// gn_partial (with out32): the epilogue also writes the GroupNorm(32) partial sums of the OUTPUT in gn_partial_kernel's layout
-// [N][slabs][32][2]; *gn_slabs_out = slabs per frame, or 0 when the shape does not allow it (the caller then runs the statistics
-// pass as usual).  launch_groupnorm(..., ready_slabs > 0) skips its statistics pass and finalizes those partials.
+                   const float* res32 = nullptr, float* out32 = nullptr, int taps3 = 0);
 // AutoencoderKLTemporalDecoder pieces: Conv3d (3,1,1) weight pack (optionally scaled by sigmoid(*mix)), bias scale, time_conv_out
 int launch_pack_conv_t(const float* w, half_t* out, int Cout, int Cin, const float* mix, int dtype, hipStream_t st, half_t* out_lo = nullptr);
 int launch_scale_by_sigmoid(const float* in, float* out, int n, const float* mix, hipStream_t st);
 int launch_time_conv_out(const float* in, const float* w, const float* bias, void* out, int T, int HW, int out_mode, hipStream_t st);
 // x: half [N, HW, C] or (x_is_f32) fp32; y: half
 int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
-                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps = 1e-6f, int max_slabs = 256, half_t* y_lo = nullptr, int ready_slabs = 0);   // max_slabs <= groupnorm_max_slabs() (x T frames for one T-frame sample)
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps = 1e-6f, int max_slabs = 256, half_t* y_lo = nullptr);   // max_slabs <= groupnorm_max_slabs() (x T frames for one T-frame sample)
 int groupnorm_max_slabs();
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st);
 int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st);

@@ -41,44 +41,9 @@ struct ConvArgs {
   float* out32;         // fp32 output: out32 = acc + bias (+ res32), nothing is rounded to half
   const half_t* zeros;  // >= 16 bytes of zeros (padded taps)
   int N, Hin, Win, Cin, Cout, ups;   // Hout = Hin << ups
-  // GroupNorm statistics of the OUTPUT, emitted by the epilogue (round 4): every wave owns whole groups of its channel range, so it
-  // writes its pixels' (sum, sum of squares) per group into its own slab of gn_partial[n][slab][32][2] -- the layout gn_partial_kernel
-  // writes -- and the GroupNorm that follows skips its statistics pass.  nullptr = off.  Needs out32 and HW % (pixels per wave) == 0.
-  float* gn_partial;
-  int gn_slabs, gn_cpg, gn_hw;   // slabs per frame (= HW / pixels per wave tile), channels per group of the OUTPUT, pixels per frame
   int taps3;   // 1: a 3-tap convolution along the image ROWS (w = [Cout, 3 * Cin], k = ky * Cin + ci; the temporal Conv3d (3,1,1) of
                // AutoencoderKLTemporalDecoder on the "image" [frames][h * w] of one video)
 };
-
-// Per-wave GroupNorm partials of a conv output tile (ConvArgs::gn_partial).  s[j] / q[j]: this lane's sums over its rows of the 4
-// channels [col0 + 16 j + 4 (lane >> 4), + 4) -- one group or part of one (cpg >= 4).  Reduction: the 16 pixel lanes of a channel
-// quad, then the quads of a group (cpg 8: two, cpg 16: four); one lane writes the wave's (frame, slab, group) entry -- no other
-// wave owns it (a wave's channel range covers whole groups: 32 | 64 channels, cpg <= 16), so plain stores, fixed order.
-template <int FN>
-__device__ __forceinline__ void gn_emit(const ConvArgs& g, float (&s)[FN], float (&q)[FN], int lane, int col0, int frame, int slab) {
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    float a = s[j], b = q[j];
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-      a += __shfl_xor(a, m, 64);
-      b += __shfl_xor(b, m, 64);
-    }
-    if (g.gn_cpg >= 8) {
-      a += __shfl_xor(a, 16, 64);
-      b += __shfl_xor(b, 16, 64);
-    }
-    if (g.gn_cpg >= 16) {
-      a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 32, 64);
-    }
-    const int quad = lane >> 4, qpg = g.gn_cpg >> 2;          // channel quads per group: 1, 2, 4
-    if ((lane & 15) == 0 && (quad % qpg) == 0) {
-      const int gi = (col0 + j * 16 + quad * 4) / g.gn_cpg;
-      *(float2*)(g.gn_partial + (((size_t)frame * g.gn_slabs + slab) * 32 + gi) * 2) = make_float2(a, b);
-    }
-  }
-}
 
 // 128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators.
 template <int DT>
@@ -174,7 +139,6 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
 
   // lane holds out[pixel m = .. + (lane & 15)][co = .. + (lane >> 4) * 4 + {0..3}]
   const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
-  float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + frow;
@@ -191,8 +155,6 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
           v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
         }
         *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
-        gs[j] += (v0 + v1) + (v2 + v3);
-        gq[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
         continue;
       }
       if (g.res != nullptr) {
@@ -206,8 +168,6 @@ __global__ void __launch_bounds__(256) conv3x3_kernel(ConvArgs g) {
       *(u32x2*)(g.out + o) = p;
     }
   }
-  if (g.gn_partial != nullptr && g.out32 != nullptr)   // this wave: 64 pixels (one slab) x 64 channels
-    gn_emit<4>(g, gs, gq, lane, n0 + wn * 64, m0 / g.gn_hw, ((m0 % g.gn_hw) >> 7) * 2 + wm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,11 +319,6 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
 
   // lane holds out[pixel m = .. + (lane & 15)][co = .. + (lane >> 4) * 4 + {0..3}]  (the plain kernel's epilogue)
   const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
-  // GroupNorm partials in 64-PIXEL slabs (rows i < 4 | i >= 4 of the wave's 128), summed per lane in the plain kernel's order: the
-  // two kernels then leave the same bits, and a frame decoded alone (few tiles: plain kernel) equals the frame inside a batch
-  float gs[FN], gq[FN], gs2[FN], gq2[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) gs[j] = gq[j] = gs2[j] = gq2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + grp * 128 + i * 16 + frow;
@@ -380,13 +335,6 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
           v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
         }
         *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
-        if (i < 4) {
-          gs[j] += (v0 + v1) + (v2 + v3);
-          gq[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        } else {
-          gs2[j] += (v0 + v1) + (v2 + v3);
-          gq2[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        }
         continue;
       }
       if (g.res != nullptr) {
@@ -399,11 +347,6 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
       const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
       *(u32x2*)(g.out + o) = p;
     }
-  }
-  if (g.gn_partial != nullptr && g.out32 != nullptr) {   // this wave: 128 pixels (two 64-pixel slabs) x WTN channels
-    const int slab0 = ((m0 % g.gn_hw) >> 6) + grp * 2;
-    gn_emit<FN>(g, gs, gq, lane, n0 + wn * WTN, m0 / g.gn_hw, slab0);
-    gn_emit<FN>(g, gs2, gq2, lane, n0 + wn * WTN, m0 / g.gn_hw, slab0 + 1);
   }
 }
 
@@ -886,12 +829,11 @@ inline int grid_for(size_t n, int block) {
 
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
                    const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
-                   const float* res32, float* out32, int taps3, float* gn_partial, int* gn_slabs_out) {
+                   const float* res32, float* out32, int taps3) {
   if (Cin % 64 != 0 || Cout % 128 != 0) return fail(LATTE_ERR_INVALID, "conv3x3: need Cin % 64 == 0 and Cout % 128 == 0");
   if (!out && !out32) return fail(LATTE_ERR_INVALID, "conv3x3: no output");
   if (taps3 && ups) return fail(LATTE_ERR_INVALID, "conv3x3: the 3-tap form has no upsampling");
-  ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups, nullptr, 0, 0, 0, taps3};
-  if (gn_slabs_out) *gn_slabs_out = 0;
+  ConvArgs a{in, w, bias, res, out, res32, out32, zeros, N, Hin, Win, Cin, Cout, ups, taps3};
   const int M = N * (Hin << ups) * (Win << ups);
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv3x3: the VAE kernels are built for f16 operands only");
   // the ping-pong kernel (256 pixels x 128 | 256 channels) wherever its tiles fill the chip; small maps keep the 128 x 128 tile
@@ -901,17 +843,7 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   // its gather addresses the input through 32-bit buffer offsets and, with the upsample, packs (y, x) into 16 bits each
   const bool pp_ok = (uint64_t)N * Hin * Win * Cin * 2 < (1ull << 32) && (uint64_t)Cout * 9 * Cin * 2 < (1ull << 32) &&
                      (!ups || ((Hin << ups) < 32768 && (Win << ups) < 65536));
-  const int HWo = (Hin << ups) * (Win << ups);
-  auto want_gn = [&](int px_per_wave) -> bool {   // whole wave tiles inside a frame, the partial buffer's slab bound, 4 | 8 | 16 channels per group
-    const int cpg = Cout / 32;
-    if (!gn_partial || !out32 || !gn_slabs_out || taps3 || (cpg != 4 && cpg != 8 && cpg != 16)) return false;
-    if (HWo % 256 != 0 || HWo / px_per_wave > groupnorm_max_slabs()) return false;   // whole tiles of either kernel inside a frame
-    a.gn_partial = gn_partial; a.gn_slabs = HWo / px_per_wave; a.gn_cpg = cpg; a.gn_hw = HWo;
-    *gn_slabs_out = a.gn_slabs;
-    return true;
-  };
   if (pp_ok && debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
-    want_gn(64);   // 64-pixel slabs in both kernels
     if (bn == 256) {
       constexpr int LDS_PP = 2 * (256 + 256) * 128;
       static std::atomic<uint64_t> attr_a{0};
@@ -929,7 +861,6 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   }
   const int tiles = ((M + 127) / 128) * (Cout / 128);
   constexpr int LDS = 2 * 256 * 128;
-  want_gn(64);
   static std::atomic<uint64_t> attr_f16{0};
   if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_kernel<LATTE_DTYPE_F16>, LDS, attr_f16)) return rc_;
   hipLaunchKernelGGL(conv3x3_kernel<LATTE_DTYPE_F16>, dim3(tiles), dim3(256), LDS, st, a);
@@ -939,15 +870,14 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
 }
 
 int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma, const float* beta, float* partial, float* stats,
-                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps, int max_slabs, half_t* y_lo, int ready_slabs) {
+                     int N, int HW, int C, int silu, int dtype, hipStream_t st, float eps, int max_slabs, half_t* y_lo) {
   if (C != 128 && C != 256 && C != 512) return fail(LATTE_ERR_INVALID, "groupnorm: C must be 128, 256 or 512");
   int slabs = HW / 256;   // >= 256 pixels per slab (round 3: 1024 -- the 64 x 64 and 128 x 128 maps then had 64 / 256 workgroups for 256 CUs)
   if (slabs < 1) slabs = 1;
   if (slabs > max_slabs) slabs = max_slabs;
   const size_t total_oct = (size_t)N * HW * C / 8;
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "groupnorm: the VAE kernels are built for f16 operands only");
-  if (ready_slabs > 0) slabs = ready_slabs;   // the producing convolution's epilogue wrote the partials (ConvArgs::gn_partial)
-  else if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
+  if (x_is_f32) hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, true>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   else hipLaunchKernelGGL((gn_partial_kernel<LATTE_DTYPE_F16, false>), dim3(slabs, N), dim3(256), 0, st, x, partial, HW, C, slabs);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, st, partial, stats, slabs, (float)HW * (float)(C / 32), eps);
   kprof_mark(VC_GN_STATS, st);
@@ -960,7 +890,7 @@ int launch_groupnorm(const void* x, int x_is_f32, half_t* y, const float* gamma,
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
-int groupnorm_max_slabs() { return 1024; }   // 64-pixel slabs of a 256 x 256 map   // (round 3: 64 -- 1024 workgroups on the largest map, 64 iterations of one load each per thread)
+int groupnorm_max_slabs() { return 256; }   // (round 3: 64 -- 1024 workgroups on the largest map, 64 iterations of one load each per thread)
 
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st) {
   hipLaunchKernelGGL(post_quant_kernel, dim3(grid_for((size_t)N * hw, 256)), dim3(256), 0, st, z, w, b, out, N, hw, z_scale);

@@ -84,10 +84,6 @@ struct latte_vae {
   float* ones;         // [512] gate vector of ones (attention out-projection through the gated fp32 residual epilogue)
   half_t* zeros;
   float *pq_out, *scores, *gn_partial, *gn_stats, *stage;
-  // GroupNorm statistics handed over by the convolution that produced a tensor (round 4, vae.hip: ConvArgs::gn_partial): slabs per
-  // frame sitting in gn_partial for the tensor at gn_ready_ptr, 0 = none.  Consumed (or dropped) by the next GroupNorm call.
-  int gn_ready = 0;
-  const void* gn_ready_ptr = nullptr;
   int64_t stage_numel = 0;
   bool bias_folded = false;
   // AutoencoderKLTemporalDecoder mode (latte_vae_create_temporal): every resnet is a SpatioTemporalResBlock, no
@@ -172,26 +168,6 @@ int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, con
   return rc_;
 }
 
-// GroupNorm of the fp32 tensor x: the statistics pass is skipped when the convolution that wrote x left its partial sums behind
-int gn_stream(latte_vae* v, const float* x, half_t* y, const float* gamma, const float* beta, int N, int HW, int C, int silu, hipStream_t st,
-              float eps = 1e-6f, half_t* y_lo = nullptr) {
-  const int ready = (v->gn_ready > 0 && v->gn_ready_ptr == (const void*)x) ? v->gn_ready : 0;
-  v->gn_ready = 0;
-  v->gn_ready_ptr = nullptr;
-  return launch_groupnorm(x, 1, y, gamma, beta, v->gn_partial, v->gn_stats, N, HW, C, silu, v->dtype, st, eps, groupnorm_max_slabs(), y_lo, ready);
-}
-// a 3x3 convolution into the fp32 tensor out32 (+ res32) that also leaves the GroupNorm partials of its output (SD-VAE mode only: the
-// temporal decoder's split-operand passes finish a tensor in two or three launches)
-int conv_stream(latte_vae* v, const half_t* in, const half_t* w, const float* bias, int N, int H, int W, int Cin, int Cout, int ups,
-                hipStream_t st, const float* res32, float* out32) {
-  int slabs = 0;
-  const int rc = launch_conv3x3(in, w, bias, nullptr, nullptr, v->zeros, N, H, W, Cin, Cout, ups, v->dtype, st, res32, out32, 0,
-                                v->temporal ? nullptr : v->gn_partial, v->temporal ? nullptr : &slabs);
-  v->gn_ready = slabs;
-  v->gn_ready_ptr = slabs > 0 ? (const void*)out32 : nullptr;
-  return rc;
-}
-
 // ResnetBlock2D on the fp32 stream: x = *s -> *s (in place when cin == cout, else through *s2 and the two are swapped);
 // b, c, d: half scratch.  [N, H, W, C]
 int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, half_t* c, half_t* d, int N, int H, int W,
@@ -202,21 +178,21 @@ int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, 
   // temporal-decoder mode: the activation operand of both 3x3 convolutions is split hi + lo (b = the f16 rounding residual of the
   // GroupNorm output) and a second pass adds conv(lo): the decoder with twice as many blocks per stage stays under the 1e-3 bar
   half_t* lo = v->temporal ? b : nullptr;
-  if ((rc = gn_stream(v, x, c, r.n1w, r.n1b, N, HW, r.cin, 1, st, 1e-6f, lo))) return rc;
-  if ((rc = conv_stream(v, c, r.c1w, r.c1b, N, H, W, r.cin, r.cout, 0, st, nullptr, v->tbuf))) return rc;
+  if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
+  if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, nullptr, v->tbuf))) return rc;
   if (lo && (rc = launch_conv3x3(lo, r.c1w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, v->tbuf, v->tbuf))) return rc;
-  if ((rc = gn_stream(v, v->tbuf, c, r.n2w, r.n2b, N, HW, r.cout, 1, st, 1e-6f, lo))) return rc;
+  if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
   if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
     float* y = *s2;
     if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
     kprof_mark(VC_SMALL, st);
     if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
-    if ((rc = conv_stream(v, c, r.c2w, r.c2b, N, H, W, r.cout, r.cout, 0, st, y, y))) return rc;
+    if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     if (lo && (rc = launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     std::swap(*s, *s2);
     return LATTE_OK;
   }
-  if ((rc = conv_stream(v, c, r.c2w, r.c2b, N, H, W, r.cout, r.cout, 0, st, x, x))) return rc;
+  if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x))) return rc;
   if (lo) return launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
   return LATTE_OK;
 }
@@ -460,8 +436,6 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   hipStream_t st = (hipStream_t)stream;
   const int N = n_frames, dt = v->dtype, top = v->ch[3];
   int H = v->h, W = v->h;
-  v->gn_ready = 0;            // nothing is handed over between decodes (a traced decode stops right behind a convolution)
-  v->gn_ready_ptr = nullptr;
   if (!v->bias_folded) {
     // softmax rows sum to 1, so  to_out(P (V0 + 1 bv^T)) = to_out(P V0) + (Wo bv + bo): the value bias is folded into
     // the output bias and V^T is produced directly by a GEMM (no transpose kernel)
@@ -499,7 +473,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   {  // mid-block attention: 1 head, dim 512, tokens = H*W per frame
     const int L = H * W;
     if (L % 128 != 0) return fail(LATTE_ERR_INVALID, "vae_decode: H*W must be a multiple of 128 for the attention GEMMs");
-    if ((rc = gn_stream(v, a, c, v->agn_w, v->agn_b, N, L, top, 0, st))) return rc;
+    if ((rc = launch_groupnorm(a, 1, c, v->agn_w, v->agn_b, v->gn_partial, v->gn_stats, N, L, top, 0, dt, st))) return rc;
     if ((rc = gemm_h16(c, v->aq_w, v->aq_b, b, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // q  [N L, 512]
     if ((rc = gemm_h16(c, v->ak_w, v->ak_b, d, nullptr, N * L, top, top, EPI_BIAS_H16, dt, st))) return rc;   // k  [N L, 512]
     half_t* vt = b + (size_t)N * L * top;   // V0^T per frame [512, L], behind q in buffer b
@@ -537,7 +511,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
       const int cch = v->ch[3 - i];
       if ((rc = launch_convert_f32_to_h16(a, d, (int64_t)N * H * W * cch, dt, st))) return rc;
       kprof_mark(VC_SMALL, st);
-      if ((rc = conv_stream(v, d, v->upc_w[i], v->upc_b[i], N, H, W, cch, cch, 1, st, nullptr, a2))) return rc;
+      if ((rc = launch_conv3x3(d, v->upc_w[i], v->upc_b[i], nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, nullptr, a2))) return rc;
       std::swap(a, a2);
       H *= 2;
       W *= 2;
@@ -545,7 +519,7 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     }
   }
   if (stop_after >= 0) return fail(LATTE_ERR_INVALID, "vae_trace: stage index beyond the last traced stage");
-  if ((rc = gn_stream(v, a, c, v->no_w, v->no_b, N, H * W, v->ch[0], 1, st))) return rc;
+  if ((rc = launch_groupnorm(a, 1, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
   if (!v->temporal) return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
   // conv_out to fp32 NCHW frames, then time_conv_out over the frames of the chunk
   if ((rc = launch_conv_out(c, v->co_w, v->co_b, v->tbuf, N, H, W, v->ch[0], 0, dt, st))) return rc;
