@@ -614,7 +614,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   }
   if (k == "fuse_qkv_attn") {
     if (value < 0 || value > 31)
-      return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-3 = schedule variant (0..31)");
+      return fail(LATTE_ERR_INVALID, "fuse_qkv_attn: bit 0 = spatial blocks, bit 1 = temporal blocks, bits 2-4 = schedule features off (0..31)");
     e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }

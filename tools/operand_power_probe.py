@@ -1,0 +1,128 @@
+"""Is the GEMM rate bound by the kernel's schedule or by the chip's power cap?  The same launches of the model's fc1 / fc2 / proj
+shapes are timed on operands that toggle the MFMA data paths differently (random values, half of them zero, constants, zeros) in
+both operand types, with rocm-smi power / shader clock sampled from a thread.  A schedule-bound kernel runs every pattern at the
+same rate; a power-bound one speeds up as the data gets quieter.  Measurement only (profiles/r4_operand_power_probe.log)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from latte_amd._lib import check, load_library, ptr, stream_ptr  # noqa: E402
+
+lib = load_library()
+samples = []
+stop = False
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.2
+
+
+def sampler():
+    while not stop:
+        try:
+            r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
+            samples.append((time.time(), r.stdout.strip()))
+        except Exception as ex:  # noqa: BLE001
+            samples.append((time.time(), "ERR " + str(ex)))
+        time.sleep(0.1)
+
+
+def smi_between(a, b):
+    power, sclk = [], []
+    for t, s in samples:
+        if not (a + 0.3 <= t <= b):
+            continue
+        try:
+            j = json.loads(s)
+            c = j[next(iter(j))]
+        except Exception:  # noqa: BLE001
+            continue
+        for k, v in c.items():
+            kl = k.lower()
+            try:
+                if "power" in kl:
+                    power.append(float(str(v).split()[0]))
+                elif "sclk" in kl and "clock speed" in kl:
+                    sclk.append(float(str(v).strip("()MmHhZz ")))
+            except ValueError:
+                pass
+    mean = lambda v: sum(v) / len(v) if v else float("nan")  # noqa: E731
+    return mean(power), mean(sclk), len(power)
+
+
+def operands(pattern, M, N, K, tdt, g):
+    Mp = (M + 255) // 256 * 256
+    if pattern == "random":
+        A = torch.randn(Mp, K, generator=g, device="cuda")
+        W = torch.randn(N, K, generator=g, device="cuda") / K ** 0.5
+    elif pattern == "half_zero":          # what a GELU output looks like: half of the activations (almost) zero
+        A = torch.randn(Mp, K, generator=g, device="cuda").clamp_min(0.0)
+        W = torch.randn(N, K, generator=g, device="cuda") / K ** 0.5
+    elif pattern == "random_x_zero_w":    # operand A toggles, every product is zero
+        A = torch.randn(Mp, K, generator=g, device="cuda")
+        W = torch.zeros(N, K, device="cuda")
+    elif pattern == "constant":           # non-zero, no toggling between consecutive operands
+        A = torch.ones(Mp, K, device="cuda")
+        W = torch.full((N, K), 1.0 / K, device="cuda")
+    elif pattern == "zeros":
+        A = torch.zeros(Mp, K, device="cuda")
+        W = torch.zeros(N, K, device="cuda")
+    else:
+        raise ValueError(pattern)
+    return A.to(tdt), W.to(tdt)
+
+
+def main():
+    global stop
+    torch.zeros(1, device="cuda")
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    time.sleep(0.5)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [("fc2", 32768, 1152, 4608, 2), ("fc1", 32768, 4608, 1152, 1), ("proj", 32768, 1152, 1152, 2)]
+    rows = []
+    for dt_name, dt, tdt in (("f16", 1, torch.float16), ("bf16", 0, torch.bfloat16)):
+        for name, M, N, K, epi in shapes:
+            Mp = (M + 255) // 256 * 256
+            bias = torch.zeros(N, device="cuda")
+            gate = torch.full((N,), 1e-3, device="cuda")
+            for pattern in ("random", "half_zero", "random_x_zero_w", "constant", "zeros"):
+                A, W = operands(pattern, M, N, K, tdt, g)
+                out = torch.zeros(Mp, N, device="cuda", dtype=torch.float32 if epi >= 2 else tdt)
+
+                def launch(n):
+                    for _ in range(n):
+                        check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(out), ptr(gate), M, N, K, 0, M, epi, dt, 0,
+                                                   stream_ptr()))
+                launch(20)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.time()
+                n_total = 0
+                e0.record()
+                while time.time() - t0 < SECONDS:
+                    launch(200)
+                    n_total += 200
+                    torch.cuda.synchronize()
+                e1.record()
+                torch.cuda.synchronize()
+                t1 = time.time()
+                us = e0.elapsed_time(e1) * 1e3 / n_total
+                tf = 2.0 * M * N * K / us * 1e-6
+                p, clk, ns = smi_between(t0, t1)
+                rows.append(dict(dtype=dt_name, gemm=name, pattern=pattern, us_per_launch=round(us, 1), tflops=round(tf, 1),
+                                 frac_of_2500=round(tf / 2500.0, 3), power_w=round(p, 0), sclk_mhz=round(clk, 0), smi_samples=ns))
+                print(json.dumps(rows[-1]), flush=True)
+                del A, W, out
+    stop = True
+    th.join(timeout=10)
+    if samples:
+        print("last rocm-smi sample:", samples[-1][1][:400])
+
+
+if __name__ == "__main__":
+    main()
