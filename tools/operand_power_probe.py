@@ -19,6 +19,7 @@ lib = load_library()
 samples = []
 stop = False
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.2
+PART = sys.argv[2] if len(sys.argv) > 2 else "gemm"      # gemm | fused (fused QKV + attention kernel, whole forward)
 
 
 def sampler():
@@ -76,12 +77,83 @@ def operands(pattern, M, N, K, tdt, g):
     return A.to(tdt), W.to(tdt)
 
 
+def timed(launch, per_round, flops, tag):
+    launch(10)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    n_total = 0
+    e0.record()
+    while time.time() - t0 < SECONDS:
+        launch(per_round)
+        n_total += per_round
+        torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    us = e0.elapsed_time(e1) * 1e3 / n_total
+    tf = flops / us * 1e-6
+    p, clk, ns = smi_between(t0, t1)
+    row = dict(tag, us_per_launch=round(us, 1), tflops=round(tf, 1), frac_of_2500=round(tf / 2500.0, 3), power_w=round(p, 0),
+               sclk_mhz=round(clk, 0), smi_samples=ns)
+    print(json.dumps(row), flush=True)
+
+
+def fused_part():
+    """The fused QKV + attention kernel on quiet / random operands, and the XL/2 forward at B = 8 with the power sampled."""
+    import latte_amd
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, F, T, D, H = 8, 16, 256, 1152, 16
+    M = B * F * T
+    for dt_name, dt, tdt in (("f16", 1, torch.float16), ("bf16", 0, torch.bfloat16)):
+        for pattern in ("random", "zeros"):
+            if pattern == "random":
+                xn = torch.randn(M, D, generator=g, device="cuda").to(tdt)
+                W = (torch.randn(3 * D, D, generator=g, device="cuda") / D ** 0.5).to(tdt)
+            else:
+                xn = torch.zeros(M, D, device="cuda", dtype=tdt)
+                W = torch.zeros(3 * D, D, device="cuda", dtype=tdt)
+            bias = torch.zeros(3 * D, device="cuda")
+            out = torch.zeros(M, D, device="cuda", dtype=tdt)
+            for mode in (0, 1):
+                L = T if mode == 0 else F
+                flops = 2.0 * M * D * 3 * D + 4.0 * M * L * D
+
+                def launch(n):
+                    for _ in range(n):
+                        check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(out), None, B, F, T, D, H, mode, 7, dt,
+                                                            stream_ptr()))
+                timed(launch, 200, flops, dict(dtype=dt_name, kernel="qkv_attn_" + ("spatial" if mode == 0 else "temporal"),
+                                               pattern=pattern))
+    for dt_name in ("f16", "bf16"):
+        m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=1, compute_dtype=dt_name, max_batch=B)
+        gc = torch.Generator("cpu").manual_seed(1)
+        with torch.no_grad():
+            for _, p in m.named_parameters():
+                if p.requires_grad and float(p.detach().abs().max()) == 0.0:
+                    p.copy_(torch.randn(p.shape, generator=gc) * 0.02)
+        m = m.to("cuda").eval()
+        x = torch.randn(B, 16, 4, 32, 32, device="cuda")
+        t = torch.full((B,), 500, device="cuda", dtype=torch.int64)
+
+        def fwd(n):
+            for _ in range(n):
+                m(x, t)
+        timed(fwd, 10, B * 3.726e12, dict(dtype=dt_name, kernel="XL/2 forward B=8 (whole model, random latents and weights)"))
+        del m
+
+
 def main():
     global stop
     torch.zeros(1, device="cuda")
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
     time.sleep(0.5)
+    if PART == "fused":
+        fused_part()
+        stop = True
+        th.join(timeout=10)
+        return
     g = torch.Generator(device="cuda").manual_seed(0)
     shapes = [("fc2", 32768, 1152, 4608, 2), ("fc1", 32768, 4608, 1152, 1), ("proj", 32768, 1152, 1152, 2)]
     rows = []
