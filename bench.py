@@ -33,6 +33,9 @@ Beside the headline, in the same JSON line:
     algorithmic TFLOP/s (3 x forward FLOPs);
   * `config4` (N = 1): BASELINE config 4 -- Latte-1 text-to-video 512x512x16: one guided DDIM step of LatteT2V inside the
     engine and the 16-frame AutoencoderKLTemporalDecoder decode, random weights of the real shapes;
+  * `power_check` (N = 1): socket power and shader clock (rocm-smi) during ~1.5 s of the headline forward, and the dominant GEMM
+    stand-alone on random and on all-zero operands -- on random operands the 1400 W socket cap throttles the MFMA kernels to
+    ~1.7-1.9 GHz (of 2.4); on quiet operands the same launches keep the full clock (profiles/r4_operand_power_probe_*.log);
   * `cpu_baseline` (N = 1): the oracle's sampling-loop body (forward + ddim_sample) on the host cores, standing in for the reference's
     loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
     than it because it skips the reference's repeated adaLN rows: oracle/VALIDATION.md).
@@ -272,6 +275,99 @@ def vae_decoder_work(h):
             fl += conv3(H, c, c)
     gn_in += gn(H, 128)                      # conv_norm_out
     return fl, gn_in, gn_in + gn_in // 2
+
+
+def power_check(device, model, x, dtype):
+    """Is the step bound by the kernels' schedule or by the socket's power cap?  (tools/operand_power_probe.py is the full table,
+    profiles/r4_operand_power_probe_*.log.)  Two short legs outside the timed region: (1) ~1.5 s of the headline forward with
+    rocm-smi's socket power and shader clock sampled from a thread; (2) the dominant GEMM (fc2: 32768 x 1152 x 4608, gated
+    read-modify-write epilogue) stand-alone on random operands and on all-zero operands -- the same instruction stream and the same
+    bytes, but nothing toggles in the MFMA data paths, so the chip keeps its full clock: that rate is what the kernel's schedule
+    reaches when the 1400 W cap does not throttle it."""
+    import subprocess
+    import threading
+    from latte_amd._lib import check, load_library, ptr, stream_ptr
+    lib = load_library()
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
+                samples.append((time.time(), r.stdout))
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.1)
+
+    def smi_mean(a, b):
+        pw, ck = [], []
+        for ts, txt in samples:
+            if not (a + 0.3 <= ts <= b):
+                continue
+            try:
+                card = next(iter(json.loads(txt).values()))
+            except Exception:  # noqa: BLE001
+                continue
+            for k, v in card.items():
+                try:
+                    if "power" in k.lower():
+                        pw.append(float(str(v).split()[0]))
+                    elif "sclk" in k.lower() and "speed" in k.lower():
+                        ck.append(float(str(v).strip("()MmHhZz ")))
+                except ValueError:
+                    pass
+        return (round(sum(pw) / len(pw), 0) if pw else None), (round(sum(ck) / len(ck), 0) if ck else None), len(pw)
+
+    def spin(launch, seconds, per_round):
+        launch(per_round)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, n = time.time(), 0
+        e0.record()
+        while time.time() - t0 < seconds:
+            launch(per_round)
+            n += per_round
+            torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, t0, time.time()
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    out = {"socket_power_cap_w": 1400, "shader_clock_max_mhz": 2400}
+    try:
+        t = torch.full((x.shape[0],), 500, device=device, dtype=torch.int64)
+        ms, a, b = spin(lambda n: [model(x, t) for _ in range(n)], 1.5, 5)
+        pw, ck, ns = smi_mean(a, b)
+        out["forward"] = {"ms": round(ms, 3), "socket_power_w": pw, "shader_clock_mhz": ck, "rocm_smi_samples": ns}
+        M, N, K = 32768, 1152, 4608
+        tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+        bias = torch.zeros(N, device=device)
+        gate = torch.full((N,), 1e-3, device=device)
+        res = torch.zeros(M, N, device=device)
+        for pattern in ("random", "zeros"):
+            if pattern == "random":
+                A = torch.randn(M, K, device=device).to(tdt)
+                W = (torch.randn(N, K, device=device) / K ** 0.5).to(tdt)
+            else:
+                A = torch.zeros(M, K, device=device, dtype=tdt)
+                W = torch.zeros(N, K, device=device, dtype=tdt)
+
+            def launch(n):
+                for _ in range(n):
+                    check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(res), ptr(gate), M, N, K, 0, M, 2, 1 if dtype == "f16" else 0,
+                                               0, stream_ptr()))
+            ms, a, b = spin(launch, 1.0, 200)
+            pw, ck, ns = smi_mean(a, b)
+            tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+            out["fc2_standalone_" + pattern + "_operands"] = {"avg_launch_ms": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                                                               "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "socket_power_w": pw,
+                                                               "shader_clock_mhz": ck}
+            del A, W
+    finally:
+        stop[0] = True
+        th.join(timeout=10)
+    return out
 
 
 def vae_decode_rate(device):
@@ -617,6 +713,12 @@ def main():
                           "ms_per_step": round(v["ms_per_step"], 4), "steps": v["steps"]}
                 if "batch" in v:
                     res[k]["per_gpu_batch"] = v["batch"]
+        if world == 1 and not args.no_side:
+            note('power check (socket power / shader clock in the forward; dominant GEMM on quiet operands)')
+            try:
+                res["power_check"] = power_check(device, model, x, args.dtype)
+            except Exception as ex:  # noqa: BLE001  (rocm-smi absent or unreadable: the line must still print)
+                res["power_check"] = {"error": repr(ex)[:200]}
         if world == 1 and not args.no_vae:
             res["vae_decode"] = vae_decode_rate(device)
         if world == 1 and not args.no_side:
