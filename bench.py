@@ -277,6 +277,25 @@ def vae_decoder_work(h):
     return fl, gn_in, gn_in + gn_in // 2
 
 
+def parse_rocm_smi(txt):
+    """(socket power in W, shader clock in MHz) of the first card in `rocm-smi -c -P --json` output; None for what is not there."""
+    try:
+        card = next(iter(json.loads(txt).values()))
+    except Exception:  # noqa: BLE001
+        return None, None
+    power = clock = None
+    for k, v in card.items():
+        kl = k.lower()
+        try:
+            if "power" in kl and power is None:
+                power = float(str(v).split()[0])
+            elif "sclk" in kl and "speed" in kl:
+                clock = float(str(v).strip("()MmHhZz "))
+        except (ValueError, IndexError):
+            pass
+    return power, clock
+
+
 def power_check(device, model, x, dtype):
     """Is the step bound by the kernels' schedule or by the socket's power cap?  (tools/operand_power_probe.py is the full table,
     profiles/r4_operand_power_probe_*.log.)  Two short legs outside the timed region: (1) ~1.5 s of the headline forward with
@@ -302,20 +321,12 @@ def power_check(device, model, x, dtype):
     def smi_mean(a, b):
         pw, ck = [], []
         for ts, txt in samples:
-            if not (a + 0.3 <= ts <= b):
-                continue
-            try:
-                card = next(iter(json.loads(txt).values()))
-            except Exception:  # noqa: BLE001
-                continue
-            for k, v in card.items():
-                try:
-                    if "power" in k.lower():
-                        pw.append(float(str(v).split()[0]))
-                    elif "sclk" in k.lower() and "speed" in k.lower():
-                        ck.append(float(str(v).strip("()MmHhZz ")))
-                except ValueError:
-                    pass
+            if a + 0.3 <= ts <= b:
+                p_w, c_mhz = parse_rocm_smi(txt)
+                if p_w is not None:
+                    pw.append(p_w)
+                if c_mhz is not None:
+                    ck.append(c_mhz)
         return (round(sum(pw) / len(pw), 0) if pw else None), (round(sum(ck) / len(ck), 0) if ck else None), len(pw)
 
     def spin(launch, seconds, per_round):

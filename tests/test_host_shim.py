@@ -186,3 +186,19 @@ def test_oracle_is_only_imported_by_the_checkers():
         assert oracle_imports(path) == [], path
     assert set(oracle_imports(os.path.join(root, "bench.py"))) <= {"cpu_baseline"}
     assert set(oracle_imports(os.path.join(root, "__graft_entry__.py"))) <= {"smoke"}
+
+
+def test_bench_reads_power_and_clock_from_rocm_smi_json():
+    """bench.py's power_check samples `rocm-smi -c -P --json`; the text below is what the tool prints on the GPU boxes of the pool
+    (profiles/r4_operand_power_probe_gemm.log, last line).  Unreadable output must give (None, None), never an exception."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    txt = ('{"card0": {"fclk clock speed:": "(1250Mhz)", "fclk clock level:": "0", "mclk clock speed:": "(2000Mhz)", '
+           '"mclk clock level:": "0", "sclk clock speed:": "(2403Mhz)", "sclk clock level:": "1", "socclk clock speed:": "(73Mhz)", '
+           '"socclk clock level:": "S", "Current Socket Graphics Package Power (W)": "771.0"}}')
+    assert bench.parse_rocm_smi(txt) == (771.0, 2403.0)
+    assert bench.parse_rocm_smi("") == (None, None)
+    assert bench.parse_rocm_smi('{"card0": {"sclk clock speed:": "n/a"}}') == (None, None)
