@@ -19,7 +19,7 @@ lib = load_library()
 samples = []
 stop = False
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.2
-PART = sys.argv[2] if len(sys.argv) > 2 else "gemm"      # gemm | fused (fused QKV + attention kernel, whole forward)
+PART = sys.argv[2] if len(sys.argv) > 2 else "gemm"      # gemm | fused (fused QKV + attention kernel, whole forward) | side (small batches, VAE)
 
 
 def sampler():
@@ -143,14 +143,50 @@ def fused_part():
         del m
 
 
+def side_part():
+    """Which of the side paths run into the power cap?  XL/2 forward at B = 1 / 2 / 4 (with the per-class table of the B = 1 forward),
+    the SD-VAE decode of a 16-frame video and the convolution class alone."""
+    import latte_amd
+    from latte_amd.random_init import vae_decoder_state_dict
+    for B in (1, 2, 4):
+        m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=1, max_batch=B)
+        gc = torch.Generator("cpu").manual_seed(1)
+        with torch.no_grad():
+            for _, p in m.named_parameters():
+                if p.requires_grad and float(p.detach().abs().max()) == 0.0:
+                    p.copy_(torch.randn(p.shape, generator=gc) * 0.02)
+        m = m.to("cuda").eval()
+        x = torch.randn(B, 16, 4, 32, 32, device="cuda")
+        t = torch.full((B,), 500, device="cuda", dtype=torch.int64)
+
+        def fwd(n):
+            for _ in range(n):
+                m(x, t)
+        timed(fwd, 20, B * 3.726e12, dict(dtype=m.operand_dtype(), kernel=f"XL/2 forward B={B}"))
+        if B == 1:
+            m.profile_forward(x, t)
+            prof = m.profile_forward(x, t)
+            print(json.dumps({"B=1 per class: ms per forward, launches": {k: (round(v[0], 4), v[1]) for k, v in prof.items() if v[1]}}), flush=True)
+        del m
+    vae = latte_amd.AutoencoderKL(latent_size=32, max_frames=16)
+    vae.load_state_dict(vae_decoder_state_dict(0))
+    vae.to("cuda")
+    lat = torch.randn(1, 16, 4, 32, 32, device="cuda") * 0.18215
+
+    def dec(n):
+        for _ in range(n):
+            vae.decode_video_uint8(lat)
+    timed(dec, 5, 9.741e12, dict(dtype="f16", kernel="SD-VAE decode, 16 frames 256x256 (9.74 TFLOP of convolutions per video)"))
+
+
 def main():
     global stop
     torch.zeros(1, device="cuda")
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
     time.sleep(0.5)
-    if PART == "fused":
-        fused_part()
+    if PART in ("fused", "side"):
+        fused_part() if PART == "fused" else side_part()
         stop = True
         th.join(timeout=10)
         return
