@@ -1069,6 +1069,257 @@ int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
   return LATTE_OK;
 }
 
+#ifdef LATTE_GEMM_ABLATE
+// ------------------------------------------------------------------------------------------------
+// Measurement build only (variant 14): ONE MFMA wave per SIMD.  256 x 256 tile, four waves (2 x 2, wave tile 128 x 128:
+// 64 accumulator fragments = the 256 AGPRs, two fragment sets of 16 ds_read_b128 = 128 VGPRs), persistent over the same
+// XCD-chunked tile order as the ping-pong kernel, K tiles of 64 in two 64 KB LDS stages.  Per K tile and wave:
+//     A: MFMAs of the first half (fragment set 0)   ||  ds_reads of set 1
+//     lgkmcnt(0), own DMA of K tile t + 1 landed, ONE barrier (everybody done reading stage t & 1, everybody's t + 1 landed)
+//     B: MFMAs of the second half (set 1)           ||  DMA of K tile t + 2 into stage t & 1  ||  ds_reads of set 0 of K tile t + 1
+// The (tile, K tile) sequence is flat: the first two K tiles of the next output tile are in flight / landed when a tile's
+// epilogue starts, and the epilogue's stores are issued AFTER that DMA, so the first barrier of the next tile waits with a
+// counted vmcnt (the stores) instead of draining them.  DESIGN.md section 8: the question is whether a lone wave with a full
+// register file covers its own LDS latency, which the 168-register waves of the 12-wave kernel do not.
+template <int EPI, int DT>
+__global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
+  constexpr int BM = 256, BN = 256, NW = 4, FM = 8, FN = 8;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr bool LDS_EPI = EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16;
+  constexpr int EPI_STORES = LDS_EPI ? 32 : 0;   // global store instructions of one epilogue (LDS_EPI form)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int K = g.K, nk = K / 64;
+  const unsigned row_bytes = (unsigned)K * 2u;
+
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN, nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  const int group_m = g.group_m > 0 ? g.group_m : 8;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)tiles_m * BM * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)g.N * row_bytes, 0x00020000);
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const unsigned off_lane = (unsigned)lrow * row_bytes + (unsigned)((cpos ^ (((wave * 8 + lrow) >> 1) & 7)) * 16);
+  unsigned step32 = 32u * row_bytes;
+  asm volatile("" : "+s"(step32));
+  // K tile kt of output tile (tm_, tn_) into stage stg: row-groups wave + 4 j of A and of W, 16 one-KB pieces per wave
+  auto dma = [&](int tm_, int tn_, int kt, int stg) __attribute__((always_inline)) {
+    char* sA = smem + stg * STAGE + wave * 1024;
+    const unsigned soA = (unsigned)(tm_ * BM + wave * 8) * row_bytes + (unsigned)kt * 128u;
+    const unsigned soB = (unsigned)(tn_ * BN + wave * 8) * row_bytes + (unsigned)kt * 128u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bload_lds16(rsA, sA + j * NW * 1024, off_lane, soA + (unsigned)j * step32);
+      bload_lds16(rsB, sA + A_BYTES + j * NW * 1024, off_lane, soB + (unsigned)j * step32);
+    }
+  };
+  const int sw = (lane >> 1) & 7;
+  const int chunkb = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (wm * 128 + (lane & 15)) * 128 + chunkb;
+  const int b_off = A_BYTES + (wn * 128 + (lane & 15)) * 128 + chunkb;
+  u32x4 fa[2][FM], fb[2][FN];
+  auto read_set = [&](int set, int stg, int ks) __attribute__((always_inline)) {
+    const char* sbuf = smem + stg * STAGE;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) fa[set][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[set][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma_set = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(fb[set][j], fa[set][i], acc[i][j]);
+  };
+
+  // the bias of the wave's 128 columns goes global -> LDS by one DMA piece (1 KB: the 128 floats + the next 128, unused) into a
+  // wave-private slot, double-buffered by tile parity, issued BEFORE the operand DMA of the tile's last K step: no register
+  // holds it through the K loop and no load sits behind the DMA in the in-order vmcnt queue when the epilogue starts
+  const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, (unsigned)g.N * 4u, 0x00020000);
+  char* const bias_lds = smem + 2 * STAGE + NW * 4096 + wave * 2048;
+  auto dma_bias = [&](int tn_, int par) __attribute__((always_inline)) {
+    bload_lds16(rsBias, bias_lds + par * 1024, (unsigned)lane * 16u, (unsigned)(tn_ * BN + wn * 128) * 4u);
+  };
+  int bias_par = 0;
+  auto epilogue = [&](int tm_, int tn_) __attribute__((always_inline)) {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int fr = le & 15, gq = le >> 4;
+    const int ncol0 = tn_ * BN + wn * 128, mrow0 = tm_ * BM + wm * 128;
+    if constexpr (LDS_EPI) {
+      // wave-private 4 KB patch [32 rows][128 B] behind the two stages: every global store writes 8 complete 128-byte row pieces
+      char* patch = smem + 2 * STAGE + wave * 4096;
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        float4 b4[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) b4[jj] = *(const float4*)(bias_lds + bias_par * 1024 + (jh * 64 + jj * 16 + gq * 4) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * c + ii, row = ii * 16 + fr;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = jh * 4 + jj;
+              float v0 = acc[i][j][0] + b4[jj].x, v1 = acc[i][j][1] + b4[jj].y, v2 = acc[i][j][2] + b4[jj].z, v3 = acc[i][j][3] + b4[jj].w;
+              if constexpr (EPI == EPI_BIAS_GELU_H16) {
+                v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
+              }
+              const u32x2 pk = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+              const int piece = jj * 2 + (gq >> 1);
+              *(u32x2*)(patch + row * 128 + ((piece ^ ((row >> 1) & 7)) << 4) + ((gq & 1) << 3)) = pk;
+              acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) {
+            const int row = kq * 8 + (le >> 3), piece = le & 7;
+            const u32x4 v = *(const u32x4*)(patch + row * 128 + ((piece ^ ((row >> 1) & 7)) << 4));
+            const int m = mrow0 + c * 32 + row;
+            if (m < g.M) *(u32x4*)((half_t*)g.out + (size_t)m * g.N + ncol0 + jh * 64 + piece * 8) = v;
+          }
+        }
+      }
+    } else {
+      const int ncol = ncol0 + gq * 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = mrow0 + i * 16 + fr;
+        const float* gate_row = nullptr;
+        if constexpr (EPI == EPI_GATE_RES_F32) gate_row = g.gate + (size_t)(min(m, g.M - 1) / g.rows_per_sample) * g.gate_stride;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if (m < g.M) epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, gate_row);
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+
+  // flat walk over (tile, K tile) steps: the K loop below multiplies step (tile, kt); n1 = the step after it (landing / landed),
+  // n2 = the one after that (issued in this step's second half); both cross into the workgroup's next tile on their own
+  int pos = slot, tm, tn;
+  decode(chunk0 + pos, tm, tn);
+  // next step; when the walk ends p = -1 and the coordinates stay where they were (a valid K tile: the DMA / reads of the last two
+  // steps run unconditionally -- a branch would split the scheduling region the interleave below is written for -- and are unused)
+  auto advance = [&](int& p, int& a, int& b, int& k) __attribute__((always_inline)) {
+    if (k + 1 < nk) { ++k; return; }
+    if (p + per >= cnt) { p = -1; return; }
+    k = 0;
+    p += per;
+    decode(chunk0 + p, a, b);
+  };
+  int pos1 = pos, tm1 = tm, tn1 = tn, kt1 = 0;
+  if constexpr (LDS_EPI) dma_bias(tn, 0);
+  dma(tm, tn, 0, 0);
+  advance(pos1, tm1, tn1, kt1);                       // step 1 (nk >= 2: same tile, kt 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  dma(tm1, tn1, kt1, 1);
+  read_set(0, 0, 0);
+  int pos2 = pos1, tm2 = tm1, tn2 = tn1, kt2 = kt1;
+  advance(pos2, tm2, tn2, kt2);                       // step 2
+  int stg = 0;
+  bool after_stores = false;
+  for (;;) {
+    int posN = -1, tmN = 0, tnN = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool opens_next = kt == nk - 1 && pos1 >= 0;     // n1 is K tile 0 of the workgroup's next tile
+      if (LDS_EPI && opens_next) dma_bias(tn1, bias_par ^ 1);
+      // ---- A: first half of the K tile (set 0), fragment set 1 arriving under it: one read per two MFMAs, then MFMAs alone
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(1, stg, 1);
+      mma_set(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_STORES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      after_stores = false;
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- B: second half (set 1), the DMA of step + 2 into the stage just released, set 0 of step + 1
+      dma(tm2, tn2, kt2, stg);
+      read_set(0, stg ^ 1, 0);
+      mma_set(1);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (opens_next) { posN = pos1; tmN = tm1; tnN = tn1; }
+      pos1 = pos2; tm1 = tm2; tn1 = tn2; kt1 = kt2;
+      if (pos2 >= 0) advance(pos2, tm2, tn2, kt2);
+      stg ^= 1;
+    }
+    epilogue(tm, tn);
+    after_stores = EPI_STORES > 0;
+    bias_par ^= 1;
+    if (posN < 0) break;
+    pos = posN; tm = tmN; tn = tnN;
+  }
+}
+
+template <int DT>
+int launch_w4(const GemmArgs& a, int epi, hipStream_t st) {
+  constexpr int LDS = 2 * 512 * 128 + 4 * 4096 + 4 * 2048;
+  if (a.N % 256 || a.K % 64 || a.K < 128 || a.k_chunk) return fail(LATTE_ERR_INVALID, "gemm w4: needs N % 256 == 0, K % 64 == 0, K >= 128, no split K");
+  const int tiles = ((a.M + 255) / 256) * (a.N / 256);
+  const int nblk = tiles >= 256 ? 256 : (tiles + 7) / 8 * 8;
+  dim3 grid(nblk), block(256);
+#define LATTE_GEMM_CASE(E)                                                                           \
+  case E: {                                                                                          \
+    auto kern = gemm_w4_kernel<E, DT>;                                                               \
+    static std::atomic<uint64_t> attr_done{0};                                                       \
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
+    break;                                                                                           \
+  }
+  switch (epi) {
+    LATTE_GEMM_CASE(EPI_BIAS_H16)
+    LATTE_GEMM_CASE(EPI_BIAS_GELU_H16)
+    LATTE_GEMM_CASE(EPI_GATE_RES_F32)
+    LATTE_GEMM_CASE(EPI_BIAS_F32)
+    LATTE_GEMM_CASE(EPI_ABLATE_NOSTORE)
+    default:
+      return fail(LATTE_ERR_INVALID, "gemm w4: unknown epilogue");
+  }
+#undef LATTE_GEMM_CASE
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+#endif   // LATTE_GEMM_ABLATE
+
 template <int DT>
 int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
   switch (variant) {
@@ -1083,6 +1334,10 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
     case 9: return launch_pps<256, DT>(a, epi, st);
     case 12: return launch_n144<DT, 0>(a, epi, st);
     case 13: return launch_n144<DT, 1>(a, epi, st);
+#ifdef LATTE_GEMM_ABLATE   // measurement build: one consumer wave per SIMD (4 waves x 512 registers, wave tile 128 x 128) on the plain template
+    case 14: return launch_w4<DT>(a, epi, st);
+    case 15: return launch_cfg<256, 256, 2, 2, DT>(a, epi, st);   // the same wave layout on the plain two-stage template
+#endif
     default: return fail(LATTE_ERR_INVALID, "gemm: unknown tile variant");
   }
 }
@@ -1093,7 +1348,7 @@ int gemm_tile_m(int variant) { return variant == 1 || variant == 12 || variant =
 
 int gemm_tile_n(int variant) {
   switch (variant) {
-    case 3: case 6: case 9: return 256;
+    case 3: case 6: case 9: case 14: case 15: return 256;
     case 5: case 8: case 10: case 11: return 192;
     case 12: case 13: return 144;
     default: return 128;
