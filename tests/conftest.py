@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The fp32 oracle (CPU torch) is the slow part of the GPU suite.  On the 256-core host of a GPU box torch's default thread count
+    # oversubscribes it: an XL/2 oracle forward takes 3.5-4.3 s on 32 threads against 4.9-7.2 s on 64 and 9.4-14 s on 128
+    # (bench.py's cpu_baseline sweep).  Tolerance-based comparisons do not depend on the thread count; the
+    # bit-exact ones compare GPU results with each other or with committed fixtures.
+    import torch
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
