@@ -23,8 +23,15 @@ SOURCES = ["gemm.hip", "gemm_pw.hip", "gemm_tn.hip", "train.hip", "train_attn.hi
 COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if DEBUG_BUILD:   # measurement build: main-loop / epilogue ablation instantiations of the GEMM
     COMMON.append("-DLATTE_GEMM_ABLATE")
+# compiler-flag A/B builds (measurement only): LATTE_BUILD_TAG=<tag> LATTE_EXTRA_HIPFLAGS="<flags>" builds lib/liblatte_amd_<tag>.so
+# from objects under build_<tag>/ with the extra flags on the .hip files; loaded through LATTE_AMD_LIB like the measurement build
+BUILD_TAG = os.environ.get("LATTE_BUILD_TAG", "")
+EXTRA_HIP = os.environ.get("LATTE_EXTRA_HIPFLAGS", "").split() if BUILD_TAG else []
+if BUILD_TAG:
+    OBJ = os.path.join(HERE, "build_" + BUILD_TAG)
+    LIB = os.path.join(LIBDIR, "liblatte_amd_%s.so" % BUILD_TAG)
 FLAGS = {
-    ".hip": COMMON + ["-O3"],
+    ".hip": COMMON + ["-O3"] + EXTRA_HIP,
     # host logic reproduces fp64/fp32 reference arithmetic: no FMA contraction
     ".cpp": COMMON + ["-O2", "-ffp-contract=off"],
 }
