@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import latte_amd  # noqa: E402
 
 B = 8
+torch.manual_seed(0)      # the constructor's default initialisers draw from the global generator
 m = latte_amd.Latte_models["Latte-XL/2"](input_size=32, num_frames=16, extras=1, max_batch=B)
 gc = torch.Generator("cpu").manual_seed(1)
 with torch.no_grad():
