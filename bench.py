@@ -284,6 +284,8 @@ def parse_rocm_smi(txt):
     except Exception:  # noqa: BLE001
         return None, None
     power = clock = None
+    if not isinstance(card, dict):
+        return None, None
     for k, v in card.items():
         kl = k.lower()
         try:
