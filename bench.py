@@ -298,6 +298,20 @@ def parse_rocm_smi(txt):
     return power, clock
 
 
+def mean_power_clock(samples, a, b):
+    """Mean socket power / shader clock over the rocm-smi samples [(time, json text)] taken in [a + 0.3 s, b] (the first 0.3 s of a
+    leg still show the previous leg's power), and the number of power samples."""
+    pw, ck = [], []
+    for ts, txt in samples:
+        if a + 0.3 <= ts <= b:
+            p_w, c_mhz = parse_rocm_smi(txt)
+            if p_w is not None:
+                pw.append(p_w)
+            if c_mhz is not None:
+                ck.append(c_mhz)
+    return (round(sum(pw) / len(pw), 0) if pw else None), (round(sum(ck) / len(ck), 0) if ck else None), len(pw)
+
+
 def power_check(device, model, x, dtype):
     """Is the step bound by the kernels' schedule or by the socket's power cap?  (tools/operand_power_probe.py is the full table,
     profiles/r4_operand_power_probe_*.log.)  Two short legs outside the timed region: (1) ~1.5 s of the headline forward with
@@ -321,15 +335,7 @@ def power_check(device, model, x, dtype):
             time.sleep(0.1)
 
     def smi_mean(a, b):
-        pw, ck = [], []
-        for ts, txt in samples:
-            if a + 0.3 <= ts <= b:
-                p_w, c_mhz = parse_rocm_smi(txt)
-                if p_w is not None:
-                    pw.append(p_w)
-                if c_mhz is not None:
-                    ck.append(c_mhz)
-        return (round(sum(pw) / len(pw), 0) if pw else None), (round(sum(ck) / len(ck), 0) if ck else None), len(pw)
+        return mean_power_clock(samples, a, b)
 
     def spin(launch, seconds, per_round):
         launch(per_round)

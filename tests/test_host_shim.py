@@ -202,3 +202,8 @@ def test_bench_reads_power_and_clock_from_rocm_smi_json():
     assert bench.parse_rocm_smi(txt) == (771.0, 2403.0)
     assert bench.parse_rocm_smi("") == (None, None)
     assert bench.parse_rocm_smi('{"card0": {"sclk clock speed:": "n/a"}}') == (None, None)
+    one = lambda w, mhz: '{"card0": {"sclk clock speed:": "(%dMhz)", "Current Socket Graphics Package Power (W)": "%.1f"}}' % (mhz, w)  # noqa: E731
+    samples = [(10.0, one(700, 2400)), (10.2, one(900, 2300)), (10.4, one(1390, 1700)), (11.0, one(1400, 1710)), (11.2, "garbage"),
+               (12.5, one(800, 2400))]
+    assert bench.mean_power_clock(samples, 10.0, 12.0) == (1395.0, 1705.0, 2)      # the first 0.3 s and everything after b are left out
+    assert bench.mean_power_clock([], 0.0, 1.0) == (None, None, 0)
