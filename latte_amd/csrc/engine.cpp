@@ -602,6 +602,9 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   for (int gi = 0; gi < 4; ++gi) {
     static const char* names[4] = {"gemm_variant_qkv", "gemm_variant_proj", "gemm_variant_fc1", "gemm_variant_fc2"};
     if (k == names[gi]) {
+#ifdef LATTE_GEMM_ABLATE   // measurement build: 17 = the two-accumulator-set kernel of the gated GEMMs (gemm_pw.hip)
+      if (value == 17 && (gi == 1 || gi == 3)) { e->gemm_variant_of[gi] = 17; return LATTE_OK; }
+#endif
       if (value < 0 || value > 13) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..13");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;

@@ -1349,7 +1349,7 @@ int gemm_tile_m(int variant) { return variant == 1 || variant == 12 || variant =
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: case 14: case 15: return 256;
-    case 5: case 8: case 10: case 11: return 192;
+    case 5: case 8: case 10: case 11: case 17: return 192;
     case 12: case 13: return 144;
     default: return 128;
   }
@@ -1437,6 +1437,9 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
 #endif
   if (variant == 0) variant = gemm_resolve_variant(a.M, a.N, a.K, epi);
   if (variant == 10 || variant == 11) return launch_gemm_pw(a, epi, dtype, variant == 11, st);
+#ifdef LATTE_GEMM_ABLATE
+  if (variant == 17) return launch_gemm_pw(a, epi, dtype, 3, st);   // two-accumulator-set kernel (gemm_pw.hip; measured: loses)
+#endif
   const int bn = gemm_tile_n(variant);
   const int nq = variant >= 7 && variant <= 9 ? bn / 4 : bn;   // persistent kernels: partial last tile column in whole wave widths
   if (a.K % 64 != 0 || a.N % nq != 0 || a.M <= 0)

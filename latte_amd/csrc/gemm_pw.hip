@@ -49,6 +49,15 @@ __device__ __forceinline__ void mfma16_ip(f32x4& c, const u32x4& a, const u32x4&
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// first product of an accumulator: C = 0 (inline constant) instead of a zeroed register set
+template <int DT>
+__device__ __forceinline__ void mfma16_first(f32x4& c, const u32x4& a, const u32x4& b) {
+  if constexpr (DT == LATTE_DTYPE_BF16)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int EPI, int DT, int TAG>
@@ -787,6 +796,308 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
 #undef LATTE_TS
 }
 
+
+// ------------------------------------------------------------------------------------------------
+#ifdef LATTE_GEMM_ABLATE
+// Two-accumulator-set variant (variant 17, round 5; MEASUREMENT BUILD ONLY -- correct, bit-identical, and slower than variant 11).
+// The gated read-modify-write GEMMs pay main loop + epilogue burst: all 256 CUs reach a tile boundary together and idle their
+// matrix pipes while the memory system moves every workgroup's 393 KB fp32 patch.  This kernel hides the
+// burst: a 256 x 192 tile is two PASSES of 128 rows, all eight consumer waves compute every pass (waves 2 x 4, wave tile 64 x 48 =
+// 48 accumulators) and each wave owns TWO accumulator sets -- while set X collects pass p, set Y still holds pass p - 1 and leaves
+// one fragment per K step: the first sixteen K steps of a pass are unrolled, step s carries slice s of the drain (residual load
+// of fragment s issued, fragment s - RING read-modify-written), so every index is static, every wait a counted vmcnt the compiler
+// derives, and a residual load is consumed RING K steps (about 1.5 us) after it was issued.  The sets swap roles by name (the pass
+// loop is unrolled by two), an accumulator starts from C = 0 in the first K step of its pass (nothing is zeroed or copied), bias
+// and gate of a pass are staged by the producers (4-byte LDS-DMA pieces into a slice per pass parity and wave column).  Rings of
+// NA = 5 A stages (128 rows) and NB = 3 B stages, one workgroup barrier per K step, K order and epilogue arithmetic of variants
+// 8 / 10 / 11: same bits.
+// MEASURED (tools/alt_probe.py, profiles/r5_gated_overlap_*.log; XL/2 B = 8, f16): the drain is hidden, and the launch is slower --
+// out-projection 107 us against 104 stand-alone and 135 against 123 in the forward, fc2 374 against 316 / 377 against 307.  A first
+// form of the idea (the two consumer groups of variant 11 strictly alternating, one group's K loop beside the other's sixteen-slice
+// epilogue, i.e. one MFMA wave per SIMD; built, bit-identical, traced in profiles/r5_gated_overlap_v16_trace.log, not kept) landed on
+// the SAME times, so it is not the wave arrangement: a pass
+// fetches the W tile of a K step once per 128 rows instead of once per 256, 40 KB of LDS DMA per 48 MFMAs per SIMD against 56 KB per
+// 96 -- 1.43 x the operand bytes per MFMA through a path that delivers about 39 B / clock / CU, and that
+// path, not the epilogue, is what bounds the 192-wide kernels (56 KB / 39 = 1436 clocks per K step against 1536 of MFMA work).
+// Any scheme that needs a second accumulator set halves the tile a workgroup can hold and pays this.
+template <int EPI, int DT, int TAG>
+__global__ void __launch_bounds__(768) gemm_dacc_kernel(GemmArgs g) {
+  constexpr int BM = 256, HM = 128, BN = 192, FN = 3, FM = 4, WTN = 48;
+  constexpr int A_BYTES = HM * 128, B_BYTES = BN * 128;
+  constexpr int NA = 5, NB = 3;
+  constexpr int B_BASE = NA * A_BYTES;
+  constexpr int SIDE_BASE = B_BASE + NB * B_BYTES;   // [pass parity][wave column][64 bias | 64 gate] floats: 2 x 4 x 512 B, staged by the producers
+  constexpr int AH_INSTR = 4, BG_INSTR = 6;
+  constexpr int GROUP_M = 8;
+  constexpr int S = 16;                         // unrolled K steps at the head of a pass (K / 64 >= S + 2)
+  constexpr int RING = 3;                       // residual fragments in flight per wave
+  constexpr int NF = FM * FN;                   // 12 fragments per wave and pass
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = g.K;
+  const unsigned row_bytes = (unsigned)K * 2u;
+
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN, nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * group_m;
+    const int gsz = min(tiles_m - first_m, group_m);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+  const int nk = K / 64;
+  const int ntile = (cnt - slot + per - 1) / per;
+  const int NP = 2 * ntile;
+
+  if (wave >= 8) {
+    // ================================ producer ================================
+    const int pw = wave - 8;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)tiles_m * BM * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)g.N * row_bytes, 0x00020000);
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const unsigned voff = (unsigned)lrow * row_bytes + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
+    unsigned step32 = 32u * row_bytes;
+    asm volatile("" : "+s"(step32));
+    struct Walk { int pos, tm, tn, kt, half; };
+    auto dma_a = [&](const Walk& w, int stg) {
+      char* sA = smem + stg * A_BYTES + pw * 1024;
+      const unsigned so = (unsigned)(w.tm * BM + w.half * HM + pw * 8) * row_bytes + (unsigned)w.kt * 128u;
+#pragma unroll
+      for (int j = 0; j < AH_INSTR; ++j) pw_bload_lds16(rsA, sA + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    auto dma_b = [&](const Walk& w, int stg) {
+      char* sB = smem + B_BASE + stg * B_BYTES + pw * 1024;
+      const unsigned so = (unsigned)(w.tn * BN + pw * 8) * row_bytes + (unsigned)w.kt * 128u;
+#pragma unroll
+      for (int j = 0; j < BG_INSTR; ++j) pw_bload_lds16(rsB, sB + j * 4 * 1024, voff, so + (unsigned)j * step32);
+    };
+    auto advance = [&](Walk& w) {
+      if (++w.kt == nk) {
+        w.kt = 0;
+        w.half ^= 1;
+        if (w.half == 0) {
+          w.pos += per;
+          if (w.pos < cnt) decode(chunk0 + w.pos, w.tm, w.tn);
+        }
+      }
+    };
+    // bias / gate of a pass for the wave column wn = pw: two 4-byte LDS-DMA pieces (lanes 48-63 land in the padding) into the
+    // slice of the pass's parity, issued when the pass starts and read by the consumers one pass later
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, (unsigned)g.N * 4u, 0x00020000);
+    const int n_samples = (g.M - 1) / g.rows_per_sample + 1;
+    const __amdgpu_buffer_rsrc_t rsGate =
+        __builtin_amdgcn_make_buffer_rsrc((void*)g.gate, 0, ((unsigned)(n_samples - 1) * (unsigned)g.gate_stride + (unsigned)g.N) * 4u, 0x00020000);
+    auto dma_side = [&](int pp) {
+      int tm_, tn_;
+      decode(chunk0 + slot + (pp >> 1) * per, tm_, tn_);
+      const int row0 = min(tm_ * BM + (pp & 1) * HM, g.M - 1);
+      char* dst = smem + SIDE_BASE + (pp & 1) * 2048 + pw * 512;
+      const unsigned col = (unsigned)(tn_ * BN + pw * WTN) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_void_pw*)dst, 4, (unsigned)lane * 4u, col, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsGate, (lds_void_pw*)(dst + 256), 4, (unsigned)lane * 4u,
+                                               (unsigned)(row0 / g.rows_per_sample) * (unsigned)g.gate_stride * 4u + col, 0, 0);
+    };
+    const int U = NP * nk;
+    Walk wb{slot, 0, 0, 0, 0};
+    decode(chunk0 + slot, wb.tm, wb.tn);
+    Walk wa = wb;
+    int sa = 0, sb = 0;
+    dma_side(0);
+#pragma unroll
+    for (int i = -NA; i < 0; ++i) {
+      if (i + NB >= 0) { dma_b(wb, sb); advance(wb); sb = sb == NB - 1 ? 0 : sb + 1; }
+      dma_a(wa, sa); advance(wa); sa = sa == NA - 1 ? 0 : sa + 1;
+    }
+    constexpr int YOUNGER = (NB - 2) * (AH_INSTR + BG_INSTR) + AH_INSTR;
+    wait_vm<YOUNGER>();
+    __builtin_amdgcn_s_barrier();   // P
+    // (the two side pieces of a pass are issued behind the A stage of an iteration: wherever they are younger than the stage a
+    //  wait confirms, the count below is merely two too strict)
+    int pp = 0, kk = 0;   // pass / K step of iteration u
+    for (int u = 0; u < U; ++u) {
+      if (u + NA <= U) wait_vm<YOUNGER>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();   // B_u
+      if (u + NB < U) { dma_b(wb, sb); advance(wb); sb = sb == NB - 1 ? 0 : sb + 1; }
+      if (u + NA < U) { dma_a(wa, sa); advance(wa); sa = sa == NA - 1 ? 0 : sa + 1; }
+      if (++kk == nk) {
+        kk = 0;
+        if (++pp < NP) dma_side(pp);   // B_u with u the last step of pass pp - 1: the drain of pass pp - 2 (same parity) ended long ago
+      }
+    }
+    return;
+  }
+
+  // ================================ consumer ================================
+  const int wm = wave >> 2, wn = wave & 3;
+  const int sw = (lane >> 1) & 7;
+  const int chunkb = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (wm * 64 + (lane & 15)) * 128 + chunkb;
+  const int b_off = B_BASE + (wn * WTN + (lane & 15)) * 128 + chunkb;
+  const float* d_side = nullptr;   // [64 bias | 64 gate] slice of the pass being drained
+
+  f32x4 accX[FM][FN], accY[FM][FN];   // never zeroed: the first K step of a pass starts every accumulator from C = 0
+
+  // drain state of the pass that left last (scalars) and the per-lane part of a fragment address
+  const unsigned n4 = (unsigned)g.N * 4u;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (unsigned)g.M * n4, 0x00020000);
+  const unsigned srow16 = 16u * n4;
+  unsigned d_sbase = 0;
+  u32x4 qr[RING];
+  float4 d_b4, d_g4;   // bias / gate of the fragment the next slice writes: read from the LDS slice inside the K step, in front of the
+                       // lgkmcnt(0) that precedes its barrier anyway (a read behind the step's fragment look-ahead would wait for all of it)
+  auto side_read = [&](auto tt) {
+    constexpr int t = decltype(tt)::value;
+    if constexpr (t >= RING && t - RING < NF) {
+      constexpr int j = (t - RING) % FN;
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      d_b4 = *(const float4*)(d_side + j * 16 + (le >> 4) * 4);
+      d_g4 = *(const float4*)(d_side + 64 + j * 16 + (le >> 4) * 4);
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < RING; ++k) asm volatile("" : "=v"(qr[k]));   // "defined": no initial value to keep alive across the first pass
+  // slice t of the drain of `prv`: fragment t - RING is read-modify-written, the residual of fragment t is requested
+  auto drain_slice = [&](f32x4 (&prv)[FM][FN], auto tt) {
+    constexpr int t = decltype(tt)::value;
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const unsigned voff = (unsigned)(le & 15) * n4 + (unsigned)(le >> 4) * 16u;
+    auto soff = [&](int f) -> unsigned { return d_sbase + (unsigned)(f / FN) * srow16 + (unsigned)((f % FN) * 64); };
+    if constexpr (t >= RING && t - RING < NF) {
+      constexpr int f = t - RING, i = f / FN, j = f % FN;
+      const float4 b4 = d_b4, g4 = d_g4;
+      f32x4 rr = __builtin_bit_cast(f32x4, qr[f % RING]);
+      rr[0] += g4.x * (prv[i][j][0] + b4.x);
+      rr[1] += g4.y * (prv[i][j][1] + b4.y);
+      rr[2] += g4.z * (prv[i][j][2] + b4.z);
+      rr[3] += g4.w * (prv[i][j][3] + b4.w);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rr), rsO, voff, soff(f), 0);
+    }
+    if constexpr (t < NF) qr[t % RING] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(t), 0);
+  };
+
+  auto fill = [&](u32x4 (&bf)[2][FN], u32x4 (&af)[FM], const char* sA, const char* sB) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sB + (b_off + j * 2048));
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = *(const u32x4*)(sA + (a_off + i * 2048));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[1][j] = *(const u32x4*)(sB + ((b_off + j * 2048) ^ 64));
+  };
+  // One K step of the rolling pipeline on four fragment rows; LOOK = the fragments of stage u + 1 roll in behind the barrier.
+  auto kstep = [&](f32x4 (&acc)[FM][FN], u32x4 (&bf)[2][FN], u32x4 (&af)[FM], const char* sA, const char* sAn, const char* sBn, auto look, auto first, auto slice) {
+    constexpr bool LOOK = decltype(look)::value, FIRST = decltype(first)::value;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (FIRST) mfma16_first<DT>(acc[i][j], bf[0][j], af[i]);
+        else mfma16_ip<DT>(acc[i][j], bf[0][j], af[i]);
+      }
+      af[i] = *(const u32x4*)(sA + ((a_off + i * 2048) ^ 64));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    side_read(slice);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (LOOK) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sBn + (b_off + j * 2048));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 2; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
+      if constexpr (LOOK) af[i - 2] = *(const u32x4*)(sAn + (a_off + (i - 2) * 2048));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LOOK) {
+      af[2] = *(const u32x4*)(sAn + (a_off + 2 * 2048));
+      af[3] = *(const u32x4*)(sAn + (a_off + 3 * 2048));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[1][j] = *(const u32x4*)(sBn + ((b_off + j * 2048) ^ 64));
+    }
+  };
+
+  // Pass p of the workgroup's stream: accumulate into `cur`; DRAIN: the previous pass leaves `prv` meanwhile (compile-time, so that
+  // every slice is unconditional straight-line code and the compiler's vmcnt waits stay counted).  Then stage the bias / gate slice
+  // and the address of `cur` for ITS drain.
+  auto pass = [&](f32x4 (&cur)[FM][FN], f32x4 (&prv)[FM][FN], int p, auto drain) {
+    constexpr bool DRAIN = decltype(drain)::value;
+    int tm, tn;
+    decode(chunk0 + slot + (p >> 1) * per, tm, tn);
+    const int half = p & 1;
+    const int u0 = p * nk;
+    int ia = u0 % NA, ib = u0 % NB;
+    u32x4 bf[2][FN], af[FM];   // fragment registers: live inside a pass only
+    fill(bf, af, smem + ia * A_BYTES, smem + ib * B_BYTES);
+    auto step = [&](auto first, auto slice) {   // slice: the drain slice that follows this K step (-1: none)
+      const char* sA = smem + ia * A_BYTES;
+      ia = ia == NA - 1 ? 0 : ia + 1;
+      ib = ib == NB - 1 ? 0 : ib + 1;
+      kstep(cur, bf, af, sA, smem + ia * A_BYTES, smem + ib * B_BYTES, std::true_type{}, first, slice);
+    };
+    constexpr std::integral_constant<int, -1> NONE{};
+    if constexpr (DRAIN) {
+      // the first S K steps carry the drain, one slice each
+#define LATTE_DACC_STEP(T)                                                   \
+      step(std::integral_constant<bool, T == 0>{}, std::integral_constant<int, T>{});   \
+      drain_slice(prv, std::integral_constant<int, T>{});
+      LATTE_DACC_STEP(0) LATTE_DACC_STEP(1) LATTE_DACC_STEP(2) LATTE_DACC_STEP(3)
+      LATTE_DACC_STEP(4) LATTE_DACC_STEP(5) LATTE_DACC_STEP(6) LATTE_DACC_STEP(7)
+      LATTE_DACC_STEP(8) LATTE_DACC_STEP(9) LATTE_DACC_STEP(10) LATTE_DACC_STEP(11)
+      LATTE_DACC_STEP(12) LATTE_DACC_STEP(13) LATTE_DACC_STEP(14) LATTE_DACC_STEP(15)
+#undef LATTE_DACC_STEP
+      static_assert(S == 16 && NF + RING <= S, "drain slices must fit the unrolled head of a pass");
+      for (int kt = S; kt + 1 < nk; ++kt) step(std::false_type{}, NONE);
+    } else {
+      step(std::true_type{}, NONE);
+      for (int kt = 1; kt + 1 < nk; ++kt) step(std::false_type{}, NONE);
+    }
+    kstep(cur, bf, af, smem + ia * A_BYTES, nullptr, nullptr, std::false_type{}, std::false_type{}, NONE);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see mfma16_ip)
+    // what the drain of `cur` needs: rows >= M lie beyond the descriptor (loads return zeros, stores are dropped)
+    d_sbase = (unsigned)(tm * BM + half * HM + wm * 64) * n4 + (unsigned)(tn * BN + wn * WTN) * 4u;
+    d_side = (const float*)(smem + SIDE_BASE + half * 2048 + wn * 512);
+  };
+
+  __builtin_amdgcn_s_barrier();   // P: stage 0 has landed
+  pass(accX, accY, 0, std::false_type{});
+  for (int p = 1; p < NP; p += 2) {
+    pass(accY, accX, p, std::true_type{});
+    if (p + 1 < NP) pass(accX, accY, p + 1, std::true_type{});
+  }
+  // the last pass (in accY) leaves without a K loop beside it
+  {
+#define LATTE_DACC_TAIL(T) side_read(std::integral_constant<int, T>{}); drain_slice(accY, std::integral_constant<int, T>{});
+    LATTE_DACC_TAIL(0) LATTE_DACC_TAIL(1) LATTE_DACC_TAIL(2) LATTE_DACC_TAIL(3) LATTE_DACC_TAIL(4) LATTE_DACC_TAIL(5)
+    LATTE_DACC_TAIL(6) LATTE_DACC_TAIL(7) LATTE_DACC_TAIL(8) LATTE_DACC_TAIL(9) LATTE_DACC_TAIL(10) LATTE_DACC_TAIL(11)
+    LATTE_DACC_TAIL(12) LATTE_DACC_TAIL(13) LATTE_DACC_TAIL(14)
+#undef LATTE_DACC_TAIL
+  }
+}
+
+#endif   // LATTE_GEMM_ABLATE
+
 template <int DT>
 int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
   constexpr int LDS = 3 * 256 * 128 + 2 * 192 * 128 + 8 * 16 * 112;   // A ring + B ring + epilogue patches (rolling kernel)
@@ -807,6 +1118,27 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
       hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                             \
     }                                                                                                \
   }
+#ifdef LATTE_GEMM_ABLATE
+  if (roll == 3) {
+    constexpr int LDS_DACC = 5 * 128 * 128 + 3 * 192 * 128 + 2 * 4 * 512;   // 5 A stages of 128 rows, 3 B stages, bias / gate slices
+    if (a.K < 1152 || a.rows_per_sample % 128 != 0 || (uint64_t)a.M * a.N * 4 >= (1ull << 32))
+      return fail(LATTE_ERR_INVALID, "gemm (two-accumulator-set kernel): need K >= 1152, rows_per_sample % 128 == 0, M N 4 < 4 GiB");
+    if (epi != EPI_GATE_RES_F32) return fail(LATTE_ERR_INVALID, "gemm (two-accumulator-set kernel): gated read-modify-write epilogue only");
+    if (a.tag == 1) {
+      auto kern = gemm_dacc_kernel<EPI_GATE_RES_F32, DT, 1>;
+      static std::atomic<uint64_t> attr_done{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS_DACC, attr_done)) return rc_;
+      hipLaunchKernelGGL(kern, grid, block, LDS_DACC, st, a);
+    } else {
+      auto kern = gemm_dacc_kernel<EPI_GATE_RES_F32, DT, 0>;
+      static std::atomic<uint64_t> attr_done{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS_DACC, attr_done)) return rc_;
+      hipLaunchKernelGGL(kern, grid, block, LDS_DACC, st, a);
+    }
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
+#endif
   if (epi == EPI_GATE_RES_LN) {
     if (!roll || a.rows_per_sample % 256 != 0 || a.M % 256 != 0 || (a.ln.xn != nullptr && (a.ln.scale == nullptr || a.ln.slots == nullptr)))
       return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue needs the rolling 12-wave kernel, whole 256-row tiles inside a sample and a slot buffer");

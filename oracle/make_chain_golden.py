@@ -25,6 +25,9 @@ the block branches reach the latents at full weight), and the benchmarked chain 
   s2_uncond_g03, b2_uncond_g03, b2_guided_g03     as above with gate_std 0.3            250 (ddim, ddpm)
   xl_full       Latte-XL/2 16 x 32x32 unconditional, B = 1, gate_std 0.02                250 (ddim)   -> chain250_xl.npz
   xl_full_g03   the same with gate_std 0.3                                               250 (ddim)   -> chain250_xl.npz
+Round 5 -- BASELINE config 3's own model and call (sample/sample_ddp.py:140-160: UCF101 class-conditional Latte-XL/2 through
+``forward_with_cfg``, latte.py:379-398, cfg_scale 7.0) at trained-scale gates, full length:
+  xl_guided_g03 Latte-XL/2 16 x 32x32 class-cond (label 23 + null class), CFG 7.0, B = 1 (2 rows), gate_std 0.3   250 (ddim)   -> chain250_xl.npz
 ``--only a,b`` regenerates the named cases and merges them into the existing file (the XL chains take ~30 min each).
 """
 import os
@@ -59,9 +62,12 @@ CASES = {
                       ("ddim", "ddpm")),
     "xl_full": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 91, 92, 93, 1, None, 250, ("ddim",)),
     "xl_full_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 101, 102, 103, 1, None, 250, ("ddim",)),
+    "xl_guided_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 111, 112, 113, 1, [23], 250,
+                      ("ddim",)),
 }
-GATE_STD = {"s2_uncond_g03": 0.3, "b2_uncond_g03": 0.3, "b2_guided_g03": 0.3, "xl_full_g03": 0.3}   # default 0.02
-XL_FILE_CASES = ("xl_full", "xl_full_g03")
+GATE_STD = {"s2_uncond_g03": 0.3, "b2_uncond_g03": 0.3, "b2_guided_g03": 0.3, "xl_full_g03": 0.3,
+            "xl_guided_g03": 0.3}   # default 0.02
+XL_FILE_CASES = ("xl_full", "xl_full_g03", "xl_guided_g03")
 
 
 def case_file(name):
