@@ -93,9 +93,6 @@ void latte_engine_destroy(latte_engine_t* e);
  * OFF one default schedule feature of the fused kernel each -- the next unit's first operand tile fetched under the attention
  * phase, the attention-phase issue priority of wave group 0, the four-heads-per-XCD unit order of 16-head models (A/B hooks);
  * every setting gives the same bits),
- * "fuse_ln" (0 | 1, default 0: with 1 the LayerNorm + modulate of latte.py:179-180 between a gated GEMM and the linear behind it is
- * folded into the two GEMMs' epilogues wherever every kernel of the block has that form -- XL/2 at batch >= 8; parity-tested at
- * 1e-3 like the default path, measured without gain),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);

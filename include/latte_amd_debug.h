@@ -100,29 +100,6 @@ int latte_debug_vae_trace(struct latte_vae* v, const float* z, int n_frames, flo
  * workgroup 0 (s_memtime ticks, summed over the bursts). */
 int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, int reps, void* stream);
 
-/* ---- LayerNorm fusion (reference: the `modulate(self.norm1(x), ...)` of latte.py:28-29,179-180 between a gated
- * residual update and the linear that follows).  Pieces, each against its torch restatement in tests/test_gpu_kernels.py:
- *   latte_debug_gemm_gate_ln     res[M,N] += gate[s] (A W^T + bias); also xn_out(half)[M,N] = res_new (1 + scale[s]) and
- *                                slots[c][m] = {sum, sum of squares} of res_new[m, 48 c .. 48 c + 47] (float [N / 48][M][2]).
- *                                s = m / rows_per_sample, gate / scale rows `vec_stride` floats apart.  Needs M % 256 ==
- *                                rows_per_sample % 256 == 0, N % 192 == 0.
- *   latte_debug_ln_rowstat       r[m] = rsqrt(var_m + eps), rm[m] = r[m] mean_m from those slots (added in slot order, fp64)
- *   latte_debug_gemm_ln_consume  out(half)[M,N] = [gelu_tanh](r_m (A W^T) - rm_m u[s] + v[s]) -- fc1 behind a fused LayerNorm.
- *   latte_debug_modvec           uv[r] = [u | v],  u[n] = sum_k (1 + mod[r][scale_off + k]) W[n][k],
- *                                v[n] = sum_k mod[r][shift_off + k] W[n][k] + bias[n]   (fp32 sums over the half weights)
- *   latte_debug_qkv_attention_ln the fused qkv + attention kernel consuming such an operand (u, v: [3 D] per sample, v carries the bias)
- *   latte_debug_ln_fusable       host logic only: 1 when the engine folds the LayerNorms of a forward with M rows (engine.cpp) */
-int latte_debug_gemm_gate_ln(const void* A, const void* W, const float* bias, float* res, const float* gate, const float* scale, int vec_stride,
-                             void* xn_out, float* slots, int M, int N, int K, int rows_per_sample, int tag, int dtype, void* stream);
-int latte_debug_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, void* stream);
-int latte_debug_gemm_ln_consume(const void* A, const void* W, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
-                                void* out, int M, int N, int K, int rows_per_sample, int gelu, int dtype, void* stream);
-int latte_debug_modvec(const void* W, const float* bias, int N, int K, const float* mod, int mod_stride, int scale_off, int shift_off, int R,
-                       float* uv, int uv_stride, int dtype, void* stream);
-int latte_debug_qkv_attention_ln(const void* xn, const void* w, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
-                                 void* out, void* dbg_qkv, int B, int F, int T, int D, int heads, int mode, int dtype, void* stream);
-int latte_debug_ln_fusable(int D, int mlp_hidden, int heads, int F, int T, int M);
-
 /* Kernel-choice overrides for the A/B tests (process-global; value 0 restores the library's own choice).  Every offered value
  * selects another implementation of the SAME function (results equal up to rounding):
  *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too

@@ -128,15 +128,6 @@ PROTOTYPES = {
     "latte_debug_fill_normal": (c_int, [c_void, c_i64, c_u64, c_u64, c_void]),
     "latte_debug_tr16_probe": (c_int, [c_void, c_void]),
     "latte_debug_set_choice": (c_int, [c_char, c_int]),
-    "latte_debug_gemm_gate_ln": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_int, c_int, c_int,
-                                         c_int, c_int, c_int, c_void]),
-    "latte_debug_ln_rowstat": (c_int, [c_void, c_int, c_int, c_int, c_f32, c_void, c_void, c_void]),
-    "latte_debug_gemm_ln_consume": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int,
-                                            c_int, c_void]),
-    "latte_debug_modvec": (c_int, [c_void, c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
-    "latte_debug_qkv_attention_ln": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_int, c_int, c_int, c_int,
-                                             c_int, c_int, c_int, c_void]),
-    "latte_debug_ln_fusable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "latte_debug_dma_probe": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
     "latte_debug_conv3x3": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_void]),

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 DEBUG_BUILD = bool(os.environ.get("LATTE_DEBUG_BUILD"))
-# the measurement build (ablation instantiations, LnFuse::dbg, "ln_dbg" engine option) lives beside the product library and is only
+# the measurement build (ablation instantiations, the kernels that were measured and not kept) lives beside the product library and is only
 # ever loaded when LATTE_AMD_LIB names it (tools/, never tests or bench defaults)
 OBJ = os.path.join(HERE, "build_dbg" if DEBUG_BUILD else "build")
 LIBDIR = os.path.join(HERE, "lib")

@@ -79,35 +79,6 @@ enum GemmEpi : int {
   EPI_ABLATE_DMA_B = 11,    // only the B operand is DMA'd in the loop
   EPI_ABLATE_TRACE = 12,    // full loop, no stores; workgroup 0 writes per-wave phase times (s_memtime ticks) to `out`:
                             // int64 [8 waves][8] = {L, barrier-1 wait, C issue, vmcnt wait, barrier-2 wait, DMA issue, total, K tiles}
-  // LayerNorm fusion (round 4; `LnFuse` below)
-  EPI_GATE_RES_LN = 13,     // EPI_GATE_RES_F32 + the NEXT LayerNorm-modulate's operand: half x_new (1 + scale) and row sums (12-wave kernel)
-  EPI_LN_GELU_H16 = 14,     // out(half) = gelu_tanh(r (acc - mu u[s][n]) + v[s][n]): the consumer of an EPI_GATE_RES_LN operand (fc1)
-  EPI_LN_H16 = 15,          // out(half) = r (acc - mu u[s][n]) + v[s][n]                                        (un-fused qkv)
-};
-// LayerNorm + modulate (latte.py:28-29,166,168,179-180) folded into the GEMMs on either side of it.  The reference computes
-//     y = Linear(LN(x) (1 + sc) + sh),   LN(x) = (x - mu) r,  r = rsqrt(var + eps)        (per row; sc, sh per sample)
-// which is, exactly,   y[n] = r (sum_k x_k (1 + sc_k) W[n,k]  -  mu u[n]) + v[n],   u = (1 + sc) W^T,  v = sh W^T + b.
-// So the GEMM that PRODUCES x (the gated residual update) also writes the half operand a = x (1 + sc) (it holds the fp32 row
-// patch in registers anyway) and, per wave, its 48 columns' share of sum x, sum x^2 of every row into that wave's own SLOT
-// (slot = column tile * 4 + wave column: plain 8-byte stores, nothing is accumulated in memory, no state survives a launch);
-// ln_rowstat_kernel adds a row's slots in a fixed order (fp64) and leaves (r, r mu) per row; the GEMM that CONSUMES the operand
-// multiplies a W^T as before and applies r, r mu, u, v in its epilogue.  The separate LN pass (read 4 B + write 2 B per element,
-// 56 launches, 8 % of the XL/2 step) becomes a 6 MB pass.  (First version, measured and replaced: 64-bit fixed-point atomics
-// instead of slots -- order-independent too, but 14 us per launch in the producers' request-bound epilogue burst and fp64
-// conversions in every consumer tile; profiles/r4_ln_fusion_ablation_v1_atomics.log.)
-struct LnFuse {
-  // producer (EPI_GATE_RES_LN)
-  half_t* xn;              // [Mpad, N] half: x_new (1 + scale[sample]); nullptr = emit nothing
-  const float* scale;      // the next modulate's scale vector, per sample: scale + sample * gate_stride
-  float* slots;            // [N / 48][M][2]: (sum, sum of squares) of x_new over the wave's 48 columns
-  // consumer (EPI_LN_GELU_H16 / EPI_LN_H16, and the fused qkv + attention kernel)
-  const float* r;          // [Mpad] rsqrt(var + eps) of the row              (ln_rowstat_kernel)
-  const float* rm;         // [Mpad] r * mean
-  const float* u;          // per sample [N]: (1 + scale) W^T    (row stride uv_stride floats; fp32 sums over the HALF weights)
-  const float* v;          // per sample [N]: shift W^T + bias
-  int uv_stride;
-  int dbg;                 // measurement build (LATTE_DEBUG_BUILD=1) only, results garbage: bit 0 = producer skips the slot stores,
-                           // bit 1 = producer skips the operand stores, bit 4 = operand stores as direct 8-byte stores
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -125,7 +96,6 @@ struct GemmArgs {
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
   int k_chunk;        // plain kernels (variants 1-3) only: > 0 splits the contraction, grid.y = ceil(K / k_chunk) partial products
   long split_stride;  // ... written to (float*)out + blockIdx.y * split_stride (use EPI_BIAS_F32 with a zero bias)
-  LnFuse ln;          // EPI_GATE_RES_LN / EPI_LN_*: LayerNorm fusion operands (zero-initialised = unused)
 };
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
@@ -179,11 +149,8 @@ struct QkvAttnArgs {
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
-  LnFuse ln;           // ln.r != nullptr: xn is the un-normalised operand x (1 + scale) of a producer GEMM and the image-write
-                       // phase applies r (acc - mu u) + v (u, v: [3 D] per sample, v includes the bias) -- `bias` is unused then
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
-bool ln_fusable_shape(int D, int Hm, int heads, int hd, int F, int T, int M);   // engine.cpp: every kernel of a block has its LayerNorm-fused form
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 
 // ---- pointwise / small kernels ------------------------------------------------------------------
@@ -207,20 +174,6 @@ int launch_cond_rows(const float* temb, const float* ytab, const int64_t* y, flo
 // text_embedding_projection of the extras == 78 variant (latte.py:238-242): out[B,N] = Linear(SiLU(text[B,K]))
 int launch_text_proj(const float* text, const float* W, const float* bias, float* out, int B, int N, int K, hipStream_t st);
 int launch_iota(int64_t* p, int n, hipStream_t st);
-// LayerNorm fusion: u / v vectors of the linears that follow a LayerNorm-modulate (pointwise.hip: modvec_kernel).  One table entry
-// per linear; conditioning row r reads scale / shift at mod + r * mod_stride + {scale_off, shift_off} and writes
-// uv + r * uv_stride + uv_off: [u (N floats) | v (N floats)]
-struct ModvecEntry {
-  const half_t* W;      // [N, K] half weights (the MFMA operand)
-  const float* bias;    // [N]
-  int N;
-  int scale_off, shift_off;   // float offsets inside a conditioning row
-  long uv_off;                // float offset inside an output row
-};
-// (r, r mean) of every row from the producer's slots: slots [nslots][M][2], sums in slot order (fp64), row length n_cols
-int launch_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, hipStream_t st);
-int launch_modvec(const ModvecEntry* tab_dev, int entries, int max_n, const float* mod, long mod_stride, int R, float* uv, long uv_stride,
-                  int K, int dtype, hipStream_t st);
 // x[M, N] += gate[m / rows_per_sample, :] * (sum of `splits` fp32 partial products (slab stride `stride`) + bias): the reduction
 // of a split-K gated GEMM (engine.cpp: gated_gemm)
 int launch_gated_split_reduce(float* x, const float* ws, int splits, size_t stride, const float* bias, const float* gate,

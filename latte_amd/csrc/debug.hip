@@ -190,56 +190,6 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);
 }
 
-// ---- LayerNorm fusion pieces (common.h: LnFuse)
-int latte_debug_gemm_gate_ln(const void* A, const void* W, const float* bias, float* res, const float* gate, const float* scale, int vec_stride,
-                             void* xn_out, float* slots, int M, int N, int K, int rows_per_sample, int tag, int dtype, void* stream) {
-  GemmArgs g{};
-  g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = res; g.gate = gate; g.M = M; g.N = N; g.K = K;
-  g.gate_stride = vec_stride; g.rows_per_sample = rows_per_sample; g.tag = tag;
-  g.ln.xn = (half_t*)xn_out; g.ln.scale = scale; g.ln.slots = slots;
-  return launch_gemm(g, EPI_GATE_RES_LN, dtype, 0, (hipStream_t)stream);
-}
-
-int latte_debug_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, void* stream) {
-  return launch_ln_rowstat(slots, nslots, M, n_cols, eps, r, rm, (hipStream_t)stream);
-}
-
-int latte_debug_gemm_ln_consume(const void* A, const void* W, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
-                                void* out, int M, int N, int K, int rows_per_sample, int gelu, int dtype, void* stream) {
-  GemmArgs g{};
-  g.A = (const half_t*)A; g.W = (const half_t*)W; g.out = out; g.M = M; g.N = N; g.K = K; g.rows_per_sample = rows_per_sample;
-  g.ln.r = r; g.ln.rm = rm; g.ln.u = u; g.ln.v = v; g.ln.uv_stride = uv_stride;
-  return launch_gemm(g, gelu ? EPI_LN_GELU_H16 : EPI_LN_H16, dtype, 0, (hipStream_t)stream);
-}
-
-int latte_debug_modvec(const void* W, const float* bias, int N, int K, const float* mod, int mod_stride, int scale_off, int shift_off, int R,
-                       float* uv, int uv_stride, int dtype, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  ModvecEntry h{(const half_t*)W, bias, N, scale_off, shift_off, 0};
-  ModvecEntry* d = nullptr;
-  LATTE_HIP(hipMalloc((void**)&d, sizeof(h)));
-  LATTE_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, st));
-  int rc = launch_modvec(d, 1, N, mod, mod_stride, R, uv, uv_stride, K, dtype, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(d);
-  return rc;
-}
-
-int latte_debug_qkv_attention_ln(const void* xn, const void* w, const float* r, const float* rm, const float* u, const float* v, int uv_stride,
-                                 void* out, void* dbg_qkv, int B, int F, int T, int D, int heads, int mode, int dtype, void* stream) {
-  if (heads <= 0 || D % heads) return fail(LATTE_ERR_INVALID, "qkv_attention: D must be a multiple of heads");
-  QkvAttnArgs a{};
-  a.xn = (const half_t*)xn; a.w = (const half_t*)w; a.out = (half_t*)out; a.dbg_qkv = (half_t*)dbg_qkv;
-  a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = 7;
-  a.scale = 1.0f / sqrtf((float)a.hd);
-  a.ln.r = r; a.ln.rm = rm; a.ln.u = u; a.ln.v = v; a.ln.uv_stride = uv_stride;
-  return launch_qkv_attention(a, dtype, (hipStream_t)stream);
-}
-
-int latte_debug_ln_fusable(int D, int mlp_hidden, int heads, int F, int T, int M) {
-  return heads > 0 && D % heads == 0 && ln_fusable_shape(D, mlp_hidden, heads, D / heads, F, T, M) ? 1 : 0;
-}
-
 int latte_debug_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, float* stats, int num_seq, int L, int heads,
                                int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream) {
   return launch_attention_bwd((const half_t*)qkv, (const half_t*)o, (const half_t*)dout, (half_t*)dqkv, stats, num_seq, L, heads, hd, U,

@@ -66,17 +66,6 @@ struct Prof {
   std::vector<int> cls;
 };
 
-// LayerNorm fusion applies when every kernel of the block has its LN-aware form for this shape: the fused qkv + attention kernel
-// for both block kinds, the rolling 12-wave kernel for the two gated GEMMs, the 256-wide persistent kernel for fc1, and 256-row
-// tiles that stay inside one sample with whole-tile M.  (Pure host logic; latte_debug_ln_fusable exposes it to the CPU tests.)
-bool ln_fusable_shape(int D, int Hm, int heads, int hd, int F, int T, int M) {
-  const int rps = F * T;
-  if (M <= 0 || rps % 256 != 0 || M % 256 != 0 || (uint64_t)M * D * 4 >= (1ull << 32) || D % 8 != 0) return false;
-  if (!qkv_attention_fusable(D, heads, hd, F, T, 0, M) || !qkv_attention_fusable(D, heads, hd, F, T, 1, M)) return false;
-  if (gemm_resolve_variant(M, D, D, EPI_GATE_RES_F32) != 11 || gemm_resolve_variant(M, D, Hm, EPI_GATE_RES_F32) != 11) return false;
-  return gemm_resolve_variant(M, Hm, D, EPI_BIAS_GELU_H16) == 9;
-}
-
 }  // namespace latte
 
 using namespace latte;
@@ -93,20 +82,6 @@ struct latte_engine {
                                            // (qkv_attn.hip) wherever the shape allows it (T == 256 / F == 16); 0 = the un-fused pair;
                                            // bits 2, 3: QkvAttnArgs::flags (schedule variants, same results)
   int gated_split_k = 0;                   // gated GEMMs of small batches: 0 = rule of gated_gemm, 1 = never split, 2..4 = force
-  // LayerNorm fusion (round 4, common.h: LnFuse): 1 = wherever ln_fusable_shape() allows it, the LayerNorm +
-  // modulate between a gated GEMM and the linear that follows it lives in the two GEMMs' epilogues instead of its own HBM pass.
-  // Built, parity-green (same 1e-3 budget: 4.75e-4 against 4.72e-4 on XL/2 at trained-scale gates) and measured: it TIES the
-  // separate kernel in the forward and loses 1 % in the loop (263.2 against 266.1 sample-steps/s, same box) -- the half operand
-  // still has to be written (75 MB per launch, 17 us inside the producers' bandwidth-bound epilogue burst against 38 us for the
-  // whole separate pass), and shuffles / row statistics / the consumers' extra epilogue work eat the 4-byte read it saves
-  // (profiles/r4_ln_fusion_ablation_v2_slots.log).  So the default is 0 = the separate ln_modulate kernel; the option stays for A/B.
-  int fuse_ln = 0;
-  int ln_dbg = 0;                          // measurement build only: LnFuse::dbg of every launch (ablations, results garbage)
-  float *ln_slots = nullptr, *ln_r = nullptr, *ln_rm = nullptr;   // the producers' row-sum slots [D / 48][rows_pad][2], (r, r mu) per row
-  float *uv = nullptr, *uv_all = nullptr;  // u / v vectors of one forward [max_batch][uv_row] / of a chain chunk [rows][uv_row]
-  int64_t uv_all_cap = 0;
-  int64_t uv_row = 0;                      // depth * 2 * (3 D + Hm) floats: per block [u_qkv | v_qkv | u_fc1 | v_fc1]
-  ModvecEntry* modvec_tab = nullptr;       // device table: 2 entries per block (qkv, fc1)
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
@@ -217,8 +192,7 @@ int gated_gemm(latte_engine* e, const GemmArgs& g, int dt, int variant, hipStrea
 // mod_override != nullptr: the adaLN outputs of this step were precomputed ([B or 1 rows, nmod], row stride mod_stride;
 // stride 0 = one row shared by every sample) and the conditioning launches are skipped.
 int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t* y, int B, bool cfg_dup, float* out,
-                hipStream_t st, Prof* prof, const float* mod_override = nullptr, int mod_stride_override = 0,
-                const float* uv_override = nullptr) {
+                hipStream_t st, Prof* prof, const float* mod_override = nullptr, int mod_stride_override = 0) {
   const auto& c = e->cfg;
   if (B <= 0 || B > e->max_batch) return fail(LATTE_ERR_STATE, "forward: batch exceeds max_batch of the engine");
   if (c.extras == 2 && y == nullptr && !mod_override) return fail(LATTE_ERR_INVALID, "forward: class-conditional model needs y");
@@ -254,16 +228,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
                                     e->mod + fo, B, 2 * D, D, e->nmod, st))) return rc;
     }
   }
-  // --- LayerNorm fusion: is it on for this call, and the u / v vectors of the linears behind a LayerNorm (once per conditioning row)
-  const bool lnf = e->fuse_ln && (e->fuse_qkv_attn & 3) == 3 && e->gemm_variant == 0 && !e->gemm_variant_of[1] && !e->gemm_variant_of[2] &&
-                   !e->gemm_variant_of[3] && c.depth >= 2 && ln_fusable_shape(D, e->Hm, c.num_heads, e->hd, F, T, M);
-  const float* uvp = uv_override;
-  const int uv_stride = mstride == 0 ? 0 : (int)e->uv_row;
-  if (lnf && !uvp) {
-    if ((rc = launch_modvec(e->modvec_tab, 2 * c.depth, std::max(3 * D, e->Hm), modp, mstride, mstride == 0 ? 1 : B, e->uv, e->uv_row, D, dt, st)))
-      return rc;
-    uvp = e->uv;
-  }
   tm.mark(C_COND);
   // --- patch embed + pos_embed (latte.py:330-331)
   if (cfg_dup) {
@@ -282,14 +246,8 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     const float* mb = modp + (size_t)i * 6 * D;  // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     // x + temp_embed once, after the first spatial block (latte.py:357-358)
     const float* te = (i == 1) ? e->temp : nullptr;
-    // LayerNorm fusion (lnf): LN1 of blocks >= 2 was folded into the previous block's fc2 (operand x (1 + scale_msa) in xn, row sums in
-    // acc_ln1); blocks 0 and 1 run the separate kernel (block 0 follows the patch embed, block 1's LayerNorm adds temp_embed first)
-    const bool ln1_fused = lnf && i >= 2;
-    const float* ub = lnf ? uvp + (size_t)i * 2 * (3 * D + e->Hm) : nullptr;   // this block's [u_qkv | v_qkv | u_fc1 | v_fc1] of sample 0
-    if (!ln1_fused) {
-      if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
-      tm.mark(C_LN);
-    }
+    if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb, mb + D, mstride, M, D, rps, te, T, F, dt, st))) return rc;
+    tm.mark(C_LN);
     GemmArgs g{};
     g.M = M; g.rows_per_sample = rps; g.gate_stride = mstride;
     const half_t* attn_out = e->xn;
@@ -300,9 +258,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
       qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-4 switch the default schedule features OFF (A/B hook)
-      if (ln1_fused) {
-        qa.ln.r = e->ln_r; qa.ln.rm = e->ln_rm; qa.ln.u = ub; qa.ln.v = ub + 3 * D; qa.ln.uv_stride = uv_stride;
-      }
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
       attn_out = e->qkv;
@@ -319,35 +274,6 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     }
     g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
-    if (lnf) {
-      // out-projection: x += gate_msa (.), and LN2's operand x (1 + scale_mlp) -> xn (free: the fused kernel has consumed it), the
-      // row-sum slots; ln_rowstat turns them into (r, r mu) (its few microseconds are booked with the LayerNorm class)
-      g.ln.xn = e->xn; g.ln.scale = mb + 4 * D; g.ln.slots = e->ln_slots; g.ln.dbg = e->ln_dbg;
-      if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
-      tm.mark(C_PROJ);
-      if ((rc = launch_ln_rowstat(e->ln_slots, D / 48, M, D, 1e-6f, e->ln_r, e->ln_rm, st))) return rc;
-      tm.mark(C_LN);
-      g.ln = LnFuse{};
-      g.ln.r = e->ln_r; g.ln.rm = e->ln_rm; g.ln.u = ub + 2 * 3 * D; g.ln.v = ub + 2 * 3 * D + e->Hm; g.ln.uv_stride = uv_stride;
-      g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
-      if ((rc = launch_gemm(g, EPI_LN_GELU_H16, dt, 0, st))) return rc;
-      tm.mark(C_FC1);
-      // fc2: x += gate_mlp (.), and the NEXT block's LN1 operand x (1 + scale_msa[i + 1]) -> xn with its slots -- unless the next
-      // LayerNorm is not a fused one (block 1: temp_embed first; after the last block: the final layer's own): the plain epilogue then
-      g.ln = LnFuse{};
-      g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
-      if (i >= 1 && i + 1 < c.depth) {
-        g.ln.xn = e->xn; g.ln.scale = mb + 6 * D + D; g.ln.slots = e->ln_slots; g.ln.dbg = e->ln_dbg;
-        if ((rc = launch_gemm(g, EPI_GATE_RES_LN, dt, 0, st))) return rc;
-        tm.mark(C_FC2);
-        if ((rc = launch_ln_rowstat(e->ln_slots, D / 48, M, D, 1e-6f, e->ln_r, e->ln_rm, st))) return rc;
-        tm.mark(C_LN);
-      } else {
-        if ((rc = gated_gemm(e, g, dt, 0, st))) return rc;
-        tm.mark(C_FC2);
-      }
-      continue;
-    }
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     tm.mark(C_PROJ);
     if ((rc = launch_ln_modulate(e->xres, e->xres, e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st))) return rc;
@@ -551,26 +477,6 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
   TRY(dev_alloc(e, &e->cvec, (size_t)max_batch * D));
   TRY(dev_alloc(e, &e->model_out, (size_t)max_batch * e->F * e->Cout * e->H * e->H));
   TRY(dev_alloc(e, &e->noise_buf, (size_t)max_batch * e->F * e->Cin * e->H * e->H));
-  {  // LayerNorm fusion: the producers' slots, row statistics, u / v vectors, the table of the linears they belong to
-    e->uv_row = (int64_t)c.depth * 2 * (3 * D + e->Hm);
-    TRY(dev_alloc(e, &e->ln_slots, (size_t)(D / 48 + 1) * e->rows_pad * 2));
-    TRY(dev_alloc(e, &e->ln_r, (size_t)e->rows_pad));
-    TRY(dev_alloc(e, &e->ln_rm, (size_t)e->rows_pad));
-    TRY(dev_alloc(e, &e->uv, (size_t)max_batch * e->uv_row));
-    std::vector<ModvecEntry> tab;
-    for (int i = 0; i < c.depth; ++i) {
-      const BlockW& w = e->blocks[i];
-      const int mo = i * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-      const long uo = (long)i * 2 * (3 * D + e->Hm);
-      tab.push_back(ModvecEntry{w.qkv_w, w.qkv_b, 3 * D, mo + D, mo, uo});
-      tab.push_back(ModvecEntry{w.fc1_w, w.fc1_b, e->Hm, mo + 4 * D, mo + 3 * D, uo + 2 * 3 * D});
-    }
-    TRY(dev_alloc(e, &e->modvec_tab, tab.size()));
-    if (hipMemcpy(e->modvec_tab, tab.data(), tab.size() * sizeof(ModvecEntry), hipMemcpyHostToDevice) != hipSuccess) {
-      latte_engine_destroy(e);
-      return fail(LATTE_ERR_HIP, "engine_create: modvec table upload");
-    }
-  }
 #undef TRY
   *out = e;
   return LATTE_OK;
@@ -621,17 +527,6 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     e->fuse_qkv_attn = (int)value;
     return LATTE_OK;
   }
-  if (k == "fuse_ln") {
-    if (value < 0 || value > 1) return fail(LATTE_ERR_INVALID, "fuse_ln: 0 (separate LayerNorm-modulate kernel) or 1 (folded into the GEMM epilogues where the shape allows it)");
-    e->fuse_ln = (int)value;
-    return LATTE_OK;
-  }
-#ifdef LATTE_GEMM_ABLATE
-  if (k == "ln_dbg") {
-    e->ln_dbg = (int)value;
-    return LATTE_OK;
-  }
-#endif
   if (k == "seed") {
     e->seed = (uint64_t)value;
     e->rng_offset = 0;
@@ -817,13 +712,6 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
   if ((rc = grow(e, &e->cond_rows, &e->cond_cap, rows_chunk * D))) return rc;
   if ((rc = grow(e, &e->mod_all, &e->mod_all_cap, rows_chunk * e->nmod))) return rc;
   if (ex == 78 && (rc = grow(e, &e->cond_rows_t, &e->cond_t_cap, rows_chunk * D))) return rc;
-  // LayerNorm fusion: the u / v vectors of a conditioning row depend on (timestep, label) only, like the row itself -- computed per
-  // chunk next to the adaLN outputs (run_forward's own rule decides whether they are used)
-  const int Mrun = batch * e->F * e->T;
-  const bool chain_lnf = e->fuse_ln && (e->fuse_qkv_attn & 3) == 3 && e->gemm_variant == 0 && !e->gemm_variant_of[1] && !e->gemm_variant_of[2] &&
-                         !e->gemm_variant_of[3] && e->cfg.depth >= 2 &&
-                         ln_fusable_shape(D, e->Hm, e->cfg.num_heads, e->hd, e->F, e->T, Mrun);
-  if (chain_lnf && (rc = grow(e, &e->uv_all, &e->uv_all_cap, rows_chunk * e->uv_row))) return rc;
   const size_t fo = (size_t)e->cfg.depth * 6 * D;
   // conditioning of respaced steps [lo, lo + cnt): rows ordered by index ascending, row (i - lo) * bu + b
   auto chain_conditioning = [&](int lo, int cnt) -> int {
@@ -841,8 +729,6 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
           (r2 = launch_small_linear(IN_PLAIN, e->cond_rows_t + (size_t)r0 * D, nullptr, e->ada_w + fo * D, e->ada_b + fo, nullptr,
                                     nullptr, e->mod_all + (size_t)r0 * e->nmod + fo, rows, 2 * D, D, e->nmod, st))) return r2;
     }
-    if (chain_lnf && (r2 = launch_modvec(e->modvec_tab, 2 * e->cfg.depth, std::max(3 * D, e->Hm), e->mod_all, e->nmod, (int)rows_all, e->uv_all,
-                                         e->uv_row, D, e->cfg.compute_dtype, st))) return r2;
     return LATTE_OK;
   };
   const size_t numel = (size_t)batch * e->F * e->Cin * e->H * e->H;
@@ -854,8 +740,7 @@ int latte_sample_loop_ex(latte_engine_t* e, const latte_schedule_t* s, int metho
       if ((rc = chain_conditioning(chunk_lo, i - chunk_lo + 1))) return rc;
     }
     const float* mod_i = e->mod_all + (size_t)(i - chunk_lo) * bu * e->nmod;
-    const float* uv_i = chain_lnf ? e->uv_all + (size_t)(i - chunk_lo) * bu * e->uv_row : nullptr;
-    if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod, uv_i))) return rc;
+    if ((rc = run_forward(e, x, nullptr, y, batch, use_cfg, e->model_out, st, nullptr, mod_i, bu == 1 ? 0 : e->nmod))) return rc;
     SamplerCoefs c = make_coefs(s, method, i, eta, clip_denoised);
     c.cfg_scale = cfg_scale;
     const bool need_noise = (method == LATTE_METHOD_DDPM) ? (i != 0) : (c.sigma != 0.0f && i != 0);

@@ -674,11 +674,7 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
   // Half-precision outputs of the 256-wide tile go through a wave-private 4 KB LDS patch (the 32 KB the two
   // stages leave free) so that every global store instruction writes 8 complete 128-byte rows instead of
   // 16 rows x 32 bytes: the direct form is store-ISSUE bound (measured: 25-30 % of the fc1 / qkv launch).
-  // LN_EPI (round 4): the A operand is x (1 + scale), un-normalised; the LayerNorm is applied here as r (acc - mu u[n]) + v[n]
-  // with the row statistics a producer GEMM accumulated (common.h: LnFuse; v carries the bias).  256-wide tile only.
-  constexpr bool LN_EPI = EPI == EPI_LN_GELU_H16 || EPI == EPI_LN_H16;
-  static_assert(!LN_EPI || BN == 256, "the LayerNorm-consuming epilogue exists for the 256-wide tile");
-  constexpr bool LDS_EPI = (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16 || LN_EPI) && BN == 256;
+  constexpr bool LDS_EPI = (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) && BN == 256;
   auto epilogue = [&](int tm_, int tn_) {
     int le = lane;
     asm volatile("" : "+v"(le));   // opaque: keeps every lane-derived epilogue index out of the K loop's live set
@@ -695,49 +691,20 @@ __global__ void __launch_bounds__(512) gemm_pps_kernel(GemmArgs g) {
       // patch image: [32 rows][128 B]; 16-byte piece p of row r lives at piece p ^ ((r >> 1) & 7)
       char* patch = smem + 2 * STAGE + wave * 4096;
       const int gq = le >> 4;
-      float4 b4[FN], u4[LN_EPI ? FN : 1];
+      float4 b4[FN];
       const int mrow0 = tm_ * BM + grp * 128;
-      float rs8[LN_EPI ? 8 : 1], rm8[LN_EPI ? 8 : 1];   // LN_EPI: (r, r mu) of this lane's 8 rows (mrow0 + 16 i + fr), fetched up front
-      if constexpr (LN_EPI) {
-        const size_t so = (size_t)((tm_ * BM) / g.rows_per_sample) * g.ln.uv_stride + ncol0 + gq * 4;   // tiles lie inside one sample
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          b4[j] = *(const float4*)(g.ln.v + so + j * 16);
-          u4[j] = *(const float4*)(g.ln.u + so + j * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int m = min(mrow0 + i * 16 + fr, g.M - 1);
-          rs8[i] = g.ln.r[m];
-          rm8[i] = g.ln.rm[m];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);
-      }
+      for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol0 + j * 16 + gq * 4);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
           const int i = 2 * c + ii;
           const int row = ii * 16 + fr;
-          float rs = 1.0f, rm = 0.0f;   // r, r mu of this fragment row's LayerNorm
-          if constexpr (LN_EPI) {
-            rs = rs8[i];
-            rm = rm8[i];
-          }
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
-            float v0, v1, v2, v3;
-            if constexpr (LN_EPI) {
-              v0 = __builtin_fmaf(rs, acc[i][j][0], __builtin_fmaf(-rm, u4[j].x, b4[j].x));
-              v1 = __builtin_fmaf(rs, acc[i][j][1], __builtin_fmaf(-rm, u4[j].y, b4[j].y));
-              v2 = __builtin_fmaf(rs, acc[i][j][2], __builtin_fmaf(-rm, u4[j].z, b4[j].z));
-              v3 = __builtin_fmaf(rs, acc[i][j][3], __builtin_fmaf(-rm, u4[j].w, b4[j].w));
-            } else {
-              v0 = acc[i][j][0] + b4[j].x; v1 = acc[i][j][1] + b4[j].y; v2 = acc[i][j][2] + b4[j].z; v3 = acc[i][j][3] + b4[j].w;
-            }
-            if constexpr (EPI == EPI_BIAS_GELU_H16 || EPI == EPI_LN_GELU_H16) {
+            float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+            if constexpr (EPI == EPI_BIAS_GELU_H16) {
               v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3);
             }
             const u32x2 pk = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
@@ -1005,18 +972,6 @@ int launch_pps(const GemmArgs& a, int epi, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
     LATTE_HIP(hipGetLastError());
     return LATTE_OK;
-  }
-  if constexpr (BN == 256) {   // LayerNorm-consuming epilogues (common.h: LnFuse): 256-wide tile, tiles inside one sample
-    if (epi == EPI_LN_GELU_H16 || epi == EPI_LN_H16) {
-      if (a.rows_per_sample % 256 != 0 || !a.ln.r || !a.ln.rm || !a.ln.u || !a.ln.v)
-        return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-consuming epilogue needs row statistics, u / v vectors and rows_per_sample % 256 == 0");
-      switch (epi) {
-        LATTE_GEMM_CASE(EPI_LN_GELU_H16)
-        LATTE_GEMM_CASE(EPI_LN_H16)
-      }
-      LATTE_HIP(hipGetLastError());
-      return LATTE_OK;
-    }
   }
   switch (epi) {
     LATTE_GEMM_CASE(EPI_BIAS_H16)
@@ -1410,17 +1365,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
   GemmArgs a = a_in;
   // grouped tile order of the persistent kernel: the gated-residual GEMMs (192-wide tiles: an A K-tile is 32 KB, a W K-tile
   // 24 KB) walk 4 tile rows together instead of 8 (fc2 in the XL/2 forward at B = 8: 341 -> 333 us, round-2 sweep)
-  if (a.group_m == 0 && (epi == EPI_GATE_RES_F32 || epi == EPI_GATE_RES_LN)) a.group_m = 4;
-  // LayerNorm-fused epilogues (common.h: LnFuse) exist in one kernel each: the producer in the rolling 12-wave kernel (variant 11),
-  // the consumers in the 256-wide persistent kernel (variant 9)
-  if (epi == EPI_GATE_RES_LN) {
-    if (variant != 0 && variant != 11) return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-emitting gated epilogue runs on variant 11 only");
-    return launch_gemm_pw(a, epi, dtype, 1, st);
-  }
-  if (epi == EPI_LN_GELU_H16 || epi == EPI_LN_H16) {
-    if (variant != 0 && variant != 9) return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-consuming epilogues run on variant 9 only");
-    variant = 9;
-  }
+  if (a.group_m == 0 && epi == EPI_GATE_RES_F32) a.group_m = 4;
 #ifdef LATTE_GEMM_ABLATE
   if (const char* m = getenv("LATTE_RMW_MODE")) a.rmw_mode = atoi(m);
   if (const char* m = getenv("LATTE_RMW_VARIANT")) { if (epi == EPI_GATE_RES_F32 && variant == 0) variant = atoi(m); }

@@ -549,99 +549,6 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       }
       return;
     }
-    if constexpr (EPI == EPI_GATE_RES_LN) {
-      // EPI_GATE_RES_F32 + the next LayerNorm-modulate's operand (common.h: LnFuse).  The wave holds the NEW residual values of
-      // 128 rows x 48 columns in registers: it also stores a = x_new (1 + scale) as half and each row's sum x_new, sum x_new^2 over
-      // these 48 columns into the wave's own slot (lanes 0-15: one row each, one 8-byte store per fragment row).  The launcher
-      // guarantees rows_per_sample % 256 == 0, M % 256 == 0 (no row guards) and M N 4 < 4 GiB.  All global accesses are BUFFER
-      // operations on one per-lane byte offset plus scalar offsets: per-fragment 64-bit pointers (two VGPRs each, hoisted by the
-      // compiler) do not fit the 168 registers a wave of this kernel has next to its 96 accumulators.
-      const unsigned nbytes = (unsigned)g.M * (unsigned)g.N * 4u;
-      const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, nbytes, 0x00020000);
-      const bool emit = g.ln.xn != nullptr;
-      const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(emit ? g.ln.xn : (half_t*)g.out), 0, nbytes >> 1, 0x00020000);
-      const unsigned voff = ((unsigned)fr * (unsigned)g.N + (unsigned)((le >> 4) * 4)) * 4u;                        // lane part
-      const unsigned sbase = ((unsigned)(tm_ * BM + grp * 128) * (unsigned)g.N + (unsigned)(tn_ * BN + wn * WTN)) * 4u;   // wave part
-      const unsigned srow16 = 16u * (unsigned)g.N * 4u;
-      const size_t srow = (size_t)((tm_ * BM) / g.rows_per_sample) * g.gate_stride + ncol;
-      float4 b4[FN], g1[FN], s4[FN];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        b4[j] = *(const float4*)(g.bias + ncol + j * 16);
-        g1[j] = *(const float4*)(g.gate + srow + j * 16);
-        s4[j] = emit ? *(const float4*)(g.ln.scale + srow + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      constexpr int NF = 8 * FN, AHEAD = 2;
-      auto soff = [&](int f) -> unsigned { return sbase + (unsigned)(f / FN) * srow16 + (unsigned)((f % FN) * 64); };
-      u32x4 qa[AHEAD];
-#pragma unroll
-      for (int a = 0; a < AHEAD; ++a) qa[a] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(a), 0);
-      float p1 = 0.f, p2 = 0.f;
-      float* const slotp = g.ln.slots + ((size_t)(tn_ * 4 + wn) * g.M + mbase) * 2;   // this wave's slot, this lane's first row
-      // the half operand goes through the wave-private LDS patch (16 rows, pitch 112 B: the half-output epilogue's) so that the
-      // global stores are 16 B per lane on contiguous 96-byte row segments -- 1.5 store instructions per fragment row instead of
-      // three 8-byte ones on 32-byte pieces: the epilogue burst of this kernel is bound by the NUMBER of memory requests
-      // (profiles/r4_ln_fusion_ablation.log), not by their bytes
-      char* const patch = smem + B_BASE + 2 * B_BYTES + wave * PATCH_BYTES;
-      const int gq = le >> 4;
-      const int r0 = le / 6, p0 = le - r0 * 6;               // piece le      -> (row, 16-byte piece) of the 16 x 6 grid
-      const int r1 = (le + 64) / 6, p1_ = (le + 64) - r1 * 6; // piece le + 64 (lanes 0-31)
-      const unsigned vx0 = ((unsigned)r0 * (unsigned)g.N + (unsigned)(p0 * 8)) * 2u, vx1 = ((unsigned)r1 * (unsigned)g.N + (unsigned)(p1_ * 8)) * 2u;
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        f32x4 rr = __builtin_bit_cast(f32x4, qa[f % AHEAD]);
-        if (f + AHEAD < NF) qa[f % AHEAD] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voff, soff(f + AHEAD), 0);
-        asm volatile("" ::: "memory");
-        const int i = f / FN, j = f % FN;
-        rr[0] += g1[j].x * (acc[i][j][0] + b4[j].x);
-        rr[1] += g1[j].y * (acc[i][j][1] + b4[j].y);
-        rr[2] += g1[j].z * (acc[i][j][2] + b4[j].z);
-        rr[3] += g1[j].w * (acc[i][j][3] + b4[j].w);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rr), rsO, voff, soff(f), 0);
-        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (emit) {
-          const u32x2 pk = {pack2<DT>(__builtin_fmaf(rr[0], s4[j].x, rr[0]), __builtin_fmaf(rr[1], s4[j].y, rr[1])),
-                            pack2<DT>(__builtin_fmaf(rr[2], s4[j].z, rr[2]), __builtin_fmaf(rr[3], s4[j].w, rr[3]))};
-#ifdef LATTE_GEMM_ABLATE
-          if (g.ln.dbg & 16) {   // the direct form: 8 B per lane (measured: +12 us per launch against the patch route)
-            if (!(g.ln.dbg & 2)) __builtin_amdgcn_raw_buffer_store_b64(pk, rsX, voff >> 1, soff(f) >> 1, 0);
-          } else
-#endif
-          {
-            *(u32x2*)(patch + fr * 112 + j * 32 + gq * 8) = pk;
-            if (j == FN - 1) {
-              const unsigned sx = (sbase + (unsigned)i * srow16) >> 1;
-              const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
-#ifdef LATTE_GEMM_ABLATE
-              if (!(g.ln.dbg & 2))
-#endif
-              {
-                __builtin_amdgcn_raw_buffer_store_b128(w0, rsX, vx0, sx, 0);
-                if (le < 32) {
-                  const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1_ * 16);
-                  __builtin_amdgcn_raw_buffer_store_b128(w1, rsX, vx1, sx, 0);
-                }
-              }
-            }
-          }
-          p1 += (rr[0] + rr[1]) + (rr[2] + rr[3]);
-          p2 += (rr[0] * rr[0] + rr[1] * rr[1]) + (rr[2] * rr[2] + rr[3] * rr[3]);
-          if (j == FN - 1) {   // fragment row complete: the row's 48 columns sit in lanes fr, fr + 16, fr + 32, fr + 48
-            p1 += __shfl_xor(p1, 16, 64);
-            p2 += __shfl_xor(p2, 16, 64);
-            p1 += __shfl_xor(p1, 32, 64);
-            p2 += __shfl_xor(p2, 32, 64);
-#ifdef LATTE_GEMM_ABLATE
-            if (!(g.ln.dbg & 1))
-#endif
-            if (le < 16) *(float2*)(slotp + i * 32) = make_float2(p1, p2);
-            p1 = 0.f;
-            p2 = 0.f;
-          }
-        }
-      }
-      return;
-    }
     if constexpr (EPI == EPI_GATE_RES_F32) {
       if ((g.rows_per_sample % BM) == 0) {
         float* const outp = (float*)g.out;
@@ -1139,12 +1046,7 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     return LATTE_OK;
   }
 #endif
-  if (epi == EPI_GATE_RES_LN) {
-    if (!roll || a.rows_per_sample % 256 != 0 || a.M % 256 != 0 || (a.ln.xn != nullptr && (a.ln.scale == nullptr || a.ln.slots == nullptr)))
-      return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue needs the rolling 12-wave kernel, whole 256-row tiles inside a sample and a slot buffer");
-    if ((uint64_t)a.M * a.N * 4 >= (1ull << 32)) return fail(LATTE_ERR_INVALID, "gemm: the LayerNorm-fused gated epilogue addresses its output through 32-bit buffer offsets (M N 4 < 4 GiB)");
-    if (a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_LN, 1) else LATTE_PW_CASE(EPI_GATE_RES_LN, 0)
-  } else if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
+  if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
   else if (epi == EPI_GATE_RES_F32) LATTE_PW_CASE(EPI_GATE_RES_F32, 0)
   else if (epi == EPI_BIAS_F32) LATTE_PW_CASE(EPI_BIAS_F32, 0)
   else if (epi == EPI_BIAS_H16) LATTE_PW_CASE(EPI_BIAS_H16, 0)

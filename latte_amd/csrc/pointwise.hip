@@ -920,113 +920,6 @@ __global__ void scale_f32_kernel(float* __restrict__ p, float s, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] *= s;
 }
 
-// ---- LayerNorm fusion (common.h: LnFuse): the per-sample vectors the consuming GEMM epilogues apply
-//     u[r][n] = sum_k (1 + scale[r][k]) W[n][k],      v[r][n] = sum_k shift[r][k] W[n][k] + bias[n]
-// for every linear that follows a LayerNorm-modulate (qkv and fc1 of every block), fp32 sums over the HALF weights the MFMAs
-// multiply with (mu u must cancel against the accumulator's own mu-component to rounding).  One wave = 64 outputs n (lane = n:
-// each lane streams its own weight row in 16-byte pieces), RB conditioning rows per pass: the modulation values are wave-uniform,
-// so they come through scalar loads and enter the FMAs as SGPR operands -- no LDS, no cross-lane reduction.  Conditioning rows are
-// (sample) or (step, sample) rows of the adaLN output buffer; entry e of the table names one linear.
-typedef __attribute__((ext_vector_type(4))) unsigned int mv_u32x4;
-template <int DT>
-__device__ __forceinline__ void unpack8(const mv_u32x4 w, float (&f)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (DT == LATTE_DTYPE_BF16) {
-      f[2 * i] = __uint_as_float(w[i] << 16);
-      f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
-    } else {
-      // (scalar copy and 16-bit pieces: bit-casting the vector element to an f16 pair was miscompiled into re-using element 0,
-      //  the issue documented at gemm.hip's EPI_BIAS_RES_H16)
-      const unsigned int u = w[i];
-      f[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
-      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
-    }
-  }
-}
-
-template <int DT, int RB>
-__global__ void __launch_bounds__(64) modvec_kernel(const ModvecEntry* __restrict__ tab, const float* __restrict__ mod, long mod_stride,
-                                                    int R, float* __restrict__ uv, long uv_stride, int K) {
-  const ModvecEntry e = tab[blockIdx.y];
-  const int n0 = blockIdx.x * 64;
-  if (n0 >= e.N) return;
-  const int lane = threadIdx.x, n = min(n0 + lane, e.N - 1);
-  const int r0 = blockIdx.z * RB;
-  const half_t* wrow = e.W + (size_t)n * K;
-  float au[RB], av[RB], wsum = 0.f;
-#pragma unroll
-  for (int r = 0; r < RB; ++r) au[r] = av[r] = 0.f;
-  const float* sc[RB];
-#pragma unroll
-  for (int r = 0; r < RB; ++r) sc[r] = mod + (size_t)min(r0 + r, R - 1) * mod_stride;
-  for (int k = 0; k < K; k += 8) {
-    float w[8];
-    unpack8<DT>(*(const mv_u32x4*)(wrow + k), w);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wsum += w[j];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const float4 s0 = *(const float4*)(sc[r] + e.scale_off + k), s1 = *(const float4*)(sc[r] + e.scale_off + k + 4);
-      const float4 h0 = *(const float4*)(sc[r] + e.shift_off + k), h1 = *(const float4*)(sc[r] + e.shift_off + k + 4);
-      au[r] += s0.x * w[0] + s0.y * w[1] + s0.z * w[2] + s0.w * w[3] + s1.x * w[4] + s1.y * w[5] + s1.z * w[6] + s1.w * w[7];
-      av[r] += h0.x * w[0] + h0.y * w[1] + h0.z * w[2] + h0.w * w[3] + h1.x * w[4] + h1.y * w[5] + h1.z * w[6] + h1.w * w[7];
-    }
-  }
-  if (n0 + lane < e.N) {
-    const float b = e.bias[n];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      if (r0 + r < R) {
-        float* o = uv + (size_t)(r0 + r) * uv_stride + e.uv_off;
-        o[n] = wsum + au[r];
-        o[e.N + n] = av[r] + b;
-      }
-    }
-  }
-}
-
-// (r, r mu) of every row from the slots a LayerNorm-emitting gated GEMM wrote (common.h: LnFuse): slot s holds the row's
-// (sum, sum of squares) over columns [48 s, 48 s + 48); added here in slot order in fp64 -- deterministic whatever order the column
-// tiles ran in -- then mu = S1 / n, var = S2 / n - mu^2, r = rsqrt(var + eps) (latte.py:166,168: eps 1e-6, biased variance).
-__global__ void __launch_bounds__(256) ln_rowstat_kernel(const float2* __restrict__ slots, int nslots, int M, double inv_n, double eps,
-                                                         float* __restrict__ r, float* __restrict__ rm) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-  for (int s = 0; s < nslots; ++s) {
-    const float2 p = slots[(size_t)s * M + m];
-    s1 += (double)p.x;
-    s2 += (double)p.y;
-  }
-  const double mu = s1 * inv_n;
-  double var = s2 * inv_n - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const float rs = (float)(1.0 / sqrt(var + eps));
-  r[m] = rs;
-  rm[m] = rs * (float)mu;
-}
-
-int launch_ln_rowstat(const float* slots, int nslots, int M, int n_cols, float eps, float* r, float* rm, hipStream_t st) {
-  if (nslots <= 0 || M <= 0 || n_cols <= 0) return fail(LATTE_ERR_INVALID, "ln_rowstat: bad shape");
-  hipLaunchKernelGGL(ln_rowstat_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float2*)slots, nslots, M, 1.0 / (double)n_cols, (double)eps, r, rm);
-  LATTE_HIP(hipGetLastError());
-  return LATTE_OK;
-}
-
-int launch_modvec(const ModvecEntry* tab_dev, int entries, int max_n, const float* mod, long mod_stride, int R, float* uv, long uv_stride,
-                  int K, int dtype, hipStream_t st) {
-  if (K % 8 || R <= 0) return fail(LATTE_ERR_INVALID, "modvec: K % 8 != 0 or no rows");
-  constexpr int RB = 4;
-  dim3 grid((max_n + 63) / 64, entries, (R + RB - 1) / RB);
-  if (dtype == LATTE_DTYPE_BF16) hipLaunchKernelGGL((modvec_kernel<LATTE_DTYPE_BF16, RB>), grid, dim3(64), 0, st, tab_dev, mod, mod_stride, R, uv, uv_stride, K);
-  else if (dtype == LATTE_DTYPE_F16) hipLaunchKernelGGL((modvec_kernel<LATTE_DTYPE_F16, RB>), grid, dim3(64), 0, st, tab_dev, mod, mod_stride, R, uv, uv_stride, K);
-  else return fail(LATTE_ERR_INVALID, "modvec: unknown dtype");
-  LATTE_HIP(hipGetLastError());
-  return LATTE_OK;
-}
-
 int launch_scale_f32(float* p, float s, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, s, n);
   LATTE_HIP(hipGetLastError());

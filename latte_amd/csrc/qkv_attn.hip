@@ -78,11 +78,8 @@ constexpr int Q_OFF = 0, K_OFF = 256 * RPQ, V_OFF = 2 * 256 * RPQ, IMG_END = V_O
 //   [0, 36864) Q image        [36864, 73728) K image       [73728, 114688) V image
 //   [0, 32768) A tile stage 0                               [61440, 94208) A tile stage 1   [94208, 122880) W tile stage 1
 //   [122880, 151552) W tile stage 0     [151552, 152704) bias of the head (3 hd floats)
-//   LayerNorm-consuming mode (LN, round 4): [151552, 152704) v of the head (it carries the bias), [152704, 153856) u of the head,
-//   [153856, 154880) r of the unit's 256 rows, [154880, 155904) r mu of them (ln_rowstat_kernel's output, DMA'd one unit ahead)
 constexpr int A0_OFF = 0, A1_OFF = 61440, B1_OFF = 94208, B0_OFF = 122880, BIAS_OFF = B0_OFF + 224 * 128;
-constexpr int VVEC_OFF = BIAS_OFF + 288 * 4, STAT_OFF = VVEC_OFF + 288 * 4;
-constexpr int FUSED_LDS = STAT_OFF + 2 * 256 * 4;
+constexpr int FUSED_LDS = BIAS_OFF + 288 * 4;
 
 // FLAGS bit 0 (EARLY): the next unit's K tile 0 is DMA'd into stage 0 right after the attention phase has fetched its Q
 //   fragments (one barrier, taken while the waves are still aligned), so the fill latency of the next unit's operand pipeline
@@ -90,10 +87,7 @@ constexpr int FUSED_LDS = STAT_OFF + 2 * 256 * 4;
 // FLAGS bit 1 (PRIO): during the attention phase the waves of group 0 (one per SIMD) run at a higher issue priority than their
 //   SIMD partners of group 1: the two fall out of phase (group 1's MFMA segments run under group 0's softmax VALU work and vice
 //   versa) instead of competing for the same pipe in lock step.
-// LN (round 4, common.h: LnFuse): xn is the UN-normalised operand x (1 + scale) a producer GEMM emitted; the image-write phase
-//   applies the LayerNorm as r (acc - mu u[n]) + v[n] with the row statistics of ln_rowstat_kernel (u, v per sample; v carries the
-//   bias).  Row statistics and the head's u / v slices are fetched one unit ahead, like the bias of the plain mode.
-template <int HD, int DT, int MODE, int FLAGS, bool LN = false>
+template <int HD, int DT, int MODE, int FLAGS>
 __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   constexpr bool EARLY = (FLAGS & 1) != 0, PRIO = (FLAGS & 2) != 0;
   constexpr int NQ = 3 * HD;
@@ -203,32 +197,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   // thread i < 3 hd / 4 carries floats 4 i .. 4 i + 3 of the NEXT unit's head in a register from the fetch point to the next
   // unit's first barrier, where the operand DMA is drained anyway
   const int bias_i = min((int)threadIdx.x, NQ / 4 - 1) * 4, bias_mat = bias_i / HD, bias_d = bias_i - bias_mat * HD;
-  // side data of a unit.  Plain mode: the head's bias, carried in a register from the fetch point to the unit's first barrier.
-  // LN mode: nothing is carried (12 more registers through the attention phase spilled) -- r and r mu of the unit's 256 rows
-  // (waves 0-3, one row per lane: the temporal row gather is a per-lane source address), the head's u slice (wave 4) and v
-  // slice (wave 5) of the unit's SAMPLE go straight to LDS by DMA, confirmed by the vmcnt(0) that opens the unit anyway
-  const int rps = F * T;
-  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln.r, 0, 0xFFFFFFF0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln.rm, 0, 0xFFFFFFF0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln.u, 0, 0xFFFFFFF0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln.v, 0, 0xFFFFFFF0u, 0x00020000);
-  const int lmat = min(lane, NQ / 4 - 1) * 4 / HD, ld_ = min(lane, NQ / 4 - 1) * 4 - lmat * HD;   // lane -> (q | k | v block, column) of 4 floats
-  auto fetch_side = [&](const Unit& un) -> float4 {
-    if constexpr (LN) {
-      if (wave < 4) {   // r and r mu of tile row t = wave * 64 + lane: one dword per lane each, lane-linear in LDS
-        const int t = wave * 64 + lane;
-        const int grow = MODE == 0 ? un.row_base + t : un.row_base + (t & 15) * T + (t >> 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void_t*)(smem + STAT_OFF + wave * 256), 4, (unsigned)grow * 4u, 0u, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (lds_void_t*)(smem + STAT_OFF + 1024 + wave * 256), 4, (unsigned)grow * 4u, 0u, 0, 0);
-      } else if (wave < 6 && lane < NQ / 4) {
-        const unsigned so = (unsigned)((un.row_base / rps) * a.ln.uv_stride + lmat * D + un.head * HD + ld_) * 4u;
-        if (wave == 4) dma16(rsU, smem + VVEC_OFF, so, 0u); else dma16(rsV, smem + BIAS_OFF, so, 0u);
-      }
-      return make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      return *(const float4*)(a.bias + bias_mat * D + un.head * HD + bias_d);
-    }
-  };
+  auto fetch_side = [&](const Unit& un) -> float4 { return *(const float4*)(a.bias + bias_mat * D + un.head * HD + bias_d); };
 
   if (it >= it_end) return;
   Unit cur = decode(it);
@@ -271,9 +240,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (!LN) {
-      if (threadIdx.x < NQ / 4) *(float4*)(smem + BIAS_OFF + threadIdx.x * 16) = side;
-    }
+    if (threadIdx.x < NQ / 4) *(float4*)(smem + BIAS_OFF + threadIdx.x * 16) = side;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // K tile 0 has landed for everybody; the head's bias is in LDS
     dma_a_half(cur, 1, 1);
@@ -324,27 +291,12 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         if (n0 < NQ) {
           const int mat = n0 >= 2 * HD ? 2 : (n0 >= HD ? 1 : 0);
           const int d = n0 - mat * HD;
-          const float4 b4 = *(const float4*)(smem + BIAS_OFF + n0 * 4);     // q | k | v bias of the head, column n0 .. n0 + 3 (LN: v)
+          const float4 b4 = *(const float4*)(smem + BIAS_OFF + n0 * 4);     // q | k | v bias of the head, column n0 .. n0 + 3
           char* dst = smem + (mat == 2 ? V_OFF + (grp * 128 + wm * 64 + fr) * RPV : mat * K_OFF + (grp * 128 + wm * 64 + fr) * RPQ) + d * 2;
-          if constexpr (LN) {
-            const float4 u4 = *(const float4*)(smem + VVEC_OFF + n0 * 4);
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int trow = grp * 128 + wm * 64 + fr + i * 16;
-              const f32x2_t rr = {*(const float*)(smem + STAT_OFF + trow * 4), *(const float*)(smem + STAT_OFF + 1024 + trow * 4)};   // (r, r mu)
-              const u32x2 pk = {pack2<DT>(__builtin_fmaf(rr.x, acc[i][j][0], __builtin_fmaf(-rr.y, u4.x, b4.x)),
-                                          __builtin_fmaf(rr.x, acc[i][j][1], __builtin_fmaf(-rr.y, u4.y, b4.y))),
-                                pack2<DT>(__builtin_fmaf(rr.x, acc[i][j][2], __builtin_fmaf(-rr.y, u4.z, b4.z)),
-                                          __builtin_fmaf(rr.x, acc[i][j][3], __builtin_fmaf(-rr.y, u4.w, b4.w)))};
-              *(u32x2*)(dst + i * 16 * (mat == 2 ? RPV : RPQ)) = pk;
-            }
-          } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const u32x2 pk = {pack2<DT>(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y), pack2<DT>(acc[i][j][2] + b4.z, acc[i][j][3] + b4.w)};
             *(u32x2*)(dst + i * 16 * (mat == 2 ? RPV : RPQ)) = pk;
-          }
           }
         }
       }
@@ -573,9 +525,9 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   }
 }
 
-template <int HD, int DT, int MODE, int FLAGS, bool LN = false>
+template <int HD, int DT, int MODE, int FLAGS>
 int launch_one(const QkvAttnArgs& a, dim3 grid, hipStream_t st) {
-  auto kern = qkv_attn_kernel<HD, DT, MODE, FLAGS, LN>;
+  auto kern = qkv_attn_kernel<HD, DT, MODE, FLAGS>;
   static std::atomic<uint64_t> done{0};
   if (int rc = ensure_dynamic_lds((const void*)kern, FUSED_LDS, done)) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(512), FUSED_LDS, st, a);
@@ -588,10 +540,6 @@ int launch_mode(const QkvAttnArgs& a, hipStream_t st) {
   const int S = a.mode == 0 ? a.B * a.F : a.B * (a.T >> 4);
   const int units = S * a.heads;
   const dim3 grid(units >= 256 ? 256 : (units + 7) / 8 * 8);   // one workgroup per CU, a multiple of the 8 XCDs
-  if (a.ln.r != nullptr) {   // LayerNorm-consuming mode: the default schedule flags only (3 spatial, 1 temporal)
-    if (!a.ln.u || !a.ln.v || !a.ln.rm) return fail(LATTE_ERR_INVALID, "fused qkv + attention: the LayerNorm-consuming mode needs r, r mu and the u / v vectors");
-    return a.mode == 0 ? launch_one<HD, DT, 0, 3, true>(a, grid, st) : launch_one<HD, DT, 1, 1, true>(a, grid, st);
-  }
   if (a.mode == 0) {
     switch (a.flags & 3) {
       case 0: return launch_one<HD, DT, 0, 0>(a, grid, st);

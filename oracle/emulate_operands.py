@@ -11,9 +11,7 @@ case moves.  Where the engine rounds:
   output and the GELU output rounded to half (they are the next GEMM's A operand);
 * everything else (patch embed, conditioning, adaLN linears, LayerNorm statistics, final layer) is fp32.
 
-``ln_fused=True`` models the round-4 LayerNorm fusion: the gated GEMM's epilogue emits the half operand
-``x·(1+scale)`` and per-row Σx / Σx², the consuming GEMM applies ``r·(acc − μ·u[n]) + v[n]`` with ``u = (1+scale)·Wᵀ``,
-``v = shift·Wᵀ + b`` (fp32 on the rounded weights).
+(Round 4 also modelled a LayerNorm fusion here -- the engine path it predicted was measured without gain and removed in round 5.)
 """
 import torch
 import torch.nn.functional as F
@@ -27,50 +25,67 @@ def _rnd(x, dt):
     return x if dt is None else x.to(dt).float()
 
 
+# Rounding points of a block (round 5: per-point control, to attribute a parity budget on CPU).  ``exact`` = a set of point names that
+# are NOT rounded (equivalently: carried as a split hi + lo operand pair, whose residual error is 2^-22):
+#   a_qkv  LN-modulate output feeding the qkv linear        w_qkv  its weight
+#   qkv    q / k / v as they sit in LDS                     p      the softmax probabilities fed to P V
+#   a_proj attention output feeding the out-projection      w_proj
+#   a_fc1  LN-modulate output feeding fc1                   w_fc1
+#   a_fc2  GELU output feeding fc2                          w_fc2
+POINTS = ("a_qkv", "w_qkv", "qkv", "p", "a_proj", "w_proj", "a_fc1", "w_fc1", "a_fc2", "w_fc2")
+_EXACT = frozenset()          # module state of one emulated forward (set by latte_forward_emulated)
+_EXACT_BLOCKS = None          # None = every block; else the set of block indices in which `_EXACT` applies
+_CUR_BLOCK = -1
+
+
+def _rp(x, dt, point):
+    """round at a named point unless that point is exempt in the current block"""
+    if point in _EXACT and (_EXACT_BLOCKS is None or _CUR_BLOCK in _EXACT_BLOCKS):
+        return x
+    return _rnd(x, dt)
+
+
 def _attention_core(q, k, v, hd, dt):
     attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
     attn = attn.softmax(dim=-1)
     # the engine feeds exp2(s - max) (un-normalised, <= 1) to the PV MFMA as half and divides by the fp32 row sum after
     m = attn.max(dim=-1, keepdim=True).values
-    p = _rnd(attn / m, dt)
+    p = _rp(attn / m, dt, "p")
     return (p @ v) * m
 
 
-def _block(sd, i, x, c_rows, num_heads, dt, ln_fused, prescale):
+def _block(sd, i, x, c_rows, num_heads, dt):
+    global _CUR_BLOCK
+    _CUR_BLOCK = i
     pre = f"blocks.{i}."
     S, L, D = x.shape
     hd = D // num_heads
     mod = F.linear(F.silu(c_rows), sd[pre + "adaLN_modulation.1.weight"], sd[pre + "adaLN_modulation.1.bias"])
     sh1, sc1, g1, sh2, sc2, g2 = (m.unsqueeze(1) for m in mod.chunk(6, dim=1))
 
-    def modulated_linear(x, sh, sc, w, b):
-        """LN(x)·(1+sc)+sh -> half -> · W^T + b, either as the engine's separate LN pass or as the fused algebra."""
-        wq = _rnd(w, dt)
-        if not ln_fused:
-            a = _rnd(F.layer_norm(x, (D,), eps=1e-6) * (1 + sc) + sh, dt)
-            return a @ wq.t() + b
-        mu = x.mean(dim=-1, keepdim=True)
-        var = (x * x).mean(dim=-1, keepdim=True) - mu * mu          # Σx² / D − μ², as the epilogue partials give it
-        r = torch.rsqrt(var.clamp_min(0) + 1e-6)
-        a = _rnd(x * (1 + sc) * prescale, dt)
-        acc = (a @ wq.t()) / prescale
-        u = (1 + sc) @ wq.t()                                       # [S,1,N] per sample
-        v = sh @ wq.t() + b
-        return r * (acc - mu * u) + v
+    def modulated_linear(x, sh, sc, w, b, name):
+        """LN(x)·(1+sc)+sh -> half -> · W^T + b (the engine's separate LayerNorm-modulate pass in front of the linear)."""
+        wq = _rp(w, dt, "w_" + name)
+        a = _rp(F.layer_norm(x, (D,), eps=1e-6) * (1 + sc) + sh, dt, "a_" + name)
+        return a @ wq.t() + b
 
-    qkv = modulated_linear(x, sh1, sc1, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"])
-    qkv = _rnd(qkv, dt).reshape(S, L, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = modulated_linear(x, sh1, sc1, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"], "qkv")
+    qkv = _rp(qkv, dt, "qkv").reshape(S, L, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     o = _attention_core(qkv[0], qkv[1], qkv[2], hd, dt).transpose(1, 2).reshape(S, L, D)
-    o = _rnd(o, dt) @ _rnd(sd[pre + "attn.proj.weight"], dt).t() + sd[pre + "attn.proj.bias"]
+    o = _rp(o, dt, "a_proj") @ _rp(sd[pre + "attn.proj.weight"], dt, "w_proj").t() + sd[pre + "attn.proj.bias"]
     x = x + g1 * o
-    h = modulated_linear(x, sh2, sc2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
-    h = _rnd(F.gelu(h, approximate="tanh"), dt)
-    h = h @ _rnd(sd[pre + "mlp.fc2.weight"], dt).t() + sd[pre + "mlp.fc2.bias"]
+    h = modulated_linear(x, sh2, sc2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"], "fc1")
+    h = _rp(F.gelu(h, approximate="tanh"), dt, "a_fc2")
+    h = h @ _rp(sd[pre + "mlp.fc2.weight"], dt, "w_fc2").t() + sd[pre + "mlp.fc2.bias"]
     return x + g2 * h
 
 
-def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", ln_fused=False, prescale=1.0):
-    """``latte_oracle.latte_forward`` with the engine's half-precision roundings applied (class-cond / uncond only)."""
+def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", exact=(), exact_blocks=None):
+    """``latte_oracle.latte_forward`` with the engine's half-precision roundings applied (class-cond / uncond only).
+    ``exact``: names of ``POINTS`` that are not rounded (in ``exact_blocks`` only, when given) -- what a split hi + lo operand buys."""
+    global _EXACT, _EXACT_BLOCKS
+    assert all(e in POINTS for e in exact), exact
+    _EXACT, _EXACT_BLOCKS = frozenset(exact), (None if exact_blocks is None else frozenset(exact_blocks))
     dt = _DT[operand]
     B, Fr, C, H, W = x.shape
     p, D = cfg.patch_size, cfg.hidden_size
@@ -88,11 +103,11 @@ def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", ln_fused=False
     c_temp = c.repeat_interleave(T, dim=0)
     h = tok
     for i in range(0, cfg.depth, 2):
-        h = _block(sd, i, h, c_spatial, cfg.num_heads, dt, ln_fused, prescale)
+        h = _block(sd, i, h, c_spatial, cfg.num_heads, dt)
         h = h.reshape(B, Fr, T, D).permute(0, 2, 1, 3).reshape(B * T, Fr, D)
         if i == 0:
             h = h + sd["temp_embed"]
-        h = _block(sd, i + 1, h, c_temp, cfg.num_heads, dt, ln_fused, prescale)
+        h = _block(sd, i + 1, h, c_temp, cfg.num_heads, dt)
         h = h.reshape(B, T, Fr, D).permute(0, 2, 1, 3).reshape(B * Fr, T, D)
     mod = F.linear(F.silu(c.repeat_interleave(Fr, dim=0)), sd["final_layer.adaLN_modulation.1.weight"],
                    sd["final_layer.adaLN_modulation.1.bias"])
@@ -105,8 +120,18 @@ def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", ln_fused=False
     return h.reshape(B, Fr, co, H, W)
 
 
-def budget_table(cases, gate_stds=(0.02, 0.1, 0.3, 1.0), operands=("bf16", "f16"), ln_fused=(False, True), seed=0):
-    """rel-L2 of the emulated forward against the fp32 oracle per (case, gate_std, operand type, LN fusion)."""
+def latte_forward_with_cfg_emulated(sd, cfg, x, t, y, cfg_scale, **emu):
+    """``latte_oracle.latte_forward_with_cfg`` (latte.py:379-398) on the emulated forward."""
+    half = x[: len(x) // 2]
+    out = latte_forward_emulated(sd, cfg, torch.cat([half, half], dim=0), t, y, **emu)
+    eps, rest = out[:, :, :4], out[:, :, 4:]
+    cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+    half_eps = uncond + cfg_scale * (cond - uncond)
+    return torch.cat([torch.cat([half_eps, half_eps], dim=0), rest], dim=2)
+
+
+def budget_table(cases, gate_stds=(0.02, 0.1, 0.3, 1.0), operands=("bf16", "f16"), seed=0):
+    """rel-L2 of the emulated forward against the fp32 oracle per (case, gate_std, operand type)."""
     rows = []
     for name, kw, B in cases:
         cfg = lo.preset_config(name, **kw)
@@ -119,12 +144,10 @@ def budget_table(cases, gate_stds=(0.02, 0.1, 0.3, 1.0), operands=("bf16", "f16"
             with torch.no_grad():
                 ref = lo.latte_forward(sd, cfg, x, t, y)
                 for op in operands:
-                    for lf in ln_fused:
-                        out = latte_forward_emulated(sd, cfg, x, t, y, operand=op, ln_fused=lf)
-                        e = float((out - ref).double().norm() / ref.double().norm())
-                        rows.append(dict(model=name, latent=kw["input_size"], frames=kw["num_frames"], gate_std=gs, operand=op,
-                                         ln_fused=lf, rel_l2=e))
-                        print(rows[-1], flush=True)
+                    out = latte_forward_emulated(sd, cfg, x, t, y, operand=op)
+                    e = float((out - ref).double().norm() / ref.double().norm())
+                    rows.append(dict(model=name, latent=kw["input_size"], frames=kw["num_frames"], gate_std=gs, operand=op, rel_l2=e))
+                    print(rows[-1], flush=True)
     return rows
 
 

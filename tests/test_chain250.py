@@ -11,6 +11,9 @@ zero-initialises drawn N(0, 0.3), so the gates of latte.py:178-180 are O(0.1 - 1
 reaches the latents at full weight) and (b) the benchmarked chain at its full length and size: DDIM-250 of Latte-XL/2 at
 16 x 32 x 32 latents run by the reference (tests/golden/chain250_xl.npz), default gates and gate_std 0.3.  bf16 chains are run
 beside the default type on the unguided cases and recorded (asserted only at the near-zero gates where bf16 is a 1e-3 type).
+
+Round 5 adds BASELINE config 3's own chain: Latte-XL/2 class-conditional through forward_with_cfg at cfg_scale 7.0
+(sample/sample_ddp.py:140-168, latte.py:379-398), 250 DDIM steps run by the reference at gate_std 0.3 (``xl_guided_g03``).
 """
 import json
 import os
@@ -27,7 +30,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 CHAIN = [(n, m) for n in ("s2_uncond", "s2_guided", "b2_uncond", "b2_guided", "s2_uncond_g03", "b2_uncond_g03", "b2_guided_g03")
-         for m in ("ddim", "ddpm")] + [("xl_segment", "ddim"), ("xl_full", "ddim"), ("xl_full_g03", "ddim")]
+         for m in ("ddim", "ddpm")] + [("xl_segment", "ddim"), ("xl_full", "ddim"), ("xl_full_g03", "ddim"),
+                                   ("xl_guided_g03", "ddim")]
 
 
 def _record(key, drift):

@@ -319,152 +319,6 @@ def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
     assert rel < (8e-3 if dt == 0 else 1.5e-3), rel
 
 
-# ---- LayerNorm fusion (include/latte_amd_debug.h): the `modulate(norm(x), shift, scale)` of latte.py:28-29,
-# 179-180 folded into the gated GEMM that produces x and the linear that consumes LN(x)
-def _ln_rowstats(x, eps=1e-6):
-    """(r, r mean) of fp32 rows x, in fp64 (what ln_rowstat_kernel leaves per row)."""
-    xd = x.double()
-    mu = xd.mean(1)
-    r = torch.rsqrt(xd.var(1, unbiased=False) + eps)
-    return r.float().contiguous(), (r * mu).float().contiguous()
-
-
-# (M, N, K, rows_per_sample): the XL/2 out-projection and fc2 shapes on a few tile rows, S/2 width, several samples per launch
-LN_PRODUCER_CASES = [(1024, 1152, 1152, 512), (512, 1152, 4608, 256), (768, 384, 384, 256), (4096, 768, 3072, 4096)]
-
-
-@pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("shape", LN_PRODUCER_CASES)
-def test_gated_gemm_emits_the_next_layernorm_operand(lib, dev, dt, shape):
-    """EPI_GATE_RES_LN (csrc/gemm_pw.hip): the residual update of latte.py:179-180 plus, from the same registers, the next
-    modulate's operand x_new (1 + scale) in half and every wave's 48-column share of the row sums; ln_rowstat_kernel turns the
-    slots into (r, r mean)."""
-    M, N, K, rps = shape
-    g = torch.Generator("cpu").manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
-    bias = torch.randn(N, generator=g).to(dev)
-    S = M // rps
-    gate = torch.randn(S, N, generator=g).to(dev)
-    scale = (torch.randn(S, N, generator=g) * 0.5).to(dev)
-    res0 = (torch.randn(M, N, generator=g) * 2 + 0.3).to(dev)
-    si = torch.arange(M, device=dev) // rps
-    want = res0 + gate[si] * (A.float() @ W.float().t() + bias)
-    nslots = N // 48
-    runs = []
-    for tag in (0, 1, 0):
-        res = res0.clone()
-        xn = torch.full((M, N), float("nan"), dtype=TD[dt], device=dev)
-        slots = torch.full((nslots, M, 2), float("nan"), device=dev)
-        check(lib.latte_debug_gemm_gate_ln(ptr(A), ptr(W), ptr(bias), ptr(res), ptr(gate), ptr(scale), N, ptr(xn), ptr(slots),
-                                           M, N, K, rps, tag, dt, stream_ptr()))
-        r = torch.full((M,), float("nan"), device=dev)
-        rm = torch.full((M,), float("nan"), device=dev)
-        check(lib.latte_debug_ln_rowstat(ptr(slots), nslots, M, N, 1e-6, ptr(r), ptr(rm), stream_ptr()))
-        torch.cuda.synchronize()
-        assert float((res - want).norm() / want.norm()) < 2e-5
-        # the operand is the half rounding of the kernel's OWN fp32 result times (1 + scale)
-        ref_xn = torch.addcmul(res, res, scale[si])                                     # fma(x, s, x) up to one fp32 rounding
-        assert float((xn.float() - ref_xn).norm() / ref_xn.norm()) < (4e-3 if dt == 0 else 5e-4)
-        # slots: fp32 sums of 48 values each, against fp64 sums of the kernel's own result
-        chunks = res.double().view(M, nslots, 48)
-        s1, s2 = chunks.sum(2).t(), (chunks * chunks).sum(2).t()
-        assert float((slots[:, :, 0].double() - s1).abs().max()) < 1e-5 * float(chunks.abs().sum(2).max())
-        assert float(((slots[:, :, 1].double() - s2) / s2).abs().max()) < 1e-5
-        r_ref, rm_ref = _ln_rowstats(res)
-        assert float(((r - r_ref) / r_ref).abs().max()) < 1e-5 and float((rm - rm_ref).abs().max()) < 1e-5 * float(rm_ref.abs().max()) + 1e-6
-        runs.append((res, slots, xn.clone(), r, rm))
-    # bit-reproducible and independent of the kernel symbol (tag): nothing is accumulated in memory, the slot order is fixed
-    for k in (1, 2):
-        assert torch.equal(runs[0][0], runs[k][0]) and torch.equal(runs[0][1], runs[k][1]) and torch.equal(runs[0][3], runs[k][3])
-        assert torch.equal(runs[0][2].view(torch.int16), runs[k][2].view(torch.int16)) and torch.equal(runs[0][4], runs[k][4])
-
-
-def _ln_operands(M, K, rps, g, dev, dt, mean_shift=0.7):
-    """Rows x with a non-trivial mean and spread, per-sample modulation, the half operand a = x (1 + scale) and (r, r mean)."""
-    S = M // rps
-    x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 3) + mean_shift * torch.randn(M, 1, generator=g)).to(dev)
-    scale = (torch.randn(S, K, generator=g) * 0.5).to(dev)
-    shift = (torch.randn(S, K, generator=g) * 0.5).to(dev)
-    si = torch.arange(M, device=dev) // rps
-    a = (x * (1 + scale[si])).to(TD[dt])
-    return x, scale, shift, si, a, _ln_rowstats(x)
-
-
-@pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("gelu", [0, 1])
-@pytest.mark.parametrize("shape", [(1024, 4608, 1152, 512), (512, 1536, 384, 256), (768, 3072, 768, 256)])
-def test_gemm_consumes_a_layernorm_operand(lib, dev, dt, gelu, shape):
-    """EPI_LN_[GELU_]H16 (csrc/gemm.hip): out = f(r (a W^T - mu u) + v) is the reference's Linear(modulate(LN(x), shift, scale))
-    (latte.py:28-29,171,180) with (r, r mean) per row from ln_rowstat_kernel -- against fp32 torch on the same half operands, and
-    against the plain LayerNorm formula."""
-    M, N, K, rps = shape
-    g = torch.Generator("cpu").manual_seed(M + N + K + gelu)
-    x, scale, shift, si, a, stats = _ln_operands(M, K, rps, g, dev, dt)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
-    bias = torch.randn(N, generator=g).to(dev)
-    Wf = W.float()
-    mod = torch.cat([scale, shift], dim=1).contiguous()                 # conditioning rows: [scale | shift]
-    uv = torch.full((M // rps, 2 * N), float("nan"), device=dev)
-    check(lib.latte_debug_modvec(ptr(W), ptr(bias), N, K, ptr(mod), 2 * K, 0, K, M // rps, ptr(uv), 2 * N, dt, stream_ptr()))
-    torch.cuda.synchronize()
-    u_ref, v_ref = (1 + scale.double()) @ Wf.double().t(), shift.double() @ Wf.double().t() + bias.double()
-    assert float((uv[:, :N].double() - u_ref).abs().max()) < 2e-5 * float(u_ref.abs().max()) + 2e-5
-    assert float((uv[:, N:].double() - v_ref).abs().max()) < 2e-5 * float(v_ref.abs().max()) + 2e-5
-    out = torch.full((M, N), float("nan"), dtype=TD[dt], device=dev)
-    check(lib.latte_debug_gemm_ln_consume(ptr(a), ptr(W), ptr(stats[0]), ptr(stats[1]), ptr(uv), ptr(uv[:, N:]), 2 * N, ptr(out), M, N, K, rps,
-                                          gelu, dt, stream_ptr()))
-    torch.cuda.synchronize()
-    mu = x.double().mean(1, keepdim=True)
-    r = torch.rsqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-6)
-    same_operands = (r * (a.double() @ Wf.double().t() - mu * u_ref[si]) + v_ref[si]).float()
-    act = (lambda z: torch.nn.functional.gelu(z, approximate="tanh")) if gelu else (lambda z: z)
-    assert float((out.float() - act(same_operands)).norm() / act(same_operands).norm()) < OUT_TOL[dt]
-    # the reference's formula in fp32: what remains is the operand rounding of a and W
-    ln = torch.nn.functional.layer_norm(x, (K,), eps=1e-6) * (1 + scale[si]) + shift[si]
-    ref = act(ln @ Wf.t() + bias)
-    assert float((out.float() - ref).norm() / ref.norm()) < (1.2e-2 if dt == 0 else 2e-3)
-
-
-@pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("case", [(2, 16, 256, 16, 72), (1, 16, 256, 6, 64), (3, 16, 64, 4, 64)])
-@pytest.mark.parametrize("mode", [0, 1], ids=["spatial", "temporal"])
-def test_fused_qkv_attention_consumes_a_layernorm_operand(lib, dev, dt, case, mode):
-    """csrc/qkv_attn.hip in its LayerNorm-consuming mode: q | k | v = r (a W^T - mu u) + v in the image-write phase (the unit's row
-    statistics and the head's u / v slices arrive by LDS DMA one unit ahead), then the same attention core."""
-    B, F, T, H, hd = case
-    if mode == 0 and T != 256:
-        pytest.skip("spatial units are the 256 tokens of a frame")
-    D, rows, rps = H * hd, B * F * T, F * T
-    g = torch.Generator("cpu").manual_seed(rows + hd + mode)
-    x, scale, shift, si, a, stats = _ln_operands(rows, D, rps, g, dev, dt)
-    W = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev).to(TD[dt])
-    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
-    mod = torch.cat([scale, shift], dim=1).contiguous()
-    uv = torch.zeros(B, 6 * D, device=dev)
-    check(lib.latte_debug_modvec(ptr(W), ptr(bias), 3 * D, D, ptr(mod), 2 * D, 0, D, B, ptr(uv), 6 * D, dt, stream_ptr()))
-    out = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
-    dbg = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
-    for _ in range(2):   # twice: warm LDS / caches (stale side-data screen)
-        check(lib.latte_debug_qkv_attention_ln(ptr(a), ptr(W), ptr(stats[0]), ptr(stats[1]), ptr(uv), ptr(uv[:, 3 * D:]), 6 * D, ptr(out), ptr(dbg),
-                                               B, F, T, D, H, mode, dt, stream_ptr()))
-        torch.cuda.synchronize()
-    mu = x.double().mean(1, keepdim=True)
-    r = torch.rsqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-6)
-    qkv = (r * (a.double() @ W.double().t() - mu * uv[:, :3 * D].double()[si]) + uv[:, 3 * D:].double()[si]).float()
-    assert float((dbg.float() - qkv).norm() / qkv.norm()) < OUT_TOL[dt]
-    ln = torch.nn.functional.layer_norm(x, (D,), eps=1e-6) * (1 + scale[si]) + shift[si]
-    assert float((dbg.float() - (ln @ W.float().t() + bias)).norm() / qkv.norm()) < (1.2e-2 if dt == 0 else 2e-3)
-    q5 = dbg.float().view(B, F, T, 3, H, hd)                  # attention on the kernel's own half q | k | v
-    if mode == 0:
-        q, k, v = [q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3)]
-        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(rows, D)
-    else:
-        q, k, v = [q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3)]
-        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(rows, D)
-    assert float((out.float() - ref).norm() / ref.norm()) < (8e-3 if dt == 0 else 1.5e-3)
-
-
 def test_fused_qkv_attention_rejects_other_shapes(lib, dev):
     x = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
     w = torch.zeros(384, 128, dtype=torch.bfloat16, device=dev)

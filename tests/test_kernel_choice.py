@@ -72,20 +72,6 @@ def test_weight_gradient_split_plan(shape):
     assert splits * ((N + 255) // 256) * ((K + 255) // 256) <= 768
 
 
-def test_layernorm_fusion_rule(lib):
-    """engine.cpp: ln_fusable_shape -- with the engine option fuse_ln = 1 the LayerNorms are folded into the GEMM epilogues exactly where every kernel of a block has
-    its LN-aware form: 256-token x 16-frame configs (both block kinds on the fused qkv + attention kernel), gated GEMMs on the
-    rolling 12-wave kernel, fc1 on the 256-wide persistent kernel.  XL/2: the benchmarked B = 8 and config 3's 16 sequences."""
-    xl = dict(D=1152, Hm=4608, heads=16)
-    fus = lambda B, D, Hm, heads, F=16, T=256: lib.latte_debug_ln_fusable(D, Hm, heads, F, T, B * F * T)
-    assert fus(8, **xl) == 1 and fus(16, **xl) == 1 and fus(32, **xl) == 1
-    assert fus(1, **xl) == 0          # B = 1: the gated GEMMs run the 128 x 144 one-tile-per-CU kernel
-    assert fus(2, **xl) == 0          # B = 2: fc1 prefers the 12-wave kernel, which has no LN-consuming epilogue
-    assert fus(8, 384, 1536, 6) == 1  # S/2 at 16 x 32 x 32 latents
-    assert lib.latte_debug_ln_fusable(1152, 4608, 16, 16, 64, 8 * 16 * 64) == 0     # 8 x 8 tokens per frame: no fused spatial kernel
-    assert lib.latte_debug_ln_fusable(1152, 4608, 16, 8, 256, 16 * 8 * 256) == 0    # 8 frames: no fused temporal kernel
-
-
 def test_debug_choice_offers_only_implementations_of_the_same_function(lib):
     """Round-3 advisor finding: the launchers read LATTE_* environment variables per launch, among them ablation variants with
     garbage results.  The overrides are an explicit debug entry now (include/latte_amd_debug.h); the product library refuses the

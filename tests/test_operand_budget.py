@@ -3,8 +3,8 @@ rounding points applied) -- the numerics decisions of round 4 without a GPU:
 
 * at trained-checkpoint gate magnitudes (gates of latte.py:178-180 at O(0.1 - 1)) bf16 operands put the model output at
   ~3e-3 of the fp32 reference, f16 operands at ~4e-4: f16 is the default operand type (latte_amd.Latte docstring);
-* the LayerNorm fusion (the gated GEMM emits x (1 + scale) in half and row sums, the consumer applies
-  r (acc - mu u) + v) costs < 15 % of that budget.
+* (round 5) the guided combination of latte.py:394-398 amplifies the part of the rounding that differs between the two halves: which
+  rounding points carry it (test_guided_budget_by_rounding_point).
 The GPU measurements of the same cases: tests/test_gpu_parity.py::test_forward_at_trained_scale_gates.
 """
 import pytest
@@ -40,7 +40,6 @@ def _errs(gate_std, **emu):
 
 def test_fp32_emulation_is_the_oracle():
     assert _errs(0.3, operand="fp32") < 1e-6
-    assert _errs(0.3, operand="fp32", ln_fused=True) < 2e-5      # the fused algebra itself, in fp32
 
 
 @pytest.mark.parametrize("gate_std", [0.3, 1.0])
@@ -53,9 +52,3 @@ def test_f16_holds_the_bar_at_trained_scale_gates_and_bf16_does_not(gate_std):
 
 def test_bf16_only_passes_at_near_zero_gates():
     assert _errs(0.02, operand="bf16") < TOL
-
-
-@pytest.mark.parametrize("gate_std", [0.02, 0.3, 1.0])
-def test_layernorm_fusion_stays_inside_the_budget(gate_std):
-    plain, fused = _errs(gate_std, operand="f16"), _errs(gate_std, operand="f16", ln_fused=True)
-    assert fused < TOL and fused < 1.2 * plain + 1e-5, (plain, fused)
