@@ -93,6 +93,12 @@ void latte_engine_destroy(latte_engine_t* e);
  * OFF one default schedule feature of the fused kernel each -- the next unit's first operand tile fetched under the attention
  * phase, the attention-phase issue priority of wave group 0, the four-heads-per-XCD unit order of 16-head models (A/B hooks);
  * every setting gives the same bits),
+ * "guided_split" (bits, default 3; guided calls -- latte_forward_with_cfg and the guided sample loop -- only: bit 0 = the attention output
+ * that feeds the out-projection, bit 1 = the LayerNorm-modulate output that feeds fc1 are carried as SPLIT operand pairs [hi | lo] (two
+ * halves per value) against weights stored [W | W], i.e. those two linears run on K' = 2 K without rounding their activation operand.
+ * The guidance combination of latte.py:394-398 amplifies the operand rounding that differs between the two halves; with f16 operands
+ * the XL/2 guided output at trained-scale gates sits AT 1e-3 of the fp32 reference (0.6 - 1.2e-3), with the split pairs at 0.4 - 0.8e-3
+ * for +X % of the guided step.  0 = the plain f16 operands of the unguided path),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);

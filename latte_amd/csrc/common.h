@@ -149,6 +149,7 @@ struct QkvAttnArgs {
   float scale;         // hd^-0.5
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
+  int out_split;       // 1: out is [B F T, 2 D] = [hi | lo] -- the attention output as a split operand pair (mfma_util.h: split2)
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
@@ -158,7 +159,7 @@ int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 // If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T,
-                       int F, int dtype, hipStream_t st);
+                       int F, int dtype, hipStream_t st, int split = 0);   // split: y is [M, 2 D] = [hi | lo] (mfma_util.h: split2)
 enum SmallIn : int { IN_PLAIN = 0, IN_SILU = 1, IN_TFREQ = 2 };
 // out[b, n] = bias[n] + sum_k in(b,k) * W[n, k]  (+ add_table[add_idx[b], n]); fp32 exact.
 int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,

@@ -33,6 +33,22 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
   }
 }
 
+// Split-operand pair of two fp32 values: hi = the half nearest to v, lo = the half nearest to (v - hi) -- hi + lo carries ~22 mantissa
+// bits of v.  The K-concatenated operand [hi | lo] against [W | W] is the product a single half operand would give, without the
+// activation's rounding (engine option "guided_split", engine.cpp).
+template <int DT>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned int& hi, unsigned int& lo) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    hi = pack2<DT>((float)h0, (float)h1);
+    lo = pack2<DT>(v0 - (float)h0, v1 - (float)h1);
+  } else {
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    hi = pack2<DT>((float)h0, (float)h1);
+    lo = pack2<DT>(v0 - (float)h0, v1 - (float)h1);
+  }
+}
+
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

@@ -30,13 +30,29 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
   }
 }
 
+// split-operand pair (mfma_util.h: split2): hi = nearest half, lo = nearest half of the remainder
+template <int DT>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned int& hi, unsigned int& lo) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    hi = pack2<DT>((float)h0, (float)h1);
+    lo = pack2<DT>(v0 - (float)h0, v1 - (float)h1);
+  } else {
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    hi = pack2<DT>((float)h0, (float)h1);
+    lo = pack2<DT>(v0 - (float)h0, v1 - (float)h1);
+  }
+}
+
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
 // One wave per token row; lane owns the 16-byte chunks {lane + 64 c} of the row (float4 loads, 8-byte half stores: the
 // widest accesses the row length allows -- D / 4 chunks, the last group of 64 only half populated when D / 128 is odd).
 // Two-pass statistics in registers.
-template <int NCH, int DT, bool ADD_TE>
+// SPLIT: y is [M, 2 D] -- columns [0, D) the half nearest to the value, [D, 2 D) the half nearest to the remainder (mfma_util.h:
+// split2): the K-concatenated operand of a linear whose weight is stored [W | W].
+template <int NCH, int DT, bool ADD_TE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restrict__ x_in, float* x_rw,
                                                           half_t* __restrict__ y, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, int mod_stride, int M,
@@ -86,7 +102,7 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
   const float4* sh = (const float4*)(shift + (size_t)smp * mod_stride);
   const float4* sc = (const float4*)(scale + (size_t)smp * mod_stride);
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-  u32x2_t* yr = (u32x2_t*)(y + (size_t)row * D);
+  u32x2_t* yr = (u32x2_t*)(y + (size_t)row * (SPLIT ? 2 * D : D));
 #pragma unroll
   for (int c = 0; c < NQ; ++c) {
     if (has(c)) {
@@ -95,7 +111,16 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
       const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
       const float o2 = (v[c].z - mean) * rstd * (1.0f + b.z) + a.z;
       const float o3 = (v[c].w - mean) * rstd * (1.0f + b.w) + a.w;
-      yr[c * 64 + lane] = (u32x2_t){pack2<DT>(o0, o1), pack2<DT>(o2, o3)};
+      if constexpr (SPLIT) {
+        unsigned int h0_, l0_, h1_, l1_;
+        split2<DT>(o0, o1, h0_, l0_);
+        split2<DT>(o2, o3, h1_, l1_);
+        const u32x2_t hi = {h0_, h1_}, lo = {l0_, l1_};
+        yr[c * 64 + lane] = hi;
+        yr[NT + c * 64 + lane] = lo;     // + D halves = NT 8-byte chunks
+      } else {
+        yr[c * 64 + lane] = (u32x2_t){pack2<DT>(o0, o1), pack2<DT>(o2, o3)};
+      }
     }
   }
 }
@@ -791,9 +816,25 @@ int launch_training_terms(const float* tables, int n_steps, int mean_type, int v
 
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T, int F,
-                       int dtype, hipStream_t st) {
+                       int dtype, hipStream_t st, int split) {
   if (D % 128 != 0) return fail(LATTE_ERR_INVALID, "ln_modulate: D % 128 != 0");
   dim3 grid((M + 3) / 4), block(256);
+  if (split) {   // [M, 2 D] split-operand output (no temp_embed form: the LayerNorm in front of fc1 never adds it)
+    if (temp_embed) return fail(LATTE_ERR_INVALID, "ln_modulate: the split-operand output has no temp_embed form");
+#define LN_LAUNCH_SPLIT(NCH)                                                                                   \
+  do {                                                                                                         \
+    if (dtype == LATTE_DTYPE_BF16)                                                                             \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, false, true>), grid, block, 0, st, x_in, x_rw, y, \
+                         shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                      \
+    else                                                                                                       \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false, true>), grid, block, 0, st, x_in, x_rw, y, \
+                         shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                      \
+  } while (0)
+    LATTE_NCH_SWITCH(D, LN_LAUNCH_SPLIT)
+#undef LN_LAUNCH_SPLIT
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
 #define LN_LAUNCH(NCH)                                                                                         \
   do {                                                                                                         \
     if (dtype == LATTE_DTYPE_BF16) {                                                                           \

@@ -72,7 +72,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_
 // the transpose reads of 8 rows x 32 B tile the 64 banks).  At hd = 72 a Q / K row has no pad: chunk 9 of the padded contraction
 // is the next row's first chunk (real, finite data; it meets a zero Q chunk).
 constexpr int RPQ = 144, RPV = 160;
-constexpr int Q_OFF = 0, K_OFF = 256 * RPQ, V_OFF = 2 * 256 * RPQ, IMG_END = V_OFF + 256 * RPV;   // 0, 36864, 73728, 114688
+[[maybe_unused]] constexpr int Q_OFF = 0;
+constexpr int K_OFF = 256 * RPQ, V_OFF = 2 * 256 * RPQ, IMG_END = V_OFF + 256 * RPV;   // 0, 36864, 73728, 114688
 // LDS map (bytes).  The images overlay the operand stages; stage 0's W tile sits BEHIND the images, so that all of stage 0 is
 // dead memory as soon as every wave has fetched its Q fragments (the A tile of stage 0 lies inside the Q image):
 //   [0, 36864) Q image        [36864, 73728) K image       [73728, 114688) V image
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
   const int D = a.D, T = a.T, F = a.F;
+  const int out_ld = a.out_split ? 2 * D : D;   // row pitch of the output in halves
   const unsigned row_bytes = (unsigned)D * 2u;
   const int nk = D / 64;
 
@@ -430,14 +432,23 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         }
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-          half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD;
+          half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * out_ld + head * HD;
 #pragma unroll
           for (int d = 0; d < DF; ++d) {
             const int dd = 16 * d + 4 * g;
             if (dd < HD) {
-              const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
-                                pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
-              *(u32x2*)(orow + dd) = pk;
+              if (a.out_split) {   // [hi | lo]: the out-projection's K-concatenated operand
+                unsigned int h0_, l0_, h1_, l1_;
+                split2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], h0_, l0_);
+                split2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq], h1_, l1_);
+                const u32x2 hi = {h0_, h1_}, lo = {l0_, l1_};
+                *(u32x2*)(orow + dd) = hi;
+                *(u32x2*)(orow + D + dd) = lo;
+              } else {
+                const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
+                                  pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
+                *(u32x2*)(orow + dd) = pk;
+              }
             }
           }
         }
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
         ls += __shfl_xor(ls, 32, 64);
         const u32x2 pb = {pack2<DT>(st[0], st[1]), pack2<DT>(st[2], st[3])};   // P^T[key = 4g + i][q = fr]
         const float inv = 1.0f / ls;
-        half_t* orow = a.out + (size_t)(row_base + fr * T + p) * D + head * HD;    // token fr (frame) of sequence p
+        half_t* orow = a.out + (size_t)(row_base + fr * T + p) * out_ld + head * HD;    // token fr (frame) of sequence p
         u32x2 vf[5];
         {
           const char* vp = v_img + (16 * p + 4 * g + (fr >> 2)) * RPV + (fr & 3) * 8;
@@ -498,8 +509,17 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
           oacc = mfma_k16h<DT>(vf[d], pb, oacc);                               // O^T[d = 16 d + 4g + r][q = fr]
           const int dd = 16 * d + 4 * g;
           if (dd < HD) {
-            const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
-            *(u32x2*)(orow + dd) = pk;
+            if (a.out_split) {
+              unsigned int h0_, l0_, h1_, l1_;
+              split2<DT>(oacc[0] * inv, oacc[1] * inv, h0_, l0_);
+              split2<DT>(oacc[2] * inv, oacc[3] * inv, h1_, l1_);
+              const u32x2 hi = {h0_, h1_}, lo = {l0_, l1_};
+              *(u32x2*)(orow + dd) = hi;
+              *(u32x2*)(orow + D + dd) = lo;
+            } else {
+              const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
+              *(u32x2*)(orow + dd) = pk;
+            }
           }
         }
       }

@@ -34,6 +34,7 @@ def _rnd(x, dt):
 #   a_fc2  GELU output feeding fc2                          w_fc2
 POINTS = ("a_qkv", "w_qkv", "qkv", "p", "a_proj", "w_proj", "a_fc1", "w_fc1", "a_fc2", "w_fc2")
 _EXACT = frozenset()          # module state of one emulated forward (set by latte_forward_emulated)
+_PAIRED = frozenset()         # points whose second batch half is carried as (rounded first half) + rounded DIFFERENCE (guided pairs)
 _EXACT_BLOCKS = None          # None = every block; else the set of block indices in which `_EXACT` applies
 _CUR_BLOCK = -1
 
@@ -42,6 +43,12 @@ def _rp(x, dt, point):
     """round at a named point unless that point is exempt in the current block"""
     if point in _EXACT and (_EXACT_BLOCKS is None or _CUR_BLOCK in _EXACT_BLOCKS):
         return x
+    if point in _PAIRED and dt is not None:
+        # rows [0, n/2) and [n/2, n) are the two halves of a guidance pair (same latent, different conditioning): the second half's
+        # operand is (first half's rounded value) + (rounded difference) -- its rounding error is the first half's, to ~2^-11 |difference|
+        n = x.shape[0] // 2
+        a = _rnd(x[:n], dt)
+        return torch.cat([a, a + _rnd(x[n:] - a, dt)], dim=0)
     return _rnd(x, dt)
 
 
@@ -80,11 +87,12 @@ def _block(sd, i, x, c_rows, num_heads, dt):
     return x + g2 * h
 
 
-def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", exact=(), exact_blocks=None):
+def latte_forward_emulated(sd, cfg, x, t, y=None, operand="bf16", exact=(), exact_blocks=None, paired=()):
     """``latte_oracle.latte_forward`` with the engine's half-precision roundings applied (class-cond / uncond only).
     ``exact``: names of ``POINTS`` that are not rounded (in ``exact_blocks`` only, when given) -- what a split hi + lo operand buys."""
-    global _EXACT, _EXACT_BLOCKS
-    assert all(e in POINTS for e in exact), exact
+    global _EXACT, _EXACT_BLOCKS, _PAIRED
+    assert all(e in POINTS for e in tuple(exact) + tuple(paired)), (exact, paired)
+    _PAIRED = frozenset(paired)
     _EXACT, _EXACT_BLOCKS = frozenset(exact), (None if exact_blocks is None else frozenset(exact_blocks))
     dt = _DT[operand]
     B, Fr, C, H, W = x.shape

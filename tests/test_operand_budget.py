@@ -52,3 +52,35 @@ def test_f16_holds_the_bar_at_trained_scale_gates_and_bf16_does_not(gate_std):
 
 def test_bf16_only_passes_at_near_zero_gates():
     assert _errs(0.02, operand="bf16") < TOL
+
+
+def test_guided_budget_by_rounding_point():
+    """Round 5: forward_with_cfg at CFG 7.0 (latte.py:379-398) amplifies the operand rounding that differs between the cond and uncond
+    halves -- the guided error is well above the unguided one -- and the activation operands carry it, the attention output (operand of
+    the out-projection) first.  Carrying that operand and fc1's as split pairs (engine option guided_split, modelled here as "not
+    rounded") buys back a third of the guided error: what the engine does for guided calls."""
+    from oracle.emulate_operands import POINTS, latte_forward_with_cfg_emulated
+    kw = dict(input_size=16, num_frames=8, num_classes=101, extras=2)
+    cfg = lo.preset_config("Latte-S/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=0, gate_std=0.3)
+    g = torch.Generator("cpu").manual_seed(1)
+    z = torch.randn(1, 8, 4, 16, 16, generator=g)
+    x, t, y = torch.cat([z, z]), torch.tensor([500, 500]), torch.tensor([7, 101])
+    with torch.no_grad():
+        ref = lo.latte_forward_with_cfg(sd, cfg, x, t, y, 7.0)
+        ref1 = lo.latte_forward(sd, cfg, x[:1], t[:1], y[:1])
+
+        def err(**emu):
+            out = latte_forward_with_cfg_emulated(sd, cfg, x, t, y, 7.0, operand="f16", **emu)
+            return float((out[:, :, :4] - ref[:, :, :4]).double().norm() / ref[:, :, :4].double().norm())
+        plain = err()
+        single = latte_forward_emulated(sd, cfg, x[:1], t[:1], y[:1], operand="f16")
+        unguided = float((single[:, :, :4] - ref1[:, :, :4]).double().norm() / ref1[:, :, :4].double().norm())
+        weights = err(exact=tuple(p for p in POINTS if p.startswith("w_")))
+        acts = err(exact=tuple(p for p in POINTS if not p.startswith("w_")))
+        split = err(exact=("a_proj", "a_fc1"))
+    print(dict(unguided=unguided, guided=plain, weights_exact=weights, activations_exact=acts, split_proj_fc1=split))
+    assert plain > 1.4 * unguided                 # the guidance combination amplifies
+    assert acts < 0.6 * plain < weights           # ... the activation roundings, not the weights'
+    assert split < 0.85 * plain                   # what guided_split = 3 removes
+
