@@ -249,9 +249,12 @@ int latte_trainer_num_stages(const latte_trainer_t* e);
 int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offset, int64_t* numel);
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream);
 /* clip_grad_norm_ (utils.py:72-117: total 2-norm, g *= min(max_norm / (norm + 1e-6), 1) when clip != 0) + AdamW + update_ema
- * (utils.py:191-200) on the bound buffers.  `step`: AdamW's bias-correction step when >= 1; 0 = the trainer's own count of APPLIED
- * updates (what torch.optim.AdamW does: a fresh optimiser state starts at 1 even when the training-step counter continues from a
- * checkpoint, train.py:195-196 -- the count that drives clipping and logging stays with the caller).  A NON-FINITE gradient norm
+ * (utils.py:191-200) on the bound buffers.  `step` = 0 (what LatteTrainer passes): AdamW's bias correction uses the trainer's own count
+ * of APPLIED updates (what torch.optim.AdamW does: a fresh optimiser state starts at 1 even when the training-step counter continues
+ * from a checkpoint, train.py:195-196 -- the count that drives clipping and logging stays with the caller; a skipped update does not
+ * advance it).  `step` >= 1: the caller supplies the bias-correction step -- valid only while NO update is ever skipped (the caller cannot
+ * see a skip without latte_trainer_scaler_state; after one, a caller-side count runs ahead of the moments' age, which differs from
+ * GradScaler + torch.optim.AdamW): with loss scaling on, pass 0.  A NON-FINITE gradient norm
  * (overflow of the loss-scaled f16 backward or of an f16 activation; impossible in the reference's fp32 range) skips the update:
  * parameters, moments and EMA stay untouched, the gradients are zeroed, norm_out reports the non-finite norm with coefficient 0.
  * norm_out: optional device float[2] = {norm, applied coefficient} */

@@ -47,7 +47,7 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
 /* Backward of the attention core (autograd of latte.py:61-70 on the [rows, 3 D] qkv layout): dqkv [rows, 3 D] from qkv, the
  * forward output o [rows, D] and its gradient dout [rows, D]; stats: float scratch [num_seq * heads * L * 3].  Sequences are
  * addressed as in latte_debug_attention.  L <= 16 runs one wave per (sequence, head), larger L the two tile passes
- * (LATTE_ATTN_BWD_TILES=1 forces the tile passes: test hook). */
+ * (latte_debug_set_choice("attn_bwd_tiles", 1) forces the tile passes: test hook). */
 int latte_debug_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, float* stats, int num_seq, int L,
                               int heads, int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype,
                               void* stream);

@@ -120,8 +120,9 @@ for c, ctrs in acc.items():
         # 16 x the launch's MFMA count, checked against 2 M N K / 16384); GRBM_GUI_ACTIVE is summed over the 8 XCDs
         # (value / launch time = 8 x the shader clock), so elapsed cycles per SIMD = GRBM_GUI_ACTIVE / 8
         rec["mfma_busy_frac_of_simd_cycles"] = round(ca["SQ_VALU_MFMA_BUSY_CYCLES"] / (ca["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
-        if rec.get("avg_ns_in_pmc_pass"):
-            rec["shader_clock_ghz_in_pmc_pass"] = round(ca["GRBM_GUI_ACTIVE"] / 8 / rec["avg_ns_in_pmc_pass"], 3)
+        # (rounds 2-4 also printed GRBM_GUI_ACTIVE / 8 / launch time as a "shader clock": for launches of tens of microseconds the
+        #  counter covers more than the kernel's own interval and the quotient came out above the 2.4 GHz maximum -- dropped; the clock
+        #  of a launch is what rocm-smi samples beside it, bench.py: power_check)
     if "SQ_WAVE_CYCLES" in ca and ca["SQ_WAVE_CYCLES"] > 0:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in ca:

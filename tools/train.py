@@ -110,6 +110,8 @@ def main():
         print(f"Model Parameters: {sum(p.numel() for p in model.parameters()):,}; world {world}, local batch {nb}")
     parallel.barrier()
     running, t0, log_steps = 0.0, time.time(), 0
+    stuck_logs = 0      # consecutive log lines whose whole interval was skipped updates at the floor scale (or with scaling off)
+    seen_skips = 0.0
     for step in range(first_step + 1, max_steps + 1):
         x, y = data.batch(step, nb)
         out = trainer.train_step(x.to(device), y=y.to(device) if int(args.extras) == 2 else None)
@@ -122,9 +124,25 @@ def main():
             if world > 1:
                 torch.distributed.all_reduce(avg)
                 avg /= world
+            # Overflow handling of the half-precision backward (LatteTrainer docstring): a non-finite gradient norm skips the update on
+            # the device, silently.  The log line carries the counters, and a run that can no longer apply ANY update -- every step of
+            # two log intervals skipped with the scale at its floor of 1 (or with dynamic scaling off) -- stops instead of burning its
+            # budget on zero updates (a diverged model or an f16 forward overflow no loss scale cures).
+            sc = trainer.scaler_state()
+            new_skips = sc["skipped_updates"] - seen_skips
+            seen_skips = sc["skipped_updates"]
+            stuck = new_skips >= log_steps and (sc["loss_scale"] <= 1.0 or not sc["dynamic"])
+            stuck_logs = stuck_logs + 1 if stuck else 0
             if rank == 0:
                 print(f"(step={step:07d}) Train Loss: {float(avg):.4f}, Gradient Norm: {float(out['grad_norm']):.4f}, "
-                      f"Train Steps/Sec: {sps:.2f}, samples/s: {sps * nb * world:.1f}", flush=True)
+                      f"Train Steps/Sec: {sps:.2f}, samples/s: {sps * nb * world:.1f}, loss scale: {sc['loss_scale']:g}, "
+                      f"skipped updates: {int(sc['skipped_updates'])} (+{int(new_skips)})", flush=True)
+                if new_skips and not stuck:
+                    print(f"  warning: {int(new_skips)} of the last {log_steps} updates were skipped (non-finite gradient norm)", flush=True)
+            if stuck_logs >= 2:
+                raise RuntimeError(f"training is stuck: every update of the last {2 * log_steps} steps was skipped (non-finite gradient norm) "
+                                   f"with the loss scale at {sc['loss_scale']:g}" + ("" if sc["dynamic"] else " and dynamic scaling off")
+                                   + " -- the model has diverged or an f16 activation overflows; lower the learning rate or train with compute_dtype='bf16'")
             running, t0, log_steps = 0.0, time.time(), 0
         if step % ckpt_every == 0 or step == max_steps:
             if rank == 0:
