@@ -36,6 +36,8 @@ Beside the headline, in the same JSON line:
   * `power_check` (N = 1): socket power and shader clock (rocm-smi) during ~1.5 s of the headline forward, and the dominant GEMM
     stand-alone on random and on all-zero operands -- on random operands the 1400 W socket cap throttles the MFMA kernels to
     ~1.7-1.9 GHz (of 2.4); on quiet operands the same launches keep the full clock (profiles/r4_operand_power_probe_*.log);
+  * `energy` (N = 1, round 5): joules per step / per sample-step / per 250-step video and pJ per algorithmic FLOP = the forward's mean
+    socket power x this run's step time; `roofline_table` rows carry `joules_per_launch` (the same power x the class's launch time);
   * `cpu_baseline` (N = 1): the oracle's sampling-loop body (forward + ddim_sample) on the host cores, standing in for the reference's
     loop (the reference itself is not on the GPU box; the oracle is bit-identical to it and runs ~6 % faster
     than it because it skips the reference's repeated adaLN rows: oracle/VALIDATION.md).
@@ -389,6 +391,32 @@ def power_check(device, model, x, dtype):
     return out
 
 
+def energy_columns(res, world):
+    """Energy beside time (round 5).  The MFMA kernels of the step run on the socket's power cap (power_check), where a launch is as
+    fast as its ENERGY allows: joules = mean socket power of the forward (rocm-smi, random operands, sampled during ~1.5 s of
+    back-to-back forwards) x time.  Per kernel class the forward-average power is applied to the class's average launch time -- an
+    estimate (the classes draw 1300-1400 W each when run alone: tools/operand_power_probe.py), good to a few per cent; the step figure
+    is the product of two quantities measured in this run.  pJ per algorithmic FLOP = joules per sample-step / 3.726 TFLOP."""
+    pc = res.get("power_check") or {}
+    fw = pc.get("forward") or {}
+    pw = fw.get("socket_power_w")
+    if not pw:
+        return None
+    B = res["config"]["per_gpu_batch"]
+    for row in res.get("roofline_table", []):
+        row["joules_per_launch"] = round(pw * row["avg_launch_ms"] * 1e-3, 4)
+    j_step = pw * res["ms_per_step"] * 1e-3
+    out = {"socket_power_w_forward": pw, "shader_clock_mhz_forward": fw.get("shader_clock_mhz"),
+           "joules_per_step": round(j_step, 2), "joules_per_sample_step": round(j_step / B, 3),
+           "picojoules_per_algorithmic_flop": round(j_step / B / FLOPS_PER_SAMPLE_STEP["Latte-XL/2"] * 1e12, 3),
+           "joules_per_250_step_video": round(j_step / B * 250, 1),
+           "source": "rocm-smi socket power during the power_check forward leg x this run's ms_per_step; per-class rows: the same power x avg_launch_ms"}
+    for leg in ("fc2_standalone_random_operands", "fc2_standalone_zeros_operands"):
+        if leg in pc and pc[leg].get("socket_power_w"):
+            pc[leg]["joules_per_launch"] = round(pc[leg]["socket_power_w"] * pc[leg]["avg_launch_ms"] * 1e-3, 4)
+    return out
+
+
 def vae_decode_rate(device):
     """VAE decode of one 16-frame video (latents 16x4x32x32 -> 16x256x256x3 uint8), random sd-vae-ft-shaped weights;
     reported beside the headline, outside its timed region (decode is ~1.5 % of a 250-step chain)."""
@@ -644,6 +672,14 @@ def main():
         n3 = min(args.steps, 10)
         dt3 = timed_steps(lib, m3, diffusion, x3, n3, args.method, 16, y=y3, cfg_scale=7.0, guided=True)
         side["config3"] = {"ms_per_step": dt3 * 1e3, "steps": n3}
+        # the guided call's split-operand linears (engine option guided_split, default 3: DESIGN.md section 2) cost time; the plain f16
+        # operands of rounds 1-4 (guided_split 0: at 1e-3 of the fp32 reference at trained-scale gates, not under it) and the
+        # out-projection-only setting beside the default
+        for gs in (0, 1):
+            m3.set_engine_option("guided_split", gs, 16, guided=True)
+            side["config3"][f"ms_per_step_guided_split_{gs}"] = timed_steps(lib, m3, diffusion, x3, n3, args.method, 16, y=y3, cfg_scale=7.0,
+                                                                            guided=True) * 1e3
+        m3.set_engine_option("guided_split", 3, 16, guided=True)
         # the same per-kernel roofline table at config 3's M = 65 536 rows (16 sequences): what each kernel class does with twice the rows
         t3 = torch.full((16,), 500, device=device, dtype=torch.int64)
         m3.profile_forward(x3, t3, y=y3)
@@ -713,8 +749,16 @@ def main():
             if k == "config3":
                 sps = world * 8 / (v["ms_per_step"] * 1e-3)
                 res["config3"] = {"workload": "Latte-XL/2 UCF101 class-conditional (101 classes + null), CFG 7.0 through "
-                                              "forward_with_cfg, 8 samples = 16 sequences per GPU, f16 operands",
+                                              "forward_with_cfg, 8 samples = 16 sequences per GPU, f16 operands, attention output and fc1 "
+                                              "operand as split pairs (guided_split 3, the default of guided calls)",
                                   "value": round(sps, 3), "unit": "guided sample-steps/s", "ms_per_step": round(v["ms_per_step"], 3),
+                                  "other_guided_split_settings": {
+                                      f"guided_split_{gs}": {"value": round(world * 8 / (v[f"ms_per_step_guided_split_{gs}"] * 1e-3), 3),
+                                                             "ms_per_step": round(v[f"ms_per_step_guided_split_{gs}"], 3),
+                                                             "note": ("plain f16 operands (rounds 1-4): the guided XL/2 output at trained-scale gates is AT "
+                                                                      "1e-3 of the fp32 reference, 0.6-1.2e-3 over 12 draws" if gs == 0 else
+                                                                      "attention output only: 0.5-0.95e-3 (emulated)")}
+                                      for gs in (0, 1) if f"ms_per_step_guided_split_{gs}" in v},
                                   "steps": v["steps"], "global_batch": 8 * world,
                                   "model_mfma_frac": round(2 * sps / world * flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
                                   "roofline_table": v.get("roofline_table"), "forward_ms_eager_events": v.get("forward_ms_eager_events")}
@@ -738,6 +782,7 @@ def main():
                 res["power_check"] = power_check(device, model, x, args.dtype)
             except Exception as ex:  # noqa: BLE001  (rocm-smi absent or unreadable: the line must still print)
                 res["power_check"] = {"error": repr(ex)[:200]}
+            res["energy"] = energy_columns(res, world)
         if world == 1 and not args.no_vae:
             res["vae_decode"] = vae_decode_rate(device)
         if world == 1 and not args.no_side:

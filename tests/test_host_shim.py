@@ -207,3 +207,20 @@ def test_bench_reads_power_and_clock_from_rocm_smi_json():
                (12.5, one(800, 2400))]
     assert bench.mean_power_clock(samples, 10.0, 12.0) == (1395.0, 1705.0, 2)      # the first 0.3 s and everything after b are left out
     assert bench.mean_power_clock([], 0.0, 1.0) == (None, None, 0)
+
+
+def test_bench_energy_columns_are_power_times_time():
+    """bench.py: energy = the forward leg's mean socket power x this run's times (round-4 review: the quantity the power-capped MFMA
+    kernels are bound by); no power sample -> no energy object, the line still prints."""
+    import bench
+    res = {"ms_per_step": 30.0, "config": {"per_gpu_batch": 8},
+           "roofline_table": [{"class": "gemm_fc2", "avg_launch_ms": 0.3}, {"class": "ln_modulate", "avg_launch_ms": 0.04}],
+           "power_check": {"forward": {"socket_power_w": 1350.0, "shader_clock_mhz": 1920.0},
+                           "fc2_standalone_random_operands": {"socket_power_w": 1390.0, "avg_launch_ms": 0.3117},
+                           "fc2_standalone_zeros_operands": {"socket_power_w": 1119.0, "avg_launch_ms": 0.2495}}}
+    en = bench.energy_columns(res, 1)
+    assert en["joules_per_step"] == 40.5 and en["joules_per_sample_step"] == round(40.5 / 8, 3)
+    assert abs(en["picojoules_per_algorithmic_flop"] - 40.5 / 8 / 3.726e12 * 1e12) < 2e-3
+    assert res["roofline_table"][0]["joules_per_launch"] == 0.405 and res["roofline_table"][1]["joules_per_launch"] == 0.054
+    assert res["power_check"]["fc2_standalone_random_operands"]["joules_per_launch"] == round(1390.0 * 0.3117e-3, 4)
+    assert bench.energy_columns({"power_check": {"error": "no rocm-smi"}, "ms_per_step": 1.0, "config": {"per_gpu_batch": 8}}, 1) is None
