@@ -37,7 +37,9 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
  * must be 64 or 72.  dbg_qkv (may be NULL): half [B F T, 3D] receives the q | k | v values the kernel holds in LDS (what the
  * un-fused qkv GEMM would have written).  xn must not alias out.  flags = QkvAttnArgs::flags, schedule variants with identical
  * results: bit 0 = the next unit's first operand tile is fetched under the attention phase, bit 1 = attention-phase issue priority
- * for wave group 0 (spatial mode), bit 2 = four heads per XCD instead of all heads of every eighth sequence group (16 heads). */
+ * for wave group 0 (spatial mode), bit 2 = four heads per XCD instead of all heads of every eighth sequence group (16 heads);
+ * bit 8 = QkvAttnArgs::out_split: out is [B F T, 2 D] = [hi | lo], the attention output as a split operand pair (the half nearest to
+ * each value and the half nearest to the remainder) -- what guided calls feed the out-projection (engine option guided_split). */
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T,
                               int D, int heads, int mode, int flags, int dtype, void* stream);
 /* The same launch with a phase trace (measurement): trace = int64 [8 waves][4] receives workgroup 0's shader-clock ticks in

@@ -185,7 +185,8 @@ int latte_debug_qkv_attention_trace(const void* xn, const void* w, const float* 
   QkvAttnArgs a{};
   a.xn = (const half_t*)xn; a.w = (const half_t*)w; a.bias = bias; a.out = (half_t*)out; a.dbg_qkv = (half_t*)dbg_qkv;
   a.dbg_trace = trace;
-  a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = flags;
+  a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = flags & 255;
+  a.out_split = (flags >> 8) & 1;   // flags bit 8: out is [rows, 2 D] = [hi | lo] (the split-pair output of guided calls)
   a.scale = 1.0f / sqrtf((float)a.hd);
   return launch_qkv_attention(a, dtype, (hipStream_t)stream);
 }

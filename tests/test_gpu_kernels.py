@@ -319,6 +319,42 @@ def test_fused_qkv_attention_is_the_unfused_pair(lib, dev, dt, case, mode):
     assert rel < (8e-3 if dt == 0 else 1.5e-3), rel
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 256, 16, 72), (1, 16, 256, 6, 64)])
+@pytest.mark.parametrize("mode", [0, 1], ids=["spatial", "temporal"])
+def test_fused_qkv_attention_split_output(lib, dev, dt, case, mode):
+    """Guided calls (engine option guided_split, round 5) take the attention output as a split pair [hi | lo]: hi must be the plain
+    kernel's output bit for bit (the half nearest to the value), and hi + lo must carry the fp32 attention output to ~2^-20 -- i.e.
+    the out-projection's K-concatenated operand [hi | lo] . [W | W]^T no longer rounds its activation."""
+    B, F, T, H, hd = case
+    D, rows = H * hd, B * F * T
+    g = torch.Generator("cpu").manual_seed(rows + hd + mode)
+    xn = torch.randn(rows, D, generator=g).to(dev).to(TD[dt])
+    W = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev).to(TD[dt])
+    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
+    plain = torch.full((rows, D), float("nan"), dtype=TD[dt], device=dev)
+    dbg = torch.zeros(rows, 3 * D, dtype=TD[dt], device=dev)
+    flags = 3 if mode == 0 else 1
+    check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(plain), ptr(dbg), B, F, T, D, H, mode, flags, dt, stream_ptr()))
+    pair = torch.full((rows, 2 * D), float("nan"), dtype=TD[dt], device=dev)
+    check(lib.latte_debug_qkv_attention(ptr(xn), ptr(W), ptr(bias), ptr(pair), None, B, F, T, D, H, mode, flags | 256, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(pair[:, :D].view(torch.int16), plain.view(torch.int16))
+    # fp32 attention on the half q | k | v the kernel holds (latte.py:61-70)
+    q, k, v = dbg.float().reshape(B, F, T, 3, H, hd).unbind(3)
+    if mode == 0:
+        q, k, v = (t_.permute(0, 1, 3, 2, 4) for t_ in (q, k, v))          # [B, F, H, T, hd]
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(rows, D)
+    else:
+        q, k, v = (t_.permute(0, 2, 3, 1, 4) for t_ in (q, k, v))          # [B, T, H, F, hd]
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(rows, D)
+    e_plain = float((plain.float() - ref).norm() / ref.norm())
+    e_pair = float((pair[:, :D].float() + pair[:, D:].float() - ref).norm() / ref.norm())
+    print(dt, case, mode, e_plain, e_pair)
+    # the pair removes the OUTPUT rounding; what is left is the softmax probabilities' half rounding inside the kernel (P feeds the MFMA)
+    assert e_pair < 0.75 * e_plain and e_pair < (4e-3 if dt == 0 else 6e-4)
+
+
 def test_fused_qkv_attention_rejects_other_shapes(lib, dev):
     x = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
     w = torch.zeros(384, 128, dtype=torch.bfloat16, device=dev)
