@@ -247,6 +247,50 @@ def test_guided_forward_at_trained_scale_gates(gate_std, t_val, seed):
     assert e[0] < TOL and e[1] < TOL, e
 
 
+def test_guided_split_contract():
+    """Engine option guided_split (round 5): (a) unguided calls do not depend on it; (b) guided_split = 0 is the plain f16 path: the
+    guided output is the guidance combination of the SAME engine's unguided outputs of the doubled batch, bit for bit; (c) the split
+    pairs move the guided output by no more than an operand rounding (they remove one) and closer to the fp32 oracle; (d) the [W | W]
+    copies follow a reloaded weight."""
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=32, num_frames=16, num_classes=101, extras=2)      # 256 tokens x 16 frames: fused kernels, pair output
+    cfg = lo.preset_config("Latte-S/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=5, gate_std=0.3)
+    g = torch.Generator("cpu").manual_seed(6)
+    z = torch.randn(1, 16, 4, 32, 32, generator=g)
+    x, t, y = torch.cat([z, z]).cuda(), torch.tensor([300, 300]).cuda(), torch.tensor([9, 101]).cuda()
+    with torch.no_grad():
+        ref = lo.latte_forward_with_cfg(sd, cfg, x.cpu(), t.cpu(), y.cpu(), 7.0)
+    m = latte_amd.Latte_models["Latte-S/2"](max_batch=2, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    plain = m(x, t, y=y)
+    outs = {}
+    for gs in (0, 1, 2, 3):
+        m.set_engine_option("guided_split", gs, 2, guided=True)
+        outs[gs] = m.forward_with_cfg(x, t, y=y, cfg_scale=7.0)
+        assert torch.equal(m(x, t, y=y), plain), gs                               # (a)
+    cond, uncond = plain[:1, :, :4], plain[1:, :, :4]
+    eps = uncond + 7.0 * (cond - uncond)
+    want0 = torch.cat([torch.cat([eps, eps]), plain[:, :, 4:]], dim=2)
+    assert rel_l2(outs[0], want0) < 1e-6                                            # (b) same forward, fp32 combine
+    e = {gs: rel_l2(o[:, :, :4], ref[:, :, :4]) for gs, o in outs.items()}
+    print(e)
+    assert e[3] < e[0] and e[1] < e[0] and e[2] < e[0] and e[3] < TOL               # (c)
+    assert all(rel_l2(outs[gs], outs[0]) < 3e-3 for gs in (1, 2, 3))
+    # (d) reload a block weight: both paths must follow it
+    sd2 = dict(sd)
+    sd2["blocks.3.mlp.fc1.weight"] = sd["blocks.3.mlp.fc1.weight"] * 1.5
+    sd2["blocks.4.attn.proj.weight"] = sd["blocks.4.attn.proj.weight"] * 0.5
+    m.load_state_dict(sd2)
+    m.mark_weights_dirty() if hasattr(m, "mark_weights_dirty") else None
+    with torch.no_grad():
+        ref2 = lo.latte_forward_with_cfg(sd2, cfg, x.cpu(), t.cpu(), y.cpu(), 7.0)
+    m.set_engine_option("guided_split", 3, 2, guided=True)
+    got2 = m.forward_with_cfg(x, t, y=y, cfg_scale=7.0)
+    assert rel_l2(got2[:, :, :4], ref2[:, :, :4]) < TOL and rel_l2(got2, outs[3]) > 1e-2
+
+
 @pytest.mark.parametrize("cd", DTYPES)
 def test_ddim10_plumbing_config_matches_oracle(cd):
     """BASELINE.json configs[0]: Latte-S/2, 4 frames, DDIM 10 steps, batch 1 — denoised latents."""
