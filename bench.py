@@ -279,6 +279,34 @@ def vae_decoder_work(h):
     return fl, gn_in, gn_in + gn_in // 2
 
 
+def vae_conv_bytes(h, frames=16):
+    """Algorithmic bytes of the 3x3 convolutions of `frames` frames of AutoencoderKL.decode at an h x h latent: every convolution reads
+    its half operand once (the upsampler convolutions at the pre-upsample size), writes its fp32 output once, reads the fp32 residual
+    once where it adds one (the second convolution of every resnet), and the weights are read once per decode.  14.4 GB at h = 32,
+    16 frames -- the 24.4 GB the PMC pass counts through the fabric (profiles/r4_pmc.json) are 1.7 x that: a 256-pixel tile re-reads
+    the rows above / below it for its 9 taps out of the other XCDs' reach, and every tile streams its weight slice again.  At 11 ms
+    even the fabric figure is 2.2 TB/s: the convolutions are nowhere near a memory bound."""
+    def conv(H, cin, cout, res=False, ups=False):
+        hin = H // 2 if ups else H
+        return hin * hin * cin * 2 + H * H * cout * 4 + (H * H * cout * 4 if res else 0)
+    act = wts = 0
+    for _ in range(2):
+        act += conv(h, 512, 512) + conv(h, 512, 512, res=True)
+        wts += 2 * 9 * 512 * 512 * 2
+    H, prev = h, 512
+    for i, c in enumerate((512, 512, 256, 128)):
+        for r in range(3):
+            cin = prev if r == 0 else c
+            act += conv(H, cin, c) + conv(H, c, c, res=True)
+            wts += 9 * cin * c * 2 + 9 * c * c * 2
+        prev = c
+        if i < 3:
+            H *= 2
+            act += conv(H, c, c, ups=True)
+            wts += 9 * c * c * 2
+    return frames * act + wts
+
+
 def parse_rocm_smi(txt):
     """(socket power in W, shader clock in MHz) of the first card in `rocm-smi -c -P --json` output; None for what is not there."""
     try:
@@ -448,6 +476,7 @@ def vae_decode_rate(device):
             ach = conv_fl / (ms * 1e-3) / 1e12
             row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "algorithmic_flops": conv_fl,
+                        "algorithmic_bytes": vae_conv_bytes(32), "algorithmic_gbs": round(vae_conv_bytes(32) / (ms * 1e-3) / 1e9, 1),
                         "kernel": "conv3x3_kernel: implicit-GEMM 3x3 convolution (+ nearest-2x upsample in the gather), f16 operands"})
         elif k in ("groupnorm_stats", "groupnorm_apply"):
             by = gn_stats_b if k == "groupnorm_stats" else gn_apply_b

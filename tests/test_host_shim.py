@@ -224,3 +224,12 @@ def test_bench_energy_columns_are_power_times_time():
     assert res["roofline_table"][0]["joules_per_launch"] == 0.405 and res["roofline_table"][1]["joules_per_launch"] == 0.054
     assert res["power_check"]["fc2_standalone_random_operands"]["joules_per_launch"] == round(1390.0 * 0.3117e-3, 4)
     assert bench.energy_columns({"power_check": {"error": "no rocm-smi"}, "ms_per_step": 1.0, "config": {"per_gpu_batch": 8}}, 1) is None
+
+
+def test_bench_vae_conv_algorithmic_bytes():
+    """bench.py: the convolutions of a 16-frame SD-VAE decode move 14.4 GB algorithmically (operand in, fp32 out, fp32 residual, weights
+    once) -- the figure the round-4 review asked for beside the 24.4 GB of fabric traffic the PMC pass counts."""
+    import bench
+    b = bench.vae_conv_bytes(32)
+    assert 14.3e9 < b < 14.5e9
+    assert bench.vae_conv_bytes(32, frames=1) < b / 14          # the weights (96 MB) are read once per decode, not per frame
