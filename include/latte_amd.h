@@ -98,7 +98,7 @@ void latte_engine_destroy(latte_engine_t* e);
  * halves per value) against weights stored [W | W], i.e. those two linears run on K' = 2 K without rounding their activation operand.
  * The guidance combination of latte.py:394-398 amplifies the operand rounding that differs between the two halves; with f16 operands
  * the XL/2 guided output at trained-scale gates sits AT 1e-3 of the fp32 reference (0.6 - 1.2e-3), with the split pairs at 0.4 - 0.8e-3
- * for +X % of the guided step.  0 = the plain f16 operands of the unguided path),
+ * for +31 % of the guided step at XL/2.  0 = the plain f16 operands of the unguided path),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);
