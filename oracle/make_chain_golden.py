@@ -27,8 +27,10 @@ the block branches reach the latents at full weight), and the benchmarked chain 
   xl_full_g03   the same with gate_std 0.3                                               250 (ddim)   -> chain250_xl.npz
 Round 5 -- BASELINE config 3's own model and call (sample/sample_ddp.py:140-160: UCF101 class-conditional Latte-XL/2 through
 ``forward_with_cfg``, latte.py:379-398, cfg_scale 7.0) at trained-scale gates, full length:
-  xl_guided_g03 Latte-XL/2 16 x 32x32 class-cond (label 23 + null class), CFG 7.0, B = 1 (2 rows), gate_std 0.3   250 (ddim)   -> chain250_xl.npz
-``--only a,b`` regenerates the named cases and merges them into the existing file (the XL chains take ~30 min each).
+  xl_guided_g03 Latte-XL/2 16 x 32x32 class-cond (label 23 + null class), CFG 7.0, B = 1 (2 rows), gate_std 0.3   250 (ddim, ddpm: the
+                YAMLs' default sample_method)   -> chain250_xl.npz
+``--only a,b`` regenerates the named cases and merges them into the existing file (the XL chains take ~30 min each, the guided one
+~75 min per sampler); ``--methods ddpm`` restricts the regenerated cases to the named samplers (the others are kept from the file).
 """
 import os
 import sys
@@ -63,7 +65,7 @@ CASES = {
     "xl_full": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 91, 92, 93, 1, None, 250, ("ddim",)),
     "xl_full_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 101, 102, 103, 1, None, 250, ("ddim",)),
     "xl_guided_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 111, 112, 113, 1, [23], 250,
-                      ("ddim",)),
+                      ("ddim", "ddpm")),
 }
 GATE_STD = {"s2_uncond_g03": 0.3, "b2_uncond_g03": 0.3, "b2_guided_g03": 0.3, "xl_full_g03": 0.3,
             "xl_guided_g03": 0.3}   # default 0.02
@@ -102,9 +104,12 @@ def main():
     b = chain_noises(99, (2, 3, 5), 3)
     assert all(torch.equal(p, q) for p, q in zip(a, b))
     only = None
+    only_methods = None
     for i, a in enumerate(sys.argv):
         if a == "--only":
             only = set(sys.argv[i + 1].split(","))
+        if a == "--methods":
+            only_methods = set(sys.argv[i + 1].split(","))
     arrays = {OUT: {}, OUT_XL: {}}
     for path in arrays:
         if only is not None and os.path.exists(path):      # merge into what is there
@@ -123,6 +128,8 @@ def main():
         d = rd.create_diffusion("250")
         s = do.Schedule("250")
         for method in methods:
+            if only_methods is not None and method not in only_methods:
+                continue
             t0 = time.time()
             loop = d.ddim_sample_loop_progressive if method == "ddim" else d.p_sample_loop_progressive
             if y is None:

@@ -31,7 +31,7 @@ TOL = 1e-3
 
 CHAIN = [(n, m) for n in ("s2_uncond", "s2_guided", "b2_uncond", "b2_guided", "s2_uncond_g03", "b2_uncond_g03", "b2_guided_g03")
          for m in ("ddim", "ddpm")] + [("xl_segment", "ddim"), ("xl_full", "ddim"), ("xl_full_g03", "ddim"),
-                                   ("xl_guided_g03", "ddim")]
+                                   ("xl_guided_g03", "ddim"), ("xl_guided_g03", "ddpm")]
 
 
 def _record(key, drift):

@@ -247,6 +247,30 @@ def test_guided_forward_at_trained_scale_gates(gate_std, t_val, seed):
     assert e[0] < TOL and e[1] < TOL, e
 
 
+def test_guided_forward_latte_l2_width():
+    """The split-pair operands of guided calls on a width whose gated GEMMs do NOT run on the 192-wide 12-wave kernel (Latte-L/2:
+    D = 1024 = 5.33 x 192, 16 heads of 64): the K-concatenated out-projection / fc1 go through whatever tile the shape rule picks."""
+    from oracle import latte_oracle as lo
+    kw = dict(input_size=32, num_frames=16, num_classes=101, extras=2)
+    cfg = lo.preset_config("Latte-L/2", **kw)
+    sd = lo.init_state_dict(cfg, seed=7, gate_std=0.3)
+    g = torch.Generator("cpu").manual_seed(8)
+    z = torch.randn(1, 16, 4, 32, 32, generator=g)
+    x, t, y = torch.cat([z, z]), torch.tensor([500, 500]), torch.tensor([33, 101])
+    with torch.no_grad():
+        ref = lo.latte_forward_with_cfg(sd, cfg, x, t, y, 7.0)
+    m = latte_amd.Latte_models["Latte-L/2"](max_batch=2, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    e = {}
+    for gs in (3, 0):
+        m.set_engine_option("guided_split", gs, 2, guided=True)
+        out = m.forward_with_cfg(x.cuda(), t.cuda(), y=y.cuda(), cfg_scale=7.0)
+        e[gs] = rel_l2(out[:, :, :4], ref[:, :, :4])
+    print(e)
+    assert e[3] < TOL and e[3] < e[0]
+
+
 def test_guided_split_contract():
     """Engine option guided_split (round 5): (a) unguided calls do not depend on it; (b) guided_split = 0 is the plain f16 path: the
     guided output is the guidance combination of the SAME engine's unguided outputs of the doubled batch, bit for bit; (c) the split
