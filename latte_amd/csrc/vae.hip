@@ -284,8 +284,17 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
   if (grp == 0) dma_b_all(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (nk > 1) {                        // K tile 1 (stage 1 is untouched so far): each group its own pixel rows, group 0 the W tile
+    dma_a_half(1);
+    if (grp == 0) dma_b_all(1);
+  }
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
 
+  // Round 5: the DMA runs TWO K tiles ahead, as in gemm_pps_kernel (gemm.hip): K tile kt + 2 is issued into the stage just consumed,
+  // behind the barrier that ends C(kt) -- for group 0 that barrier is the one group 1 passes after ITS L(kt), so the shared W tile
+  // and group 0's pixel rows of the stage are free; group 1 only ever overwrites its own rows -- and the vmcnt(0) behind C(kt)
+  // confirms K tile kt + 1, which was issued a whole iteration earlier (round 4 issued kt + 1 inside L(kt) and waited for it one
+  // compute segment later: the gathered rows come out of the L2 / Infinity Cache with less slack than that).
   for (int kt = 0; kt < nk; ++kt) {
     const char* sbuf = smem + (kt & 1) * STAGE;
     u32x4 bf[2][FN], af[2][8];
@@ -296,10 +305,6 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
       for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
 #pragma unroll
       for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
-    }
-    if (kt + 1 < nk) {
-      dma_a_half(kt + 1);
-      if (grp == 0) dma_b_all(kt + 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage kt fully consumed by this wave
     __builtin_amdgcn_s_barrier();
@@ -312,8 +317,12 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA of K tile kt+1 landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA of K tile kt + 1 landed
     __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      dma_a_half(kt + 2);
+      if (grp == 0) dma_b_all(kt + 2);
+    }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
 
