@@ -93,15 +93,24 @@ void latte_engine_destroy(latte_engine_t* e);
  * OFF one default schedule feature of the fused kernel each -- the next unit's first operand tile fetched under the attention
  * phase, the attention-phase issue priority of wave group 0, the four-heads-per-XCD unit order of 16-head models (A/B hooks);
  * every setting gives the same bits),
- * "guided_split" (bits, default 3; guided calls -- latte_forward_with_cfg and the guided sample loop -- only: bit 0 = the attention output
+ * "guided_split" (bits; guided calls -- latte_forward_with_cfg and the guided sample loop -- only; default 12 on f16 engines, ignored
+ * beyond bits 0 / 1 on bf16 ones: bit 0 = the attention output
  * that feeds the out-projection, bit 1 = the LayerNorm-modulate output that feeds fc1 are carried as SPLIT operand pairs [hi | lo] (two
  * halves per value) against weights stored [W | W], i.e. those two linears run on K' = 2 K without rounding their activation operand.
  * The guidance combination of latte.py:394-398 amplifies the operand rounding that differs between the two halves; with f16 operands
  * the XL/2 guided output at trained-scale gates sits AT 1e-3 of the fp32 reference (0.6 - 1.2e-3), with the split pairs at 0.4 - 0.8e-3
- * for +31 % of the guided step at XL/2.  0 = the plain f16 operands of the unguided path),
+ * for +31 % of the guided step at XL/2.  Bits 2 / 3 (round 6) carry the same two operands as f16 + an FP8
+ * remainder (e4m3 of lo * 2^12, one byte per value) whose product with an fp8 copy of the weight is collected by a block-scaled fp8
+ * MFMA pass behind the f16 K loop of the SAME GEMM launch: the same parity margin at half the extra MFMA time and a quarter of the
+ * extra operand bytes; a bit-2 / 3 setting wins over bit 0 / 1 for its operand.  0 = the plain f16 operands of the unguided path.
+ * Operands whose shape has no split form stay plain: latte_engine_get_option("guided_split_active") reports the bits the last
+ * guided forward really used),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
  * pointer is supplied; the reference draws torch.randn_like, gaussian_diffusion.py:413,555). */
 int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value);
+/* Reads an option back (same names), or one of the read-only facts "guided_split_active" (bits of "guided_split" the last guided
+ * forward ran with) and "guided_split_failed" (1 after an allocation for the split operands failed: guided calls then run plain). */
+int latte_engine_get_option(const latte_engine_t* e, const char* name, int64_t* value);
 
 /* Replaces nn.Module.load_state_dict (sample.py:62-64) for ONE tensor named by its reference
  * state_dict key (SURVEY.md §8(b) lists them: "blocks.3.attn.qkv.weight", "pos_embed", ...).
@@ -368,6 +377,11 @@ int latte_t2v_guided_ddim_loop(latte_t2v_t* e, float* x, int samples, int n_step
 #define LATTE_NUM_KERNEL_CLASSES 12
 int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch,
                           float* out, float* ms_out, int* launches_out, int n, void* stream);
+/* The same with guided != 0: the denoiser call of latte_forward_with_cfg (x = the first half of the batch, used for both halves;
+ * split operands per the "guided_split" option), WITHOUT the guidance combination -- so the table describes the kernels a guided
+ * sampling step really runs (bench.py: config3.roofline_table). */
+int latte_profile_forward_ex(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, int guided,
+                             float* out, float* ms_out, int* launches_out, int n, void* stream);
 /* Stand-alone timing of the dominant kernel: C[M,N] = A[M,K] * W[N,K]^T (+bias epilogue `epi`,
  * 0 = bf16 out, 1 = bias+GELU, 2 = gated residual) on synthetic operands already resident in HBM;
  * `iters` back-to-back launches between two HIP events on `stream`.  variant selects the tile

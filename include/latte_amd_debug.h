@@ -18,6 +18,21 @@ extern "C" {
  * GEMM (0 attention out-projection, 1 fc2: separate kernel symbols for the profiler). */
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
                      int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
+/* The same product with the FP8 CORRECTION PASS of a split operand (round 6; engine option guided_split bits 2 / 3): the tile's
+ * accumulators also collect  dec(A8) 2^-12 . (dec(W8) 2^-6)^T  -- A8 [Mpad, K] / W8 [N, K] bytes of OCP e4m3 codes -- on the block-
+ * scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 behind the half-precision K loop (csrc/gemm_pw.hip, rolling 12-wave kernel; f16,
+ * N % 192 == 0, K % 128 == 0; epi 1 = bias + GELU -> half, epi 2 = gated fp32 read-modify-write). */
+int latte_debug_gemm_lo8(const void* A, const void* W, const void* A8, const void* W8, const float* bias, void* out, const float* gate,
+                         int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype, void* stream);
+/* W8 of an f16 weight: out8[i] = e4m3(clamp(w[i] * 2^6, +-448)) (n % 4 == 0). */
+int latte_debug_pack_w8(const void* w, void* out8, int64_t n, int dtype, void* stream);
+/* latte_debug_ln_modulate with the split output of the fp8 form: y [M, D] = the nearest f16 (bit for bit the plain kernel's output),
+ * y8 [M, D] bytes = e4m3(clamp((value - y) * 2^12, +-448)). */
+int latte_debug_ln_modulate_split8(const float* x, void* y, void* y8, const float* shift, const float* scale, int mod_stride, int M, int D,
+                                   int rows_per_sample, int dtype, void* stream);
+/* latte_debug_qkv_attention with the same split of the attention output: out [B F T, D] f16 + out8 [B F T, D] bytes. */
+int latte_debug_qkv_attention_split8(const void* xn, const void* w, const float* bias, void* out, void* out8, int B, int F, int T, int D,
+                                     int heads, int mode, int dtype, void* stream);
 /* Attention core of latte.py:50-70 on a [rows, 3*D] qkv buffer (see AttnArgs in csrc/common.h). */
 /* Host logic only (no GPU needed): the tile / kernel variant launch_gemm picks for C[M, N] = A[M, K] W[N, K]^T with epilogue
  * `epi` when none is forced (csrc/gemm.hip: gemm_resolve_variant; variants as for the "gemm_variant" engine option). */

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "latte_engine_create": (c_int, [ctypes.POINTER(ModelConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_engine_destroy": (None, [c_void]),
     "latte_engine_set_option": (c_int, [c_void, c_char, c_i64]),
+    "latte_engine_get_option": (c_int, [c_void, c_char, ctypes.POINTER(c_i64)]),
     "latte_engine_load_tensor": (c_int, [c_void, c_char, c_void, c_i64, c_int, c_void]),
     "latte_engine_check_weights": (c_int, [c_void]),
     "latte_engine_num_keys": (c_int, [c_void]),
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "latte_trainer_set_option": (c_int, [c_void, c_char, ctypes.c_double]),
     "latte_trainer_scaler_state": (c_int, [c_void, ctypes.POINTER(ctypes.c_double)]),
     "latte_profile_forward": (c_int, [c_void, c_void, c_void, c_void, c_int, c_void, c_void, c_void, c_int, c_void]),
+    "latte_profile_forward_ex": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_int, c_void]),
     "latte_t2v_create": (c_int, [ctypes.POINTER(T2VConfig), c_int, ctypes.POINTER(c_void)]),
     "latte_t2v_destroy": (None, [c_void]),
     "latte_t2v_num_keys": (c_int, [c_void]),
@@ -108,6 +110,12 @@ PROTOTYPES = {
     "latte_vae_decode": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void]),
     "latte_vae_profile_decode": (c_int, [c_void, c_void, c_int, c_f32, c_int, c_void, c_void, c_void, c_int, c_void]),
     # test hooks
+    "latte_debug_gemm_lo8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void]),
+    "latte_debug_pack_w8": (c_int, [c_void, c_void, c_i64, c_int, c_void]),
+    "latte_debug_ln_modulate_split8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
+    "latte_debug_qkv_attention_split8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_void]),
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),
     "latte_debug_gemm_choice": (c_int, [c_int, c_int, c_int, c_int]),

@@ -96,7 +96,17 @@ struct GemmArgs {
   int tag;            // call site of a gated-residual GEMM (0 = attention out-projection, 1 = fc2): separate kernel symbols
   int k_chunk;        // plain kernels (variants 1-3) only: > 0 splits the contraction, grid.y = ceil(K / k_chunk) partial products
   long split_stride;  // ... written to (float*)out + blockIdx.y * split_stride (use EPI_BIAS_F32 with a zero bias)
+  // Low-precision CORRECTION pass (round 6; rolling 12-wave kernel only, gemm_pw.hip): when A8 != nullptr the accumulators of a tile
+  // also collect  A8 . W8^T  -- fp8 (OCP e4m3) operands on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with the two
+  // constant E8M0 scales below -- behind the half-precision K loop and in front of the epilogue: the `lo` half of a split operand
+  // pair (mfma_util.h: split2) at a quarter of the operand bytes and half the MFMA time of the [hi | lo] . [W | W] form.
+  const uint8_t* A8;  // [Mpad, K] bytes: e4m3(lo * 2^LO8_A_SHIFT)
+  const uint8_t* W8;  // [N, K]    bytes: e4m3(W * 2^LO8_W_SHIFT)
 };
+// constant block scales of the correction pass: A8 holds the rounding remainder of a half operand (|lo| <= 2^-11 |x|), W8 weights of
+// |w| < 7; the MFMA multiplies the products back by 2^-(LO8_A_SHIFT + LO8_W_SHIFT) (E8M0 scale bytes 127 - shift)
+constexpr int LO8_A_SHIFT = 12, LO8_W_SHIFT = 6;
+bool gemm_lo8_ok(int M, int N, int K);   // the shape takes the correction pass (whole 192-wide tile columns, K % 128 == 0, 32-bit offsets)
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
 // 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
@@ -150,6 +160,8 @@ struct QkvAttnArgs {
   int flags;           // schedule variants, same results (qkv_attn.hip): bit 0 = next unit's first operand tile fetched under the
                        // attention phase, bit 1 = attention-phase issue priority for group 0, bit 2 = four heads per XCD (16 heads)
   int out_split;       // 1: out is [B F T, 2 D] = [hi | lo] -- the attention output as a split operand pair (mfma_util.h: split2)
+                       // 2 (f16): out stays [B F T, D], out8 receives the fp8 remainder (mfma_util.h: split8_f16; GemmArgs::A8)
+  unsigned char* out8; // [B F T, D] bytes
 };
 bool qkv_attention_fusable(int D, int heads, int hd, int F, int T, int mode, int64_t rows);
 int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
@@ -159,7 +171,9 @@ int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 // If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T,
-                       int F, int dtype, hipStream_t st, int split = 0);   // split: y is [M, 2 D] = [hi | lo] (mfma_util.h: split2)
+                       int F, int dtype, hipStream_t st, int split = 0,   // split 1: y is [M, 2 D] = [hi | lo] (mfma_util.h: split2)
+                       unsigned char* y8 = nullptr);   // split 2 (f16): y [M, D] + y8 [M, D] bytes = fp8 remainder (GemmArgs::A8)
+int launch_pack_w8(const half_t* in, unsigned char* out, int64_t n, int dtype, hipStream_t st);   // GemmArgs::W8 of an f16 weight
 enum SmallIn : int { IN_PLAIN = 0, IN_SILU = 1, IN_TFREQ = 2 };
 // out[b, n] = bias[n] + sum_k in(b,k) * W[n, k]  (+ add_table[add_idx[b], n]); fp32 exact.
 int launch_small_linear(int in_mode, const float* in, const int64_t* t, const float* W, const float* bias,

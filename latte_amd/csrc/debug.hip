@@ -152,6 +152,36 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
   return launch_gemm(g, epi, dtype, variant, (hipStream_t)stream);
 }
 
+int latte_debug_gemm_lo8(const void* A, const void* W, const void* A8, const void* W8, const float* bias, void* out, const float* gate,
+                         int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype, void* stream) {
+  if (!A8 || !W8) return fail(LATTE_ERR_INVALID, "gemm_lo8: null fp8 operand");
+  GemmArgs g{};
+  g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = out; g.gate = gate;
+  g.M = M; g.N = N; g.K = K; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample;
+  g.A8 = (const uint8_t*)A8; g.W8 = (const uint8_t*)W8;
+  return launch_gemm(g, epi, dtype, 0, (hipStream_t)stream);
+}
+
+int latte_debug_pack_w8(const void* w, void* out8, int64_t n, int dtype, void* stream) {
+  return launch_pack_w8((const half_t*)w, (unsigned char*)out8, n, dtype, (hipStream_t)stream);
+}
+
+int latte_debug_ln_modulate_split8(const float* x, void* y, void* y8, const float* shift, const float* scale, int mod_stride, int M, int D,
+                                   int rows_per_sample, int dtype, void* stream) {
+  return launch_ln_modulate(x, nullptr, (half_t*)y, shift, scale, mod_stride, M, D, rows_per_sample, nullptr, 1, 1, dtype, (hipStream_t)stream, 2,
+                            (unsigned char*)y8);
+}
+
+int latte_debug_qkv_attention_split8(const void* xn, const void* w, const float* bias, void* out, void* out8, int B, int F, int T, int D,
+                                     int heads, int mode, int dtype, void* stream) {
+  if (heads <= 0 || D % heads) return fail(LATTE_ERR_INVALID, "qkv_attention: D must be a multiple of heads");
+  QkvAttnArgs a{};
+  a.xn = (const half_t*)xn; a.w = (const half_t*)w; a.bias = bias; a.out = (half_t*)out; a.out8 = (unsigned char*)out8;
+  a.B = B; a.F = F; a.T = T; a.D = D; a.heads = heads; a.hd = D / heads; a.mode = mode; a.flags = 7; a.out_split = 2;
+  a.scale = 1.0f / sqrtf((float)a.hd);
+  return launch_qkv_attention(a, dtype, (hipStream_t)stream);
+}
+
 int latte_debug_gemm_choice(int M, int N, int K, int epi) { return gemm_resolve_variant(M, N, K, epi); }
 
 int latte_debug_qkv_attention_fusable(int D, int heads, int F, int T, int mode, int64_t rows) {

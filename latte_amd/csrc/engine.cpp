@@ -11,6 +11,7 @@
 //                    SAMPLE; the reference recomputes them on F or T repeated rows, latte.py:333-339)
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -59,7 +60,8 @@ struct TensorSlot {
 struct BlockW {
   half_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
   float *qkv_b, *proj_b, *fc1_b, *fc2_b;
-  half_t *proj_w2 = nullptr, *fc1_w2 = nullptr;   // [N, 2 K] = [W | W]: the weight of a split-operand linear (guided_split), built lazily
+  half_t *proj_w2 = nullptr, *fc1_w2 = nullptr;   // [N, 2 K] = [W | W]: the weight of a split-operand linear (guided_split bits 0 / 1), built lazily
+  unsigned char *proj_w8 = nullptr, *fc1_w8 = nullptr;   // [N, K] e4m3(W 2^LO8_W_SHIFT): the weight of a GEMM's fp8 correction pass (bits 2 / 3)
 };
 
 struct Prof {
@@ -89,10 +91,20 @@ struct latte_engine {
   // on CPU (oracle/emulate_operands.py) names the operands of the out-projection (attention output) and of fc1 / fc2.  guided_split:
   // bit 0 = the attention output, bit 1 = the LayerNorm-modulate output in front of fc1 are carried as SPLIT pairs [hi | lo] (two halves
   // per value, ~22 mantissa bits) against weights stored [W | W] -- the same GEMM kernels on K' = 2 K, no rounding of that operand.
-  // Guided calls only; where the fused qkv + attention kernel does not take the shape, bit 0 is ignored.
-  int guided_split = 3;
-  bool split_w_ready = false;              // proj_w2 / fc1_w2 hold the current weights
+  // Round 6: bit 2 / bit 3 = the same two operands with the remainder in FP8 (e4m3 of lo 2^12, one byte per value) and the product
+  // lo . W8^T collected by a block-scaled fp8 MFMA pass behind the f16 K loop of the same GEMM launch (GemmArgs::A8, gemm_pw.hip):
+  // half the MFMA time and a quarter of the operand bytes of the [hi | lo] . [W | W] form; the remainder term is 2^-12 of the product,
+  // so its own fp8 rounding (2^-4 relative) is 2^-16 -- below the weight operand's f16 rounding.  A bit-2/3 setting wins over bit 0/1
+  // for its operand.  Guided calls of f16 engines only (bf16 cannot reach 1e-3 with or without it: default 0 there); where a shape
+  // has no split form (un-fused attention, N % 192, K % 128) that operand stays plain -- latte_engine_get_info("guided_split_active")
+  // reports what the last guided forward really ran.
+  int guided_split = 12;
+  int guided_split_active = 0;             // what the last guided forward used (bits as above)
+  bool split_failed = false;               // an allocation for the split operands failed once: guided calls run plain from then on
+  bool split_w_ready = false;              // the derived weight copies (proj_w2 / fc1_w2 / proj_w8 / fc1_w8) hold the current weights
+  hipEvent_t load_event = nullptr;         // recorded behind every weight conversion on ITS stream: the derived copies wait for it
   half_t* xn2 = nullptr;                   // [rows_pad, 2 D]: split LayerNorm-modulate output (lazily allocated)
+  unsigned char* lo8 = nullptr;            // [rows_pad, D] bytes: the fp8 remainder of the attention output, then of fc1's operand
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
@@ -187,6 +199,7 @@ int gated_split_choice(const latte_engine* e, int M, int N, int K, int variant) 
   return 1;
 }
 int gated_gemm(latte_engine* e, const GemmArgs& g, int dt, int variant, hipStream_t st) {
+  if (g.A8) return launch_gemm(g, EPI_GATE_RES_F32, dt, 0, st);   // fp8 correction pass: the rolling 12-wave kernel carries it
   const int s = gated_split_choice(e, g.M, g.N, g.K, variant);
   if (s == 1) return launch_gemm(g, EPI_GATE_RES_F32, dt, variant, st);
   GemmArgs p = g;
@@ -200,25 +213,42 @@ int gated_gemm(latte_engine* e, const GemmArgs& g, int dt, int variant, hipStrea
                                    g.rows_per_sample, g.M, g.N, st);
 }
 
-// [W | W] copies of the weights whose operand a guided call carries as a split pair, and the [rows, 2 D] operand buffer
-int ensure_split_weights(latte_engine* e, hipStream_t st) {
+// Derived weights / operand buffers of the split operands of a guided call, for the bits of `need` only (guided_split), each pointer
+// guarded on its own.  An allocation failure does not fail the forward: it is reported once on stderr, `split_failed` is set and this
+// and every later guided call runs the plain f16 path.  The copies are built on the forward's stream BEHIND the last weight
+// conversion (load_event), whatever stream that ran on.  Returns the bits that are usable.
+int ensure_split_weights(latte_engine* e, int need, hipStream_t st) {
   const int D = e->D, Hm = e->Hm;
-  if (!e->xn2) {
-    if (int rc = dev_alloc(e, &e->xn2, (size_t)e->rows_pad * 2 * D)) return rc;
-  }
-  if (e->split_w_ready) return LATTE_OK;
+  if (e->split_failed) return 0;
+  auto give_up = [&](const char* what) {
+    fprintf(stderr, "latte_amd: guided_split: allocation of %s failed (%s); guided calls run with plain f16 operands\n", what, latte_last_error());
+    e->split_failed = true;
+    return 0;
+  };
+  bool fresh = false;
+  if ((need & 2) && !e->xn2 && dev_alloc(e, &e->xn2, (size_t)e->rows_pad * 2 * D)) return give_up("the [rows, 2 D] operand buffer");
+  if ((need & 12) && !e->lo8 && dev_alloc(e, &e->lo8, (size_t)e->rows_pad * D)) return give_up("the fp8 remainder buffer");
   for (auto& w : e->blocks) {
-    if (!w.proj_w2) {
-      if (int rc = dev_alloc(e, &w.proj_w2, (size_t)D * 2 * D, false)) return rc;
-      if (int rc = dev_alloc(e, &w.fc1_w2, (size_t)Hm * 2 * D, false)) return rc;
-    }
+    if ((need & 1) && !w.proj_w2) { if (dev_alloc(e, &w.proj_w2, (size_t)D * 2 * D, false)) return give_up("[W | W] of the out-projection"); fresh = true; }
+    if ((need & 2) && !w.fc1_w2) { if (dev_alloc(e, &w.fc1_w2, (size_t)Hm * 2 * D, false)) return give_up("[W | W] of fc1"); fresh = true; }
+    if ((need & 4) && !w.proj_w8) { if (dev_alloc(e, &w.proj_w8, (size_t)D * D, false)) return give_up("W8 of the out-projection"); fresh = true; }
+    if ((need & 8) && !w.fc1_w8) { if (dev_alloc(e, &w.fc1_w8, (size_t)Hm * D, false)) return give_up("W8 of fc1"); fresh = true; }
+  }
+  if (e->split_w_ready && !fresh) return need;
+  if (e->load_event && hipStreamWaitEvent(st, e->load_event, 0) != hipSuccess) return give_up("the wait for the weight conversion");
+  const int dt = e->cfg.compute_dtype;
+  for (auto& w : e->blocks) {
     for (int h = 0; h < 2; ++h) {
-      LATTE_HIP(hipMemcpy2DAsync(w.proj_w2 + h * D, (size_t)2 * D * 2, w.proj_w, (size_t)D * 2, (size_t)D * 2, D, hipMemcpyDeviceToDevice, st));
-      LATTE_HIP(hipMemcpy2DAsync(w.fc1_w2 + h * D, (size_t)2 * D * 2, w.fc1_w, (size_t)D * 2, (size_t)D * 2, Hm, hipMemcpyDeviceToDevice, st));
+      if (w.proj_w2 && hipMemcpy2DAsync(w.proj_w2 + h * D, (size_t)2 * D * 2, w.proj_w, (size_t)D * 2, (size_t)D * 2, D, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return give_up("the [W | W] copy");
+      if (w.fc1_w2 && hipMemcpy2DAsync(w.fc1_w2 + h * D, (size_t)2 * D * 2, w.fc1_w, (size_t)D * 2, (size_t)D * 2, Hm, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return give_up("the [W | W] copy");
     }
+    if (w.proj_w8 && launch_pack_w8(w.proj_w, w.proj_w8, (int64_t)D * D, dt, st)) return give_up("the W8 pack");
+    if (w.fc1_w8 && launch_pack_w8(w.fc1_w, w.fc1_w8, (int64_t)Hm * D, dt, st)) return give_up("the W8 pack");
   }
   e->split_w_ready = true;
-  return LATTE_OK;
+  return need;
 }
 
 // mod_override != nullptr: the adaLN outputs of this step were precomputed ([B or 1 rows, nmod], row stride mod_stride;
@@ -273,8 +303,14 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   tm.mark(C_PATCH);
   // split-operand linears of a guided call (latte_engine::guided_split); the K' = 2 K operands must stay inside the 32-bit buffer offsets
   int gsplit = cfg_dup ? e->guided_split : 0;
-  if (gsplit && (uint64_t)e->rows_pad * 2 * D * 2 >= (1ull << 32)) gsplit = 0;
-  if (gsplit && (rc = ensure_split_weights(e, st))) return rc;
+  if (dt != LATTE_DTYPE_F16) gsplit &= 3;                                          // the fp8 remainder exists beside f16 only
+  if (gsplit & 4) gsplit &= ~1;                                                    // one form per operand: fp8 wins
+  if (gsplit & 8) gsplit &= ~2;
+  if ((gsplit & 4) && !gemm_lo8_ok(M, D, D)) gsplit = (gsplit & ~4) | 1;          // no fp8 form for the shape (N % 192, K % 128): the f16 pair
+  if ((gsplit & 8) && !gemm_lo8_ok(M, e->Hm, D)) gsplit = (gsplit & ~8) | 2;
+  if ((gsplit & 3) && (uint64_t)e->rows_pad * 2 * D * 2 >= (1ull << 32)) gsplit &= ~3;
+  if (gsplit) gsplit = ensure_split_weights(e, gsplit, st);
+  int gactive = gsplit & 10;   // bits 1 / 3 always apply; bits 0 / 2 once a fused attention kernel has produced the pair
 
   for (int i = 0; i < c.depth; ++i) {
     const bool spatial = (i % 2) == 0;  // latte.py:345-346
@@ -295,8 +331,10 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       qa.xn = e->xn; qa.w = w.qkv_w; qa.bias = w.qkv_b; qa.out = e->qkv; qa.B = B; qa.F = F; qa.T = T; qa.D = D;
       qa.heads = c.num_heads; qa.hd = e->hd; qa.mode = spatial ? 0 : 1; qa.scale = 1.0f / std::sqrt((float)e->hd);
       qa.flags = ((e->fuse_qkv_attn >> 2) & 7) ^ 7;   // option bits 2-4 switch the default schedule features OFF (A/B hook)
-      split_proj = gsplit & 1;
-      qa.out_split = split_proj ? 1 : 0;              // [rows, 2 D] = [hi | lo] inside the [rows, 3 D] qkv buffer
+      split_proj = gsplit & 5;
+      qa.out_split = (gsplit & 4) ? 2 : (gsplit & 1);   // 1: [rows, 2 D] = [hi | lo] inside the [rows, 3 D] qkv buffer; 2: + fp8 remainder
+      qa.out8 = e->lo8;
+      gactive |= gsplit & 5;
       if ((rc = launch_qkv_attention(qa, dt, st))) return rc;
       tm.mark(spatial ? C_QKVATTN_S : C_QKVATTN_T);
       attn_out = e->qkv;
@@ -313,16 +351,20 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     }
     g.A = attn_out; g.W = w.proj_w; g.bias = w.proj_b; g.out = e->xres; g.gate = mb + 2 * D; g.N = D; g.K = D; g.tag = 0;
-    if (split_proj) { g.W = w.proj_w2; g.K = 2 * D; }   // [o_hi | o_lo] . [W | W]^T
+    if (split_proj && (gsplit & 4)) { g.A8 = e->lo8; g.W8 = w.proj_w8; }          // o_hi . W^T + o_lo8 . W8^T in one launch
+    else if (split_proj) { g.W = w.proj_w2; g.K = 2 * D; }                          // [o_hi | o_lo] . [W | W]^T
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
+    g.A8 = nullptr; g.W8 = nullptr;
     tm.mark(C_PROJ);
-    const bool split_fc1 = (gsplit & 2) != 0;
-    if ((rc = launch_ln_modulate(e->xres, e->xres, split_fc1 ? e->xn2 : e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st,
-                                 split_fc1 ? 1 : 0))) return rc;
+    const int split_fc1 = (gsplit & 8) ? 2 : (gsplit & 2) ? 1 : 0;
+    if ((rc = launch_ln_modulate(e->xres, e->xres, split_fc1 == 1 ? e->xn2 : e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st,
+                                 split_fc1, e->lo8))) return rc;
     tm.mark(C_LN);
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
-    if (split_fc1) { g.A = e->xn2; g.W = w.fc1_w2; g.K = 2 * D; }
+    if (split_fc1 == 1) { g.A = e->xn2; g.W = w.fc1_w2; g.K = 2 * D; }
+    if (split_fc1 == 2) { g.A8 = e->lo8; g.W8 = w.fc1_w8; }
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
+    g.A8 = nullptr; g.W8 = nullptr;
     tm.mark(C_FC1);
     g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
 
@@ -334,6 +376,7 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   if ((rc = launch_final_layer(e->xres, fm, fm + D, mstride, e->fin_wt, e->fin_b, out, M, D, rps, T, c.patch_size,
                                e->Cout, e->H, st))) return rc;
   tm.mark(C_FINAL);
+  if (cfg_dup) e->guided_split_active = gactive;
   return LATTE_OK;
 }
 
@@ -426,6 +469,7 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
 
   auto* e = new latte_engine();
   e->cfg = c;
+  if (c.compute_dtype != LATTE_DTYPE_F16) e->guided_split = 0;   // bf16 operands are a 3e-3 type at trained-scale gates, pair or not
   e->max_batch = max_batch;
   e->D = c.hidden_size;
   e->G = c.input_size / c.patch_size;
@@ -528,6 +572,7 @@ int latte_engine_create(const latte_model_config_t* cfg, int max_batch, latte_en
 void latte_engine_destroy(latte_engine_t* e) {
   if (!e) return;
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->load_event) (void)hipEventDestroy(e->load_event);
   delete e;
 }
 
@@ -571,7 +616,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     return LATTE_OK;
   }
   if (k == "guided_split") {
-    if (value < 0 || value > 3) return fail(LATTE_ERR_INVALID, "guided_split: bit 0 = attention output, bit 1 = fc1 operand carried as split pairs in guided calls (0..3)");
+    if (value < 0 || value > 15)
+      return fail(LATTE_ERR_INVALID, "guided_split: bit 0 / 1 = attention output / fc1 operand as f16 split pairs, bit 2 / 3 = the same with an fp8 remainder, in guided calls (0..15)");
     e->guided_split = (int)value;
     return LATTE_OK;
   }
@@ -581,6 +627,24 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     return LATTE_OK;
   }
   return fail(LATTE_ERR_INVALID, "set_option: unknown option '" + k + "'");
+}
+
+int latte_engine_get_option(const latte_engine_t* e, const char* name, int64_t* value) {
+  if (!e || !name || !value) return fail(LATTE_ERR_INVALID, "get_option: null argument");
+  const std::string k = name;
+  if (k == "gemm_variant") *value = e->gemm_variant;
+  else if (k == "gemm_variant_qkv") *value = e->gemm_variant_of[0];
+  else if (k == "gemm_variant_proj") *value = e->gemm_variant_of[1];
+  else if (k == "gemm_variant_fc1") *value = e->gemm_variant_of[2];
+  else if (k == "gemm_variant_fc2") *value = e->gemm_variant_of[3];
+  else if (k == "gated_split_k") *value = e->gated_split_k;
+  else if (k == "fuse_qkv_attn") *value = e->fuse_qkv_attn;
+  else if (k == "guided_split") *value = e->guided_split;
+  else if (k == "guided_split_active") *value = e->guided_split_active;
+  else if (k == "guided_split_failed") *value = e->split_failed ? 1 : 0;
+  else if (k == "seed") *value = (int64_t)e->seed;
+  else return fail(LATTE_ERR_INVALID, "get_option: unknown option '" + k + "'");
+  return LATTE_OK;
 }
 
 int latte_engine_load_tensor(latte_engine_t* e, const char* key, const float* data, int64_t numel, int on_device,
@@ -613,7 +677,11 @@ int latte_engine_load_tensor(latte_engine_t* e, const char* key, const float* da
   if (rc) return rc;
   if (!on_device) LATTE_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next call
   s.loaded = true;
-  if (s.kind == PK_H16) e->split_w_ready = false;   // a block weight changed: the [W | W] copies are stale
+  if (s.kind == PK_H16) {   // a block weight changed: the derived copies ([W | W], W8) are stale and must be rebuilt BEHIND this conversion
+    e->split_w_ready = false;
+    if (!e->load_event) LATTE_HIP(hipEventCreateWithFlags(&e->load_event, hipEventDisableTiming));
+    LATTE_HIP(hipEventRecord(e->load_event, st));
+  }
   if (s.key.compare(0, 11, "t_embedder.") == 0) {   // an installed timestep-embedding table was computed from the old weights
     e->temb_table_n = 0;
     e->temb_table_map.clear();
@@ -896,12 +964,17 @@ int64_t latte_training_workspace_floats(int batch, int64_t numel_per_sample) {
 
 int latte_profile_forward(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, float* out,
                           float* ms_out, int* launches_out, int n, void* stream) {
+  return latte_profile_forward_ex(e, x, t, y, batch, 0, out, ms_out, launches_out, n, stream);
+}
+
+int latte_profile_forward_ex(latte_engine_t* e, const float* x, const int64_t* t, const int64_t* y, int batch, int guided, float* out,
+                             float* ms_out, int* launches_out, int n, void* stream) {
   if (!e || !ms_out || !launches_out || n < LATTE_NUM_KERNEL_CLASSES) return fail(LATTE_ERR_INVALID, "profile_forward: bad arguments");
   int rc = latte_engine_check_weights(e);
   if (rc) return rc;
   Prof prof;
   hipStream_t st = (hipStream_t)stream;
-  rc = run_forward(e, x, t, y, batch, false, out, st, &prof);
+  rc = run_forward(e, x, t, y, batch, guided != 0, out, st, &prof);
   if (rc) return rc;
   LATTE_HIP(hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) {

@@ -1380,6 +1380,10 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     }
   }
 #endif
+  if (a.A8) {   // correction pass of a split operand (GemmArgs::A8 / W8): the rolling 12-wave kernel is the one that has it
+    if (!gemm_lo8_ok(a.M, a.N, a.K)) return fail(LATTE_ERR_INVALID, "gemm: the fp8 correction pass needs N % 192 == 0 and K % 128 == 0");
+    return launch_gemm_pw(a, epi, dtype, 1, st);
+  }
   if (variant == 0) variant = gemm_resolve_variant(a.M, a.N, a.K, epi);
   if (variant == 10 || variant == 11) return launch_gemm_pw(a, epi, dtype, variant == 11, st);
 #ifdef LATTE_GEMM_ABLATE

@@ -58,6 +58,19 @@ __device__ __forceinline__ void mfma16_first(f32x4& c, const u32x4& a, const u32
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
 }
 
+// Correction pass of the rolling kernel (GemmArgs::A8 / W8): one block-scaled fp8 MFMA = K = 128 of the contraction, in place like
+// mfma16_ip.  Operand maps established on the GPU against a CPU emulation by tools/mx_probe.hip (profiles/r6_mx_probe.log): lane l
+// supplies row (l & 15) and the 32 consecutive bytes k = 32 (l >> 4) ... + 31 of its operand in 8 VGPRs, byte op_sel (0 here) of the
+// lane's scale register is the E8M0 scale of those 32 elements, C / D as every 16 x 16 MFMA.  The kernel feeds it the two 16-byte
+// fragment reads of the half-precision K loop (chunk (l >> 4) and chunk 4 + (l >> 4) of a 128-byte LDS row) as ONE 32-byte operand:
+// both operands then hold the same 32 bytes-of-K per lane group, so the instruction contracts over a permutation of K -- the sum is
+// the same.  16 passes: the accumulator must not be read by a VALU within 19 wait states (the epilogue's two s_nop 15 cover it).
+typedef __attribute__((ext_vector_type(8))) unsigned int u32x8;
+__device__ __forceinline__ u32x8 cat8(const u32x4& lo, const u32x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ void mfma8_ip(f32x4& c, const u32x8& a, const u32x8& b, unsigned sa, unsigned sb) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int EPI, int DT, int TAG>
@@ -365,7 +378,11 @@ __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
 //   producer:            ... vmcnt(8) [stage u+1 landed], barrier B_u, issue B(u+2) and A(u+3)      (3 A stages, 2 B stages)
 // At a tile boundary the pipeline is drained (no look-ahead reads in the last half-step: the epilogue needs the registers)
 // and refilled from stage u + 1 after the epilogue.
-template <int EPI, int DT, int TAG>
+// LO (round 6): behind the K / 64 half-precision K tiles of an output tile the walk continues over K / 128 "virtual" K tiles of the
+// fp8 correction operands A8 / W8 (GemmArgs) -- a 128-byte row piece of an fp8 operand is K = 128, so a correction K tile has the
+// byte geometry, the LDS image, the swizzle and the DMA pieces of a half-precision one; the producers only switch descriptor and row
+// pitch, the consumers run lo_tile() (24 MFMAs of 16 passes on the same fragment reads) instead of ktile() (48 of 8 passes).
+template <int EPI, int DT, int TAG, bool LO = false>
 __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -398,6 +415,8 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     tn = in_group / gsz;
   };
   const int nk = K / 64;
+  const int nk8 = LO ? K / 128 : 0;               // correction K tiles behind the nk half-precision ones
+  const int nkt = nk + nk8;                       // K tiles of the walk per output tile
   const int ntile = (cnt - slot + per - 1) / per;
   constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -430,27 +449,48 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     const unsigned voff = (unsigned)lrow * row_bytes + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
     unsigned step32 = 32u * row_bytes;
     asm volatile("" : "+s"(step32));
+    // correction operands: rows of K bytes
+    const unsigned row_bytes8 = (unsigned)K;
+    const __amdgpu_buffer_rsrc_t rsA8 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? (const void*)g.A8 : (const void*)g.A), 0, (unsigned)tiles_m * BM * row_bytes8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB8 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? (const void*)g.W8 : (const void*)g.W), 0, (unsigned)g.N * row_bytes8, 0x00020000);
+    const unsigned voff8 = (unsigned)lrow * row_bytes8 + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
+    unsigned step32_8 = 32u * row_bytes8;
+    asm volatile("" : "+s"(step32_8));
     auto dma_a = [&](int tm_, int kt, int stg) {   // all 256 rows: row-groups pw + 4 j, j = 0..7
       char* sA = smem + stg * A_BYTES + pw * 1024;
+      if (LO && kt >= nk) {
+        const unsigned so = (unsigned)(tm_ * BM + pw * 8) * row_bytes8 + (unsigned)(kt - nk) * 128u;
+#pragma unroll
+        for (int j = 0; j < 2 * AH_INSTR; ++j) pw_bload_lds16(rsA8, sA + j * 4 * 1024, voff8, so + (unsigned)j * step32_8);
+        return;
+      }
       const unsigned so = (unsigned)(tm_ * BM + pw * 8) * row_bytes + (unsigned)kt * 128u;
 #pragma unroll
       for (int j = 0; j < 2 * AH_INSTR; ++j) pw_bload_lds16(rsA, sA + j * 4 * 1024, voff, so + (unsigned)j * step32);
     };
     auto dma_b = [&](int tn_, int kt, int stg) {
       char* sB = smem + B_BASE + stg * B_BYTES + pw * 1024;
+      if (LO && kt >= nk) {
+        const unsigned so = (unsigned)(tn_ * BN + pw * 8) * row_bytes8 + (unsigned)(kt - nk) * 128u;
+#pragma unroll
+        for (int j = 0; j < BG_INSTR; ++j) pw_bload_lds16(rsB8, sB + j * 4 * 1024, voff8, so + (unsigned)j * step32_8);
+        return;
+      }
       const unsigned so = (unsigned)(tn_ * BN + pw * 8) * row_bytes + (unsigned)kt * 128u;
 #pragma unroll
       for (int j = 0; j < BG_INSTR; ++j) pw_bload_lds16(rsB, sB + j * 4 * 1024, voff, so + (unsigned)j * step32);
     };
     struct Walk { int pos, tm, tn, kt; };
     auto advance = [&](Walk& w) {
-      if (++w.kt == nk) {
+      if (++w.kt == nkt) {
         w.kt = 0;
         w.pos += per;
         if (w.pos < cnt) decode(chunk0 + w.pos, w.tm, w.tn);
       }
     };
-    const int U = ntile * nk;
+    const int U = ntile * nkt;
     Walk wb{slot, 0, 0, 0};
     decode(chunk0 + slot, wb.tm, wb.tn);
     Walk wa = wb;
@@ -677,6 +717,63 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     LATTE_TS(3)
   };
 
+  // ---- correction K tiles (LO): the B pairs of the tile in b8, the A pairs in a ring of four (a8[i & 3] = fragment row i); same
+  // one-barrier protocol as ktile(): every read of stage u has returned in front of B_u, stage u + 1 is read behind it.
+  //   rows 0-3: 3 MFMAs each, the pair of row i + 4 rolls into the ring slot just read | rows 4-5 | lgkmcnt(0), B_u |
+  //   rows 6-7, with LOOK the pairs of stage u + 1 roll in behind the MFMAs that free their registers (A rows 0-3, then B)
+  u32x8 b8[FN], a8[4];
+  unsigned sc_w = 0, sc_a = 0;
+  if constexpr (LO) {
+    sc_w = 127u - LO8_W_SHIFT;
+    sc_a = 127u - LO8_A_SHIFT;
+    asm volatile("" : "+v"(sc_w), "+v"(sc_a));
+  }
+  auto pair_a = [&](const char* sA, int i) {
+    return cat8(*(const u32x4*)(sA + (a_off + i * 2048)), *(const u32x4*)(sA + ((a_off + i * 2048) ^ 64)));
+  };
+  auto pair_b = [&](const char* sB, int j) {
+    return cat8(*(const u32x4*)(sB + (b_off + j * 2048)), *(const u32x4*)(sB + ((b_off + j * 2048) ^ 64)));
+  };
+  auto lo_fill = [&](const char* sA, const char* sB) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b8[j] = pair_b(sB, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a8[i] = pair_a(sA, i);
+  };
+  auto lo_tile = [&](const char* sA, const char* sAn, const char* sBn, auto look) {
+    constexpr bool LOOK = decltype(look)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma8_ip(acc[i][j], b8[j], a8[i], sc_w, sc_a);
+      a8[i] = pair_a(sA, i + 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 4; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma8_ip(acc[i][j], b8[j], a8[i & 3], sc_w, sc_a);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (LOOK) {
+      a8[0] = pair_a(sAn, 0);
+      a8[1] = pair_a(sAn, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) mfma8_ip(acc[6][j], b8[j], a8[2], sc_w, sc_a);
+    if constexpr (LOOK) a8[2] = pair_a(sAn, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      mfma8_ip(acc[7][j], b8[j], a8[3], sc_w, sc_a);
+      if constexpr (LOOK) b8[j] = pair_b(sBn, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LOOK) a8[3] = pair_a(sAn, 3);
+  };
+
   int it = 0, ia = 0;
   for (;;) {
     for (int kt = 0; kt + 1 < nk; ++kt, ++it) {
@@ -689,6 +786,18 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       ia = ia == NA - 1 ? 0 : ia + 1;
       ktile(sA, nullptr, nullptr, std::false_type{});
       ++it;
+      if constexpr (LO) {   // the correction K tiles: stage `it` landed at the barrier of the tile above
+        lo_fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
+        for (int k8 = 0; k8 + 1 < nk8; ++k8, ++it) {
+          const char* sA8 = smem + ia * A_BYTES;
+          ia = ia == NA - 1 ? 0 : ia + 1;
+          lo_tile(sA8, smem + ia * A_BYTES, smem + ((it + 1) & 1) * B_BYTES, std::true_type{});
+        }
+        const char* sA8 = smem + ia * A_BYTES;
+        ia = ia == NA - 1 ? 0 : ia + 1;
+        lo_tile(sA8, nullptr, nullptr, std::false_type{});
+        ++it;
+      }
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see mfma16_ip)
       epilogue(tm, tn);
       LATTE_TS(4)
@@ -1046,6 +1155,25 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     return LATTE_OK;
   }
 #endif
+  if (a.A8) {   // correction pass (GemmArgs::A8 / W8): the rolling kernel's LO instantiations, out-projection and fc1 of guided calls
+    if (!roll || !a.W8 || a.K % 128 != 0 || !(epi == EPI_GATE_RES_F32 || epi == EPI_BIAS_GELU_H16) || DT != LATTE_DTYPE_F16)
+      return fail(LATTE_ERR_INVALID, "gemm (correction pass): rolling kernel, f16 operands, K % 128 == 0, gated-residual or GELU epilogue only");
+    if constexpr (DT == LATTE_DTYPE_F16) {
+      if (epi == EPI_GATE_RES_F32) {
+        auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 0, true>;
+        static std::atomic<uint64_t> attr_done{0};
+        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+      } else {
+        auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_H16, DT, 0, true>;
+        static std::atomic<uint64_t> attr_done{0};
+        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+      }
+    }
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   if (epi == EPI_GATE_RES_F32 && a.tag == 1) LATTE_PW_CASE(EPI_GATE_RES_F32, 1)
   else if (epi == EPI_GATE_RES_F32) LATTE_PW_CASE(EPI_GATE_RES_F32, 0)
   else if (epi == EPI_BIAS_F32) LATTE_PW_CASE(EPI_BIAS_F32, 0)
@@ -1061,6 +1189,11 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
 }
 
 }  // namespace
+
+bool gemm_lo8_ok(int M, int N, int K) {
+  return M > 0 && N % 192 == 0 && K % 128 == 0 && K >= 128 && (uint64_t)((M + 255) / 256 * 256) * K * 2 < (1ull << 32) &&
+         (uint64_t)N * K * 2 < (1ull << 32);
+}
 
 // variant 10: limits of the 32-bit buffer offsets and K >= 128 as for the persistent kernel; whole 192-wide tile columns
 int launch_gemm_pw(const GemmArgs& a, int epi, int dtype, int roll, hipStream_t st) {

@@ -49,6 +49,20 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned int& hi, uns
   }
 }
 
+// fp8 remainder of a split operand (round 6, common.h: LO8_A_SHIFT): four values -> their nearest f16 (hi01 / hi23) and ONE word of
+// four OCP e4m3 codes of (v - hi) * 2^LO8_A_SHIFT, clamped to the format's +-448 (the conversion itself does not saturate): the operand
+// of the GEMMs' block-scaled correction pass (gemm_pw.hip), whose constant E8M0 scale multiplies the 2^-LO8_A_SHIFT back.
+__device__ __forceinline__ unsigned int split8_f16(float v0, float v1, float v2, float v3, unsigned int& hi01, unsigned int& hi23) {
+  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
+  hi01 = pack2<LATTE_DTYPE_F16>((float)h0, (float)h1);
+  hi23 = pack2<LATTE_DTYPE_F16>((float)h2, (float)h3);
+  constexpr float S = (float)(1 << LO8_A_SHIFT);
+  auto cl = [](float r) { return __builtin_fminf(__builtin_fmaxf(r, -448.f), 448.f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v0 - (float)h0) * S), cl((v1 - (float)h1) * S), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v2 - (float)h2) * S), cl((v3 - (float)h3) * S), w, true);
+  return (unsigned int)w;
+}
+
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

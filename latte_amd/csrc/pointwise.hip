@@ -44,6 +44,20 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned int& hi, uns
   }
 }
 
+// fp8 remainder of a split operand (round 6, common.h: LO8_A_SHIFT): four values -> their nearest f16 (hi01 / hi23) and ONE word of
+// four OCP e4m3 codes of (v - hi) * 2^LO8_A_SHIFT, clamped to the format's +-448 (the conversion itself does not saturate) -- the
+// operand of the GEMMs' block-scaled correction pass (gemm_pw.hip), whose constant E8M0 scale multiplies the 2^-LO8_A_SHIFT back.
+__device__ __forceinline__ unsigned int split8_f16(float v0, float v1, float v2, float v3, unsigned int& hi01, unsigned int& hi23) {
+  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
+  hi01 = pack2<LATTE_DTYPE_F16>((float)h0, (float)h1);
+  hi23 = pack2<LATTE_DTYPE_F16>((float)h2, (float)h3);
+  constexpr float S = (float)(1 << LO8_A_SHIFT);
+  auto cl = [](float r) { return __builtin_fminf(__builtin_fmaxf(r, -448.f), 448.f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v0 - (float)h0) * S), cl((v1 - (float)h1) * S), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v2 - (float)h2) * S), cl((v3 - (float)h3) * S), w, true);
+  return (unsigned int)w;
+}
+
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -52,12 +66,14 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 // Two-pass statistics in registers.
 // SPLIT: y is [M, 2 D] -- columns [0, D) the half nearest to the value, [D, 2 D) the half nearest to the remainder (mfma_util.h:
 // split2): the K-concatenated operand of a linear whose weight is stored [W | W].
-template <int NCH, int DT, bool ADD_TE, bool SPLIT = false>
+// SPLIT == 2 (f16 only): y stays [M, D] (the nearest f16) and y8 [M, D] bytes receives the fp8 remainder (split8_f16) -- the operand
+// pair of a GEMM with the fp8 correction pass (GemmArgs::A8).
+template <int NCH, int DT, bool ADD_TE, int SPLIT = 0>
 __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restrict__ x_in, float* x_rw,
                                                           half_t* __restrict__ y, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, int mod_stride, int M,
                                                           int rows_per_sample, const float* __restrict__ te, int T,
-                                                          int F) {
+                                                          int F, unsigned char* __restrict__ y8 = nullptr) {
   constexpr int D = NCH * 128;
   constexpr int NT = NCH * 32;            // float4 chunks per row
   constexpr int NQ = (NT + 63) / 64;      // chunk groups per lane
@@ -110,7 +126,7 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-  u32x2_t* yr = (u32x2_t*)(y + (size_t)row * (SPLIT ? 2 * D : D));
+  u32x2_t* yr = (u32x2_t*)(y + (size_t)row * (SPLIT == 1 ? 2 * D : D));
 #pragma unroll
   for (int c = 0; c < NQ; ++c) {
     if (has(c)) {
@@ -119,13 +135,18 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const float* __restric
       const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
       const float o2 = (v[c].z - mean) * rstd * (1.0f + b.z) + a.z;
       const float o3 = (v[c].w - mean) * rstd * (1.0f + b.w) + a.w;
-      if constexpr (SPLIT) {
+      if constexpr (SPLIT == 1) {
         unsigned int h0_, l0_, h1_, l1_;
         split2<DT>(o0, o1, h0_, l0_);
         split2<DT>(o2, o3, h1_, l1_);
         const u32x2_t hi = {h0_, h1_}, lo = {l0_, l1_};
         yr[c * 64 + lane] = hi;
         yr[NT + c * 64 + lane] = lo;     // + D halves = NT 8-byte chunks
+      } else if constexpr (SPLIT == 2) {
+        unsigned int h0_, h1_;
+        const unsigned int l8 = split8_f16(o0, o1, o2, o3, h0_, h1_);
+        yr[c * 64 + lane] = (u32x2_t){h0_, h1_};
+        ((unsigned int*)(y8 + (size_t)row * D))[c * 64 + lane] = l8;
       } else {
         yr[c * 64 + lane] = (u32x2_t){pack2<DT>(o0, o1), pack2<DT>(o2, o3)};
       }
@@ -712,6 +733,23 @@ __global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ 
   }
 }
 
+// W8 of the GEMMs' fp8 correction pass (common.h: LO8_W_SHIFT): four f16 weights -> four OCP e4m3 codes of w * 2^LO8_W_SHIFT, clamped
+__global__ void pack_w8_kernel(const half_t* __restrict__ in, unsigned char* __restrict__ out, size_t n4) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  constexpr float S = (float)(1 << LO8_W_SHIFT);
+  auto cl = [](float r) { return __builtin_fminf(__builtin_fmaxf(r, -448.f), 448.f); };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x2_t v = ((const u32x2_t*)in)[i];
+    // (scalar copies first: bit-casting the vector elements directly is miscompiled into re-using element 0, gemm.hip)
+    const unsigned int lo = v[0], hi = v[1];
+    const float w0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu)), w1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
+    const float w2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu)), w3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(w0 * S), cl(w1 * S), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(w2 * S), cl(w3 * S), w, true);
+    ((unsigned int*)out)[i] = (unsigned int)w;
+  }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   const size_t total = (size_t)rows * cols;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -824,18 +862,29 @@ int launch_training_terms(const float* tables, int n_steps, int mean_type, int v
 
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T, int F,
-                       int dtype, hipStream_t st, int split) {
+                       int dtype, hipStream_t st, int split, unsigned char* y8) {
   if (D % 128 != 0) return fail(LATTE_ERR_INVALID, "ln_modulate: D % 128 != 0");
   dim3 grid((M + 3) / 4), block(256);
+  if (split == 2) {   // [M, D] f16 + [M, D] fp8 remainder (the fp8 correction operand of the GEMM behind it)
+    if (temp_embed || !y8 || dtype != LATTE_DTYPE_F16)
+      return fail(LATTE_ERR_INVALID, "ln_modulate: the fp8-remainder output is f16 only, needs y8 and has no temp_embed form");
+#define LN_LAUNCH_SPLIT8(NCH)                                                                                          \
+  hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false, 2>), grid, block, 0, st, x_in, x_rw, y, shift, scale, \
+                     mod_stride, M, rows_per_sample, temp_embed, T, F, y8)
+    LATTE_NCH_SWITCH(D, LN_LAUNCH_SPLIT8)
+#undef LN_LAUNCH_SPLIT8
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   if (split) {   // [M, 2 D] split-operand output (no temp_embed form: the LayerNorm in front of fc1 never adds it)
     if (temp_embed) return fail(LATTE_ERR_INVALID, "ln_modulate: the split-operand output has no temp_embed form");
 #define LN_LAUNCH_SPLIT(NCH)                                                                                   \
   do {                                                                                                         \
     if (dtype == LATTE_DTYPE_BF16)                                                                             \
-      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, false, true>), grid, block, 0, st, x_in, x_rw, y, \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_BF16, false, 1>), grid, block, 0, st, x_in, x_rw, y, \
                          shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                      \
     else                                                                                                       \
-      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false, true>), grid, block, 0, st, x_in, x_rw, y, \
+      hipLaunchKernelGGL((ln_modulate_kernel<NCH, LATTE_DTYPE_F16, false, 1>), grid, block, 0, st, x_in, x_rw, y, \
                          shift, scale, mod_stride, M, rows_per_sample, temp_embed, T, F);                      \
   } while (0)
     LATTE_NCH_SWITCH(D, LN_LAUNCH_SPLIT)
@@ -1031,6 +1080,13 @@ int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype
     hipLaunchKernelGGL(widen_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
   else
     hipLaunchKernelGGL(widen_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_pack_w8(const half_t* in, unsigned char* out, int64_t n, int dtype, hipStream_t st) {
+  if (dtype != LATTE_DTYPE_F16 || n % 4) return fail(LATTE_ERR_INVALID, "pack_w8: f16 weights, n % 4 == 0");
+  hipLaunchKernelGGL(pack_w8_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, in, out, (size_t)(n / 4));
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -91,7 +91,7 @@ constexpr int FUSED_LDS = BIAS_OFF + 288 * 4;
 // SPLIT: the output leaves as [hi | lo] pairs, row pitch 2 D (QkvAttnArgs::out_split) -- a template parameter, not a run-time branch: a
 // branch on the kernel argument inside the attention phase changed the f16 instantiation's results (hipcc, ROCm 7.2; the bf16 one was
 // unaffected), so the plain kernel stays byte for byte what rounds 3 / 4 measured and verified.
-template <int HD, int DT, int MODE, int FLAGS, bool SPLIT = false>
+template <int HD, int DT, int MODE, int FLAGS, int SPLIT = 0>
 __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   constexpr bool EARLY = (FLAGS & 1) != 0, PRIO = (FLAGS & 2) != 0;
   constexpr int NQ = 3 * HD;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
   const int D = a.D, T = a.T, F = a.F;
-  const int out_ld = SPLIT ? 2 * D : D;   // row pitch of the output in halves
+  const int out_ld = SPLIT == 1 ? 2 * D : D;   // row pitch of the output in halves
   const unsigned row_bytes = (unsigned)D * 2u;
   const int nk = D / 64;
 
@@ -440,13 +440,18 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
           for (int d = 0; d < DF; ++d) {
             const int dd = 16 * d + 4 * g;
             if (dd < HD) {
-              if constexpr (SPLIT) {   // [hi | lo]: the out-projection's K-concatenated operand
+              if constexpr (SPLIT == 1) {   // [hi | lo]: the out-projection's K-concatenated operand
                 unsigned int h0_, l0_, h1_, l1_;
                 split2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], h0_, l0_);
                 split2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq], h1_, l1_);
                 const u32x2 hi = {h0_, h1_}, lo = {l0_, l1_};
                 *(u32x2*)(orow + dd) = hi;
                 *(u32x2*)(orow + D + dd) = lo;
+              } else if constexpr (SPLIT == 2) {   // f16 + fp8 remainder: the out-projection's correction operand (GemmArgs::A8)
+                unsigned int h0_, h1_;
+                const unsigned int l8 = split8_f16(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq], h0_, h1_);
+                *(u32x2*)(orow + dd) = (u32x2){h0_, h1_};
+                *(unsigned int*)(a.out8 + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD + dd) = l8;
               } else {
                 const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
                                   pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
@@ -512,13 +517,18 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
           oacc = mfma_k16h<DT>(vf[d], pb, oacc);                               // O^T[d = 16 d + 4g + r][q = fr]
           const int dd = 16 * d + 4 * g;
           if (dd < HD) {
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
               unsigned int h0_, l0_, h1_, l1_;
               split2<DT>(oacc[0] * inv, oacc[1] * inv, h0_, l0_);
               split2<DT>(oacc[2] * inv, oacc[3] * inv, h1_, l1_);
               const u32x2 hi = {h0_, h1_}, lo = {l0_, l1_};
               *(u32x2*)(orow + dd) = hi;
               *(u32x2*)(orow + D + dd) = lo;
+            } else if constexpr (SPLIT == 2) {
+              unsigned int h0_, h1_;
+              const unsigned int l8 = split8_f16(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv, h0_, h1_);
+              *(u32x2*)(orow + dd) = (u32x2){h0_, h1_};
+              *(unsigned int*)(a.out8 + (size_t)(row_base + fr * T + p) * D + head * HD + dd) = l8;
             } else {
               const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
               *(u32x2*)(orow + dd) = pk;
@@ -548,7 +558,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   }
 }
 
-template <int HD, int DT, int MODE, int FLAGS, bool SPLIT = false>
+template <int HD, int DT, int MODE, int FLAGS, int SPLIT = 0>
 int launch_one(const QkvAttnArgs& a, dim3 grid, hipStream_t st) {
   auto kern = qkv_attn_kernel<HD, DT, MODE, FLAGS, SPLIT>;
   static std::atomic<uint64_t> done{0};
@@ -563,8 +573,16 @@ int launch_mode(const QkvAttnArgs& a, hipStream_t st) {
   const int S = a.mode == 0 ? a.B * a.F : a.B * (a.T >> 4);
   const int units = S * a.heads;
   const dim3 grid(units >= 256 ? 256 : (units + 7) / 8 * 8);   // one workgroup per CU, a multiple of the 8 XCDs
+  if (a.out_split == 2) {   // f16 + fp8 remainder (f16 only)
+    if constexpr (DT == LATTE_DTYPE_F16) {
+      if (!a.out8) return fail(LATTE_ERR_INVALID, "fused qkv + attention: out_split 2 needs out8");
+      return a.mode == 0 ? launch_one<HD, DT, 0, 3, 2>(a, grid, st) : launch_one<HD, DT, 1, 1, 2>(a, grid, st);
+    } else {
+      return fail(LATTE_ERR_INVALID, "fused qkv + attention: the fp8-remainder output is f16 only");
+    }
+  }
   if (a.out_split)   // the split-pair output exists for the default schedule of each mode
-    return a.mode == 0 ? launch_one<HD, DT, 0, 3, true>(a, grid, st) : launch_one<HD, DT, 1, 1, true>(a, grid, st);
+    return a.mode == 0 ? launch_one<HD, DT, 0, 3, 1>(a, grid, st) : launch_one<HD, DT, 1, 1, 1>(a, grid, st);
   if (a.mode == 0) {
     switch (a.flags & 3) {
       case 0: return launch_one<HD, DT, 0, 0>(a, grid, st);

@@ -10,6 +10,8 @@ import math
 import os
 
 import numpy as np
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -245,6 +247,9 @@ class Latte(nn.Module):
                 check(lib.latte_engine_create(cfg, want, h))
             rec = self._engines[dtype] = [h, key, False]
             self.max_batch = want
+            for (odt, name), value in getattr(self, "_engine_options", {}).items():   # options survive a re-creation (larger batch)
+                if odt == dtype:
+                    check(lib.latte_engine_set_option(h, name.encode(), int(value)))
         if not rec[2]:
             sd = self.state_dict()
             with torch.cuda.device(dev):
@@ -260,7 +265,18 @@ class Latte(nn.Module):
         return rec[0]
 
     def set_engine_option(self, name, value, batch=1, guided=False):
+        """``latte_engine_set_option`` on the engine this call shape uses; remembered per operand type and re-applied when the
+        engine is re-created for a larger batch."""
         check(load_library().latte_engine_set_option(self.engine(batch, guided), name.encode(), int(value)))
+        if not hasattr(self, "_engine_options"):
+            self._engine_options = {}
+        self._engine_options[(self.operand_dtype(guided), name)] = int(value)
+
+    def get_engine_option(self, name, batch=1, guided=False):
+        """``latte_engine_get_option``: the current value of an option, or a read-only fact such as "guided_split_active"."""
+        v = _lib.c_i64(0)
+        check(load_library().latte_engine_get_option(self.engine(batch, guided), name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     # ------------------------------------------------------------------ the model-callable protocol
     def _set_text(self, text_embedding, B, guided=False):
@@ -329,20 +345,21 @@ class Latte(nn.Module):
                                                         ptr(out), stream_ptr()))
         return out
 
-    def profile_forward(self, x, t, y=None):
-        """One eager forward with HIP events around every launch -> {class: (ms, launches)} (bench.py)."""
+    def profile_forward(self, x, t, y=None, guided=False):
+        """One eager forward with HIP events around every launch -> {class: (ms, launches)} (bench.py).  ``guided``: the denoiser
+        call of ``forward_with_cfg`` (split operands per the engine option ``guided_split``), without the guidance combination."""
         names = ["gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial", "attn_temporal", "ln_modulate",
                  "embed_cond", "patch_embed", "final_layer", "qkv_attn_spatial", "qkv_attn_temporal"]
         x32, t64, y64 = self._prep(x, t, y)
         B = x32.shape[0]
-        eng = self.engine(B)
+        eng = self.engine(B, guided)
         out = torch.empty(B, self.num_frames, self.out_channels, self.input_size, self.input_size,
                           device=x32.device, dtype=torch.float32)
         ms = (_lib.c_f32 * len(names))()
         cnt = (_lib.c_int * len(names))()
         with torch.cuda.device(x32.device):
-            check(load_library().latte_profile_forward(eng, ptr(x32), ptr(t64), ptr(y64), B, ptr(out), ms, cnt,
-                                                       len(names), stream_ptr()))
+            check(load_library().latte_profile_forward_ex(eng, ptr(x32), ptr(t64), ptr(y64), B, 1 if guided else 0, ptr(out), ms, cnt,
+                                                          len(names), stream_ptr()))
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names)}
 
 

@@ -100,10 +100,18 @@ def text_projection_weight(D: int, seed: int = 0, scale: float = 0.01) -> torch.
     return torch.from_numpy((v * scale).astype(np.float32)).reshape(D, TEXT_TOKENS * TEXT_DIM)
 
 
-def init_state_dict(cfg: LatteConfig, seed: int = 0, gate_std: float = 0.02) -> dict:
+def init_state_dict(cfg: LatteConfig, seed: int = 0, gate_std: float = 0.02, final_std: float = None,
+                    v_scale: float = 1.0) -> dict:
     """Synthetic reference-format weights.  Same *distributions* as ``initialize_weights``
     (latte.py:257-295) but NOT the same RNG stream; every tensor the reference zero-inits
-    (adaLN modulation, final layer) is drawn N(0, gate_std) so outputs are non-trivial."""
+    (adaLN modulation, final layer) is drawn N(0, gate_std) so outputs are non-trivial.
+
+    ``final_std`` (default: gate_std) is the scale of ``final_layer.linear.{weight,bias}`` alone and ``v_scale`` multiplies the
+    rows of that layer which produce the learned-range variance channels v (unpatchify's last index c >= in_channels,
+    latte.py:297-310, split at gaussian_diffusion.py:291).  A trained checkpoint predicts eps of rms ~ 1 and v inside [-1, 1]
+    (frac = (v + 1) / 2 interpolates two log-variances, gaussian_diffusion.py:292-297); gate_std 0.3 on the final layer gives rms ~ 10
+    for both, which makes the last DDPM step exponentiate far outside that range (profiles/r5_ddpm_conditioning.log).  Both
+    are post-scalings of the same draws, so the RNG stream -- and every fixture generated with the defaults -- is unchanged."""
     g = torch.Generator("cpu").manual_seed(seed)
     D, p, C = cfg.hidden_size, cfg.patch_size, cfg.in_channels
     Hm = int(D * cfg.mlp_ratio)
@@ -141,8 +149,13 @@ def init_state_dict(cfg: LatteConfig, seed: int = 0, gate_std: float = 0.02) -> 
         sd[pre + "mlp.fc2.bias"] = normal(D)
         sd[pre + "adaLN_modulation.1.weight"] = normal(6 * D, D, std=gate_std)
         sd[pre + "adaLN_modulation.1.bias"] = normal(6 * D, std=gate_std)
-    sd["final_layer.linear.weight"] = normal(p * p * cfg.out_channels, D, std=gate_std)
-    sd["final_layer.linear.bias"] = normal(p * p * cfg.out_channels, std=gate_std)
+    fstd = gate_std if final_std is None else final_std
+    sd["final_layer.linear.weight"] = normal(p * p * cfg.out_channels, D, std=fstd)
+    sd["final_layer.linear.bias"] = normal(p * p * cfg.out_channels, std=fstd)
+    if v_scale != 1.0 and cfg.out_channels > C:
+        vrows = (torch.arange(p * p * cfg.out_channels) % cfg.out_channels) >= C      # row = (p q) * out_channels + c
+        sd["final_layer.linear.weight"][vrows] *= v_scale
+        sd["final_layer.linear.bias"][vrows] *= v_scale
     sd["final_layer.adaLN_modulation.1.weight"] = normal(2 * D, D, std=gate_std)
     sd["final_layer.adaLN_modulation.1.bias"] = normal(2 * D, std=gate_std)
     return sd

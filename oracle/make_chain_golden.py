@@ -29,6 +29,15 @@ Round 5 -- BASELINE config 3's own model and call (sample/sample_ddp.py:140-160:
 ``forward_with_cfg``, latte.py:379-398, cfg_scale 7.0) at trained-scale gates, full length:
   xl_guided_g03 Latte-XL/2 16 x 32x32 class-cond (label 23 + null class), CFG 7.0, B = 1 (2 rows), gate_std 0.3   250 (ddim, ddpm: the
                 YAMLs' default sample_method)   -> chain250_xl.npz
+Round 6 -- the YAML-default sampler (DDPM, configs/ffs/ffs_sample.yaml:23-24) on WELL-CONDITIONED trained-scale weights.  The ``*_g03`` cases
+above also draw ``final_layer.linear`` at 0.3, which makes eps and the learned-range v come out at rms ~ 10: the chains run at latent rms
+1e3 - 1e6 and the reference's own last DDPM step exponentiates v far outside [-1, 1] (gaussian_diffusion.py:292-297), amplifying ANY relative
+difference 3.2 x (profiles/r5_ddpm_conditioning.log).  They stay as stress rows.  The ``*_g03b`` / ``xl_uncond_g03`` cases keep every gate at
+0.3 but draw the final projection as a trained checkpoint has it -- ``init_state_dict(final_std=0.03, v_scale=0.15)``: eps of rms ~ 1 (x CFG),
+|v| < 0.6 on every step so ``frac`` stays inside [0, 1] -- and the latents stay at rms 1 ... 6e2 (the growth a random eps-model gives any chain):
+  b2_guided_g03b  Latte-B/2  16 x 16x16 class-cond, CFG 7.0                                    250 (ddim, ddpm)
+  xl_uncond_g03   Latte-XL/2 16 x 32x32 unconditional, B = 1: BASELINE config 2's own chain    250 (ddpm)         -> chain250_xl.npz
+  xl_guided_g03b  Latte-XL/2 16 x 32x32 class-cond (label 23 + null), CFG 7.0, B = 1 (2 rows)  250 (ddpm)         -> chain250_xl.npz
 ``--only a,b`` regenerates the named cases and merges them into the existing file (the XL chains take ~30 min each, the guided one
 ~75 min per sampler); ``--methods ddpm`` restricts the regenerated cases to the named samplers (the others are kept from the file).
 """
@@ -66,10 +75,17 @@ CASES = {
     "xl_full_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 101, 102, 103, 1, None, 250, ("ddim",)),
     "xl_guided_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 111, 112, 113, 1, [23], 250,
                       ("ddim", "ddpm")),
+    "b2_guided_g03b": ("Latte-B/2", dict(input_size=16, num_frames=16, num_classes=101, extras=2), 121, 122, 123, 1, [5], 250,
+                       ("ddim", "ddpm")),
+    "xl_uncond_g03": ("Latte-XL/2", dict(input_size=32, num_frames=16, extras=1), 131, 132, 133, 1, None, 250, ("ddpm",)),
+    "xl_guided_g03b": ("Latte-XL/2", dict(input_size=32, num_frames=16, num_classes=101, extras=2), 141, 142, 143, 1, [23], 250,
+                       ("ddpm",)),
 }
 GATE_STD = {"s2_uncond_g03": 0.3, "b2_uncond_g03": 0.3, "b2_guided_g03": 0.3, "xl_full_g03": 0.3,
-            "xl_guided_g03": 0.3}   # default 0.02
-XL_FILE_CASES = ("xl_full", "xl_full_g03", "xl_guided_g03")
+            "xl_guided_g03": 0.3, "b2_guided_g03b": 0.3, "xl_uncond_g03": 0.3, "xl_guided_g03b": 0.3}   # default 0.02
+# name -> (final_std, v_scale) of init_state_dict: the final projection at trained-checkpoint output scale (default: gate_std, 1.0)
+FINAL = {"b2_guided_g03b": (0.03 * (1152 / 768) ** 0.5, 0.15), "xl_uncond_g03": (0.03, 0.15), "xl_guided_g03b": (0.03, 0.15)}
+XL_FILE_CASES = ("xl_full", "xl_full_g03", "xl_guided_g03", "xl_uncond_g03", "xl_guided_g03b")
 
 
 def case_file(name):
@@ -81,7 +97,8 @@ def case_inputs(name):
     x0 = cat([z, z]), y = [labels..., null class...] (sample/sample.py:92-99)."""
     preset, kw, wseed, xseed, nseed, B, labels, steps, methods = CASES[name]
     cfg = lo.preset_config(preset, **kw)
-    sd = lo.init_state_dict(cfg, seed=wseed, gate_std=GATE_STD.get(name, 0.02))
+    fstd, vsc = FINAL.get(name, (None, 1.0))
+    sd = lo.init_state_dict(cfg, seed=wseed, gate_std=GATE_STD.get(name, 0.02), final_std=fstd, v_scale=vsc)
     g = torch.Generator("cpu").manual_seed(xseed)
     z = torch.randn(B, kw["num_frames"], 4, kw["input_size"], kw["input_size"], generator=g)
     if labels is None:
@@ -136,16 +153,18 @@ def main():
                 fn, mk = model.forward, dict(y=None)
             else:
                 fn, mk = model.forward_with_cfg, dict(y=y, cfg_scale=CFG_SCALE)
-            keep = []
+            keep, rms = [], []
             torch.manual_seed(nseed)
             with torch.no_grad():
                 for k, r in enumerate(loop(fn, x0.shape, noise=x0.clone(), clip_denoised=False, model_kwargs=mk, device="cpu")):
+                    rms.append(float(r["sample"].pow(2).mean().sqrt()))
                     if (k + 1) % EVERY == 0 or k + 1 == steps:
                         keep.append((k, r["sample"].clone()))
                     if k + 1 == steps:
                         break
             arrays[case_file(name)][f"{name}::{method}::steps"] = np.asarray([k for k, _ in keep], dtype=np.int64)
             arrays[case_file(name)][f"{name}::{method}::samples"] = torch.stack([v for _, v in keep]).numpy()
+            arrays[case_file(name)][f"{name}::{method}::rms"] = np.asarray(rms, dtype=np.float32)      # latent rms after every step
             msg = f"{name} {method}: {steps} reference steps in {time.time() - t0:.1f}s, |x_final| rms {float(keep[-1][1].pow(2).mean().sqrt()):.3f}"
             if not name.startswith("xl"):   # the oracle beside the reference (pin over the full chain length)
                 nz = chain_noises(nseed, x0.shape, steps)
