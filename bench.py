@@ -252,6 +252,31 @@ def vae_decoder_flops(h):
     return f + conv(H, 128, 3)
 
 
+def vae_temporal_decoder_flops(h):
+    """Algorithmic FLOPs PER FRAME of AutoencoderKLTemporalDecoder.decode at an h x h latent (stable-video-diffusion's VAE decoder as
+    oracle/vae_temporal_oracle.py restates it): the SD-VAE decoder without post_quant_conv, plus, behind every one of the 14 resnets, a temporal
+    resnet of two Conv3d (3, 1, 1) c -> c at that resnet's output width / resolution (2 * pixels * c * c * 3 each), plus the 3-tap
+    time_conv_out on RGB.  -> (total, FLOPs of the convolutions that run on the MFMA implicit-GEMM kernels: 3x3 spatial + (3,1,1) temporal).
+    Counted ONCE: the engine runs the spatial convolutions with a second pass on the activation remainder and the temporal ones as three
+    split-operand passes for parity -- that is cost, not algorithmic work."""
+    conv3 = lambda H, cin, cout: 2 * H * H * cin * cout * 9
+    tconv = lambda H, c: 2 * H * H * c * c * 3
+    mfma = 0
+    for _ in range(2):                       # mid block
+        mfma += 2 * conv3(h, 512, 512) + 2 * tconv(h, 512)
+    H, prev = h, 512
+    for i, c in enumerate((512, 512, 256, 128)):
+        for r in range(3):
+            cin = prev if r == 0 else c
+            mfma += conv3(H, cin, c) + conv3(H, c, c) + 2 * tconv(H, c)
+        prev = c
+        if i < 3:
+            H *= 2
+            mfma += conv3(H, c, c)
+    total = vae_decoder_flops(h) - 2 * h * h * 4 * 4 + (mfma - vae_decoder_work(h)[0]) + 2 * H * H * 3 * 3 * 3
+    return total, mfma
+
+
 def vae_decoder_work(h):
     """Per frame of AutoencoderKL.decode at an h x h latent: (FLOPs of the 3x3 convolutions that run on the MFMA implicit-GEMM kernel,
     algorithmic bytes of the GroupNorm statistics passes = every GroupNorm input read once (fp32 stream), algorithmic bytes of the
@@ -548,8 +573,36 @@ def config4_rate(device, n_steps=4):
     vid = decode()
     torch.cuda.synchronize()
     dd = time.perf_counter() - t0
+    tot_fl, mfma_fl = (16 * v for v in vae_temporal_decoder_flops(64))
     res["temporal_decoder"] = {"ms_per_16_frame_video": round(dd * 1e3, 2), "frames_per_sec": round(16 / dd, 1),
-                               "finite": bool(all(torch.isfinite(v).all() for v in vid))}
+                               "finite": bool(all(torch.isfinite(v).all() for v in vid)),
+                               "algorithmic_tflop_per_video": round(tot_fl / 1e12, 2),
+                               "algorithmic_tflops_per_s": round(tot_fl / 1e12 / dd, 1),
+                               "model_mfma_frac": round(tot_fl / 1e12 / dd / MFMA_PEAK_TFLOPS, 4)}
+    # per kernel class (HIP events behind every launch, latte_vae_profile_decode) for the 14-frame chunk, scaled to what it is: the convolutions
+    # against the MFMA peak with the layer shapes' FLOPs counted ONCE (the engine's split-operand passes for parity are cost, not work)
+    z14 = z[:14].contiguous()
+    vae2 = latte_amd.AutoencoderKLTemporalDecoder(latent_size=64, max_frames=14)
+    vae2.load_state_dict(vae_temporal_decoder_state_dict(0))
+    vae2.to(device)
+    vae2.decode(z14, num_frames=14)
+    vae2.profile_decode(z14)
+    prof = vae2.profile_decode(z14)
+    tot_ms = sum(v[0] for v in prof.values())
+    table = []
+    for k, (ms, n) in prof.items():
+        row = {"class": k, "launches": n, "ms_per_14_frame_chunk": round(ms, 3), "share_of_decode": round(ms / max(tot_ms, 1e-9), 4)}
+        if k == "conv3x3" and ms > 0:
+            ach = 14 * vae_temporal_decoder_flops(64)[1] / (ms * 1e-3) / 1e12
+            row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                        "algorithmic_flops": 14 * vae_temporal_decoder_flops(64)[1],
+                        "kernel": "conv3x3_pp_kernel / conv3x3_kernel: implicit-GEMM 3x3 and (3,1,1) convolutions; spatial ones run twice (activation "
+                                  "remainder pass), temporal ones three times (hi.hi + lo.hi + hi.lo) for the 1e-3 parity of this decoder"})
+        table.append(row)
+    table.sort(key=lambda r: -r["share_of_decode"])
+    res["temporal_decoder"]["roofline_table"] = table
+    res["temporal_decoder"]["chunk14_ms_eager_events"] = round(tot_ms, 3)
+    del vae2
     res["seconds_per_video_50_steps_plus_decode"] = round(50 * dstep + dd, 2)
     del vae
     torch.cuda.empty_cache()

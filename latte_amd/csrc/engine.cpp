@@ -586,7 +586,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
   if (!e || !name) return fail(LATTE_ERR_INVALID, "set_option: null argument");
   const std::string k = name;
   if (k == "gemm_variant") {
-    if (value < 0 || value > 13) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..13");
+    if (value < 0 || (value > 13 && value != 18 && value != 19)) return fail(LATTE_ERR_INVALID, "gemm_variant must be 0..13, 18 or 19");
     const int bn = value >= 7 && value <= 9 ? gemm_tile_n((int)value) / 4 : gemm_tile_n((int)value);   // 7-9: whole wave widths
     if (value != 0 && ((3 * e->D) % bn || e->D % bn || e->Hm % bn))
       return fail(LATTE_ERR_INVALID, "gemm_variant: every N of the model must be a multiple of the tile width");
@@ -599,7 +599,7 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
 #ifdef LATTE_GEMM_ABLATE   // measurement build: 17 = the two-accumulator-set kernel of the gated GEMMs (gemm_pw.hip)
       if (value == 17 && (gi == 1 || gi == 3)) { e->gemm_variant_of[gi] = 17; return LATTE_OK; }
 #endif
-      if (value < 0 || value > 13) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..13");
+      if (value < 0 || (value > 13 && value != 18 && value != 19)) return fail(LATTE_ERR_INVALID, "gemm_variant_*: must be 0..13, 18 or 19");
       e->gemm_variant_of[gi] = (int)value;
       return LATTE_OK;
     }

@@ -188,12 +188,19 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_kernel(GemmArgs g) {
 // -- and the MFMA waves issue none.  A wave whose last piece index runs past 33 repeats its previous piece (same bytes to the
 // same place), so that every issuing wave has the same number of pieces per K tile in flight and one vmcnt constant serves all;
 // 12 and 4 are even, so the source-side swizzle of a wave's pieces is the same.  24 accumulators per lane.
-template <int EPI, int DT, int PRODUCER>
+// BM = 256 (variants 18 / 19, round 6): the same kernel on a 256 x 144 tile -- wave tile 64 x 48 (48 accumulators), THREE stages of
+// (256 + 144) x 128 B = 50 KB, two K tiles in flight.  For the shapes whose 256 x 192 tiling leaves the last round of the chip half
+// empty: fc1 at B = 1 (M = 4096, N = 4608: 384 tiles of 256 x 192 = 1.5 rounds -> 512 of 256 x 144 = 2 full rounds of 3/4 the work) and
+// the gated GEMMs at B = 2 (M = 8192, N = 1152: 192 tiles on 256 CUs -> 256).  With the four producer waves the register budget is 128:
+// no room for the residual prefetch, so the gated epilogue of variant 19 is a plain load / add / store behind the K loop; variant 18
+// (768 threads, 170 registers) keeps the prefetch.
+template <int EPI, int DT, int PRODUCER, int BM = 128>
 __global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmArgs g) {
-  constexpr int BM = 128, BN = 144, NS = 4;
-  constexpr int FM = 2, FN = 3;
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, NPIECE = (BM + BN) / 8;
+  constexpr int BN = 144, NS = BM == 128 ? 4 : 3, LOOK = NS - 1;
+  constexpr int FM = BM / 64, FN = 3, WTM = BM / 4;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, NPIECE = (BM + BN) / 8, APIECE = BM / 8;
   constexpr int NISSUE = PRODUCER ? 4 : 12, PER_WAVE = (NPIECE + NISSUE - 1) / NISSUE;   // issuing waves, pieces per wave
+  constexpr bool PREFETCH = EPI == EPI_GATE_RES_F32 && (BM == 128 || !PRODUCER);          // residual / gate / bias ahead of the K loop
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -203,7 +210,7 @@ __global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmAr
   const int m0 = tm * BM, n0 = tn * BN;
   const int K = g.K, nk = K / 64;
 
-  // ---- DMA: piece p < 16 = A rows 8 p .. 8 p + 7, else W rows 8 (p - 16) ..; lane -> (row lane >> 3, chunk swizzled)
+  // ---- DMA: piece p < APIECE = A rows 8 p .. 8 p + 7, else W rows 8 (p - APIECE) ..; lane -> (row lane >> 3, chunk swizzled)
   const bool issuer = PRODUCER ? wave >= 12 : true;
   const half_t* src[PER_WAVE];
   int dst_off[PER_WAVE];
@@ -214,36 +221,38 @@ __global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmAr
     for (int j = 0; j < PER_WAVE; ++j) {
       int p = iw + NISSUE * j;
       if (p >= NPIECE) p -= NISSUE;
-      const int grp8 = p < 16 ? p : p - 16;
+      const int grp8 = p < APIECE ? p : p - APIECE;
       const int row = grp8 * 8 + lrow;
       const int schunk = cpos ^ ((row >> 1) & 7);
       // A rows beyond M exist (row-padded operand); W rows are all inside N (N % 144 == 0)
-      src[j] = (p < 16 ? g.A + (size_t)(m0 + row) * K : g.W + (size_t)(n0 + row) * K) + schunk * 8;
+      src[j] = (p < APIECE ? g.A + (size_t)(m0 + row) * K : g.W + (size_t)(n0 + row) * K) + schunk * 8;
       dst_off[j] = p * 1024;
     }
   }
-  auto stage = [&](int kt) __attribute__((always_inline)) {
-    char* s = smem + (kt & (NS - 1)) * STAGE;
+  auto stage = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* s = smem + slot * STAGE;
     const int koff = kt * 64;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + koff, s + dst_off[j]);
   };
-  // own pieces of K tile kt landed (those of kt + 1, kt + 2 may stay in flight)
+  // own pieces of K tile kt landed (those of the LOOK - 1 newer K tiles may stay in flight)
   auto wait_tile = [&](int kt) __attribute__((always_inline)) {
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+    if (kt + 2 < nk && LOOK >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
     else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
+  auto next_slot = [](int s_) { return s_ == NS - 1 ? 0 : s_ + 1; };
 
   if constexpr (PRODUCER) {
     if (wave >= 12) {
-      stage(0);
-      if (nk > 1) stage(1);
-      if (nk > 2) stage(2);
+      int islot = 0;
+#pragma unroll
+      for (int t = 0; t < LOOK; ++t)
+        if (nk > t) { stage(t, islot); islot = next_slot(islot); }
       for (int kt = 0; kt < nk; ++kt) {
         wait_tile(kt);
         __builtin_amdgcn_s_barrier();   // K tile kt is complete for the MFMA waves; every read of K tile kt - 1 has retired
-        if (kt + 3 < nk) stage(kt + 3);
+        if (kt + LOOK < nk) { stage(kt + LOOK, islot); islot = next_slot(islot); }
       }
       return;
     }
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmAr
   const int frow = lane & 15;
   const int sw = (lane >> 1) & 7;
   const int chunk0 = ((lane >> 4) ^ sw) * 16;
-  const int a_off = (wm * 32 + frow) * 128 + chunk0;
+  const int a_off = (wm * WTM + frow) * 128 + chunk0;
   const int b_off = A_BYTES + (wn * 48 + frow) * 128 + chunk0;
 
   f32x4 acc[FM][FN];
@@ -267,81 +276,102 @@ __global__ void __launch_bounds__(PRODUCER ? 1024 : 768) gemm_n144_kernel(GemmAr
   // loop also covers them and their latency disappears under the main loop (a load / wait / store chain per fragment after it
   // cost six dependent round trips).  Rows >= M read row M - 1 and are not stored.
   const int ncol = n0 + wn * 48 + (lane >> 4) * 4;
-  float4 rres[FM][FN], g4[FM][FN], b4[FN];
-  if constexpr (EPI == EPI_GATE_RES_F32) {
+  constexpr int PF = PREFETCH ? FM : 1, PG = PREFETCH && BM == 128 ? FM : 1;   // BM = 256: rows_per_sample % 256 == 0 (launcher), one gate row per tile
+  float4 rres[PF][FN], g4[PG][FN], b4[FN];
+  if constexpr (PREFETCH) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) b4[j] = *(const float4*)(g.bias + ncol + j * 16);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int mc = min(m0 + wm * 32 + i * 16 + frow, g.M - 1);
+      const int mc = min(m0 + wm * WTM + i * 16 + frow, g.M - 1);
       const float* gate_row = g.gate + (size_t)(mc / g.rows_per_sample) * g.gate_stride;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         rres[i][j] = *(const float4*)((const float*)g.out + (size_t)mc * g.N + ncol + j * 16);
-        g4[i][j] = *(const float4*)(gate_row + ncol + j * 16);
+        if (PG == FM || i == 0) g4[PG == FM ? i : 0][j] = *(const float4*)(gate_row + ncol + j * 16);
       }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 
+  int islot = 0, cslot = 0;
   if constexpr (!PRODUCER) {
-    stage(0);
-    if (nk > 1) stage(1);
-    if (nk > 2) stage(2);
+#pragma unroll
+    for (int t = 0; t < LOOK; ++t)
+      if (nk > t) { stage(t, islot); islot = next_slot(islot); }
   }
   for (int kt = 0; kt < nk; ++kt) {
-    // K tile kt has landed for everybody; the barrier also retires every read of K tile kt - 1, whose stage takes K tile kt + 3
+    // K tile kt has landed for everybody; the barrier also retires every read of K tile kt - 1, whose stage takes K tile kt + LOOK
     if constexpr (!PRODUCER) wait_tile(kt);
     __builtin_amdgcn_s_barrier();
     if constexpr (!PRODUCER) {
-      if (kt + 3 < nk) stage(kt + 3);
+      if (kt + LOOK < nk) { stage(kt + LOOK, islot); islot = next_slot(islot); }
     }
-    const char* sbuf = smem + (kt & (NS - 1)) * STAGE;
-    u32x4 af[2][FM], bf[2][FN];
+    const char* sbuf = smem + cslot * STAGE;
+    cslot = next_slot(cslot);
+    if constexpr (BM == 128) {
+      u32x4 af[2][FM], bf[2][FN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+        for (int i = 0; i < FM; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+    } else {   // 256-row tile: one k-half of fragments at a time (28 instead of 56 fragment registers)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[j], af[i], acc[i][j]);
+      }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
   }
 
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * 32 + i * 16 + frow;
+    const int m = m0 + wm * WTM + i * 16 + frow;
     if (m >= g.M) continue;
+    const float* gate_row = nullptr;
+    if constexpr (EPI == EPI_GATE_RES_F32 && !PREFETCH) gate_row = g.gate + (size_t)(m / g.rows_per_sample) * g.gate_stride;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      if constexpr (EPI == EPI_GATE_RES_F32) {
+      if constexpr (PREFETCH) {
         float4 r = rres[i][j];
-        r.x += g4[i][j].x * (acc[i][j][0] + b4[j].x);
-        r.y += g4[i][j].y * (acc[i][j][1] + b4[j].y);
-        r.z += g4[i][j].z * (acc[i][j][2] + b4[j].z);
-        r.w += g4[i][j].w * (acc[i][j][3] + b4[j].w);
+        const float4 gg = g4[PG == FM ? i : 0][j];
+        r.x += gg.x * (acc[i][j][0] + b4[j].x);
+        r.y += gg.y * (acc[i][j][1] + b4[j].y);
+        r.z += gg.z * (acc[i][j][2] + b4[j].z);
+        r.w += gg.w * (acc[i][j][3] + b4[j].w);
         *(float4*)((float*)g.out + (size_t)m * g.N + ncol + j * 16) = r;
       } else {
-        epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, nullptr);
+        epilogue_store<EPI, DT>(g, acc[i][j], m, ncol + j * 16, gate_row);
       }
     }
   }
 }
 
-template <int DT, int PRODUCER>
+template <int DT, int PRODUCER, int BM = 128>
 int launch_n144(const GemmArgs& a, int epi, hipStream_t st) {
-  constexpr int LDS = 4 * (128 + 144) * 128;
+  constexpr int LDS = (BM == 128 ? 4 : 3) * (BM + 144) * 128;
   if (a.N % 144 != 0 || a.K % 64 != 0 || a.k_chunk != 0)
-    return fail(LATTE_ERR_INVALID, "gemm (128 x 144 tile): need N % 144 == 0, K % 64 == 0, no K split");
-  dim3 grid(((a.M + 127) / 128) * (a.N / 144)), block(PRODUCER ? 1024 : 768);
+    return fail(LATTE_ERR_INVALID, "gemm (144-wide tile): need N % 144 == 0, K % 64 == 0, no K split");
+  dim3 grid(((a.M + BM - 1) / BM) * (a.N / 144)), block(PRODUCER ? 1024 : 768);
 #define LATTE_GEMM_CASE(E)                                                                           \
   case E: {                                                                                          \
-    auto kern = gemm_n144_kernel<E, DT, PRODUCER>;                                                   \
+    auto kern = gemm_n144_kernel<E, DT, PRODUCER, BM>;                                               \
     static std::atomic<uint64_t> attr_done{0};                                                       \
     if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;                 \
     hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                               \
@@ -353,7 +383,7 @@ int launch_n144(const GemmArgs& a, int epi, hipStream_t st) {
     LATTE_GEMM_CASE(EPI_GATE_RES_F32)
     LATTE_GEMM_CASE(EPI_BIAS_F32)
     default:
-      return fail(LATTE_ERR_INVALID, "gemm (128 x 144 tile): unknown epilogue");
+      return fail(LATTE_ERR_INVALID, "gemm (144-wide tile): unknown epilogue");
   }
 #undef LATTE_GEMM_CASE
   LATTE_HIP(hipGetLastError());
@@ -1289,6 +1319,10 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
     case 9: return launch_pps<256, DT>(a, epi, st);
     case 12: return launch_n144<DT, 0>(a, epi, st);
     case 13: return launch_n144<DT, 1>(a, epi, st);
+    case 18:   // the prefetching form keeps ONE gate row per 256-row tile: samples must be whole tiles, else the producer-wave form
+      if (epi == EPI_GATE_RES_F32 && a.rows_per_sample % 256 != 0) return launch_n144<DT, 1, 256>(a, epi, st);
+      return launch_n144<DT, 0, 256>(a, epi, st);
+    case 19: return launch_n144<DT, 1, 256>(a, epi, st);
 #ifdef LATTE_GEMM_ABLATE   // measurement build: one consumer wave per SIMD (4 waves x 512 registers, wave tile 128 x 128) on the plain template
     case 14: return launch_w4<DT>(a, epi, st);
     case 15: return launch_cfg<256, 256, 2, 2, DT>(a, epi, st);   // the same wave layout on the plain two-stage template
@@ -1299,13 +1333,13 @@ int launch_dt(const GemmArgs& a, int epi, int variant, hipStream_t st) {
 
 }  // namespace
 
-int gemm_tile_m(int variant) { return variant == 1 || variant == 12 || variant == 13 ? 128 : 256; }
+int gemm_tile_m(int variant) { return variant == 1 || variant == 12 || variant == 13 ? 128 : 256; }   // (18 / 19: 256 x 144)
 
 int gemm_tile_n(int variant) {
   switch (variant) {
     case 3: case 6: case 9: case 14: case 15: return 256;
     case 5: case 8: case 10: case 11: case 17: return 192;
-    case 12: case 13: return 144;
+    case 12: case 13: case 18: case 19: return 144;
     default: return 128;
   }
 }
@@ -1346,6 +1380,12 @@ bool gemm_small_tile_ok(int M, int N, int K) {
   return N % 144 == 0 && K % 64 == 0 && (long)((M + 127) / 128) * (N / 144) <= 256;
 }
 
+// (Round 6: the 256 x 144 tile -- variants 18 / 19, gemm_n144_kernel<..., 256> -- was built for the shapes whose 192-wide tiling wastes
+//  the last round of the chip (fc1 at B = 1: 384 tiles = 1.5 rounds; the gated GEMMs at B = 2: 192 tiles on 256 CUs) and measured inside the
+//  XL/2 forward, profiles/r6_gemm_tile_256x144_inmodel_B1_B2.log: fc1 at B = 1 54.7 - 55.6 us against 52.7 for the 12-wave 256 x 192 kernel,
+//  proj / fc2 at B = 2 35.8 / 85.5 against 36.9 / 86.5 -- ties.  The small-batch GEMMs are bound by the bytes a CU can pull through its
+//  L2 -> LDS path (~ 50 GB/s per CU): one tile per CU of M N / 256 outputs needs (BM + BN) K 2 bytes whatever its shape, fc2 at B = 1
+//  2.5 MB per CU = 50 us.  The variants stay selectable ("gemm_variant_*" = 18 | 19) and tested; no shape rule picks them.)
 // What launch_gemm runs when no variant is forced (pure host logic; latte_debug_gemm_choice exposes it to the CPU tests).
 int gemm_resolve_variant(int M, int N, int K, int epi) {
   if (epi == EPI_GATE_RES_F32 && gemm_small_tile_ok(M, N, K)) return 13;
@@ -1368,6 +1408,7 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
   if (a.group_m == 0 && epi == EPI_GATE_RES_F32) a.group_m = 4;
 #ifdef LATTE_GEMM_ABLATE
   if (const char* m = getenv("LATTE_RMW_MODE")) a.rmw_mode = atoi(m);
+  if (const char* m = getenv("LATTE_PWR_ABL")) { if (epi == EPI_GATE_RES_F32) a.rmw_mode = atoi(m); }   // ladder rungs of the rolling kernel (gemm_pw.hip)
   if (const char* m = getenv("LATTE_RMW_VARIANT")) { if (epi == EPI_GATE_RES_F32 && variant == 0) variant = atoi(m); }
   if (const char* m = getenv("LATTE_GROUP_M")) {   // "epi:value[,epi:value]" e.g. "2:5" = gated-residual GEMMs walk 5 tile rows together
     for (const char* q = m; q && *q;) {

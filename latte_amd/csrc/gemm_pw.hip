@@ -382,9 +382,15 @@ __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
 // fp8 correction operands A8 / W8 (GemmArgs) -- a 128-byte row piece of an fp8 operand is K = 128, so a correction K tile has the
 // byte geometry, the LDS image, the swizzle and the DMA pieces of a half-precision one; the producers only switch descriptor and row
 // pitch, the consumers run lo_tile() (24 MFMAs of 16 passes on the same fragment reads) instead of ktile() (48 of 8 passes).
-template <int EPI, int DT, int TAG, bool LO = false>
+// ABL (measurement build only, round 6 -- the probe-to-kernel LADDER of tools/ladder_probe.py, results are garbage): bits taken away from
+// the production kernel one at a time, top down:  1 = no epilogue (accumulators dropped at a tile boundary), 2 = no tile boundaries (the
+// K walk never drains / refills), 4 = operands from an L2-resident pool (tile 0, K tiles 0-3) instead of their real addresses, 8 = no
+// vmcnt / lgkmcnt waits and no barrier inside the K walk, 16 = fragments read from the LDS once and reused, 32 = no operand DMA.
+template <int EPI, int DT, int TAG, bool LO = false, int ABL = 0>
 __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
+  constexpr bool A_NOEPI = (ABL & 1) != 0, A_ONE = (ABL & 2) != 0, A_HOT = (ABL & 4) != 0, A_NOWAIT = (ABL & 8) != 0,
+                 A_NOLDS = (ABL & 16) != 0, A_NODMA = (ABL & 32) != 0;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int NA = 3;
   constexpr int B_BASE = NA * A_BYTES;
@@ -460,6 +466,8 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     asm volatile("" : "+s"(step32_8));
     auto dma_a = [&](int tm_, int kt, int stg) {   // all 256 rows: row-groups pw + 4 j, j = 0..7
       char* sA = smem + stg * A_BYTES + pw * 1024;
+      if constexpr (A_NODMA) return;
+      if constexpr (A_HOT) { tm_ = 0; kt &= 3; }
       if (LO && kt >= nk) {
         const unsigned so = (unsigned)(tm_ * BM + pw * 8) * row_bytes8 + (unsigned)(kt - nk) * 128u;
 #pragma unroll
@@ -472,6 +480,8 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     };
     auto dma_b = [&](int tn_, int kt, int stg) {
       char* sB = smem + B_BASE + stg * B_BYTES + pw * 1024;
+      if constexpr (A_NODMA) return;
+      if constexpr (A_HOT) { tn_ = 0; kt &= 3; }
       if (LO && kt >= nk) {
         const unsigned so = (unsigned)(tn_ * BN + pw * 8) * row_bytes8 + (unsigned)(kt - nk) * 128u;
 #pragma unroll
@@ -506,9 +516,9 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     for (int u = 0; u < U; ++u) {
       LATTE_TS(5)
       // stage u + 1 must have landed; the only younger DMA is A(u+2)
-      if (u + 2 < U) wait_vm<2 * AH_INSTR>(); else wait_vm<0>();
+      if constexpr (!A_NOWAIT) { if (u + 2 < U) wait_vm<2 * AH_INSTR>(); else wait_vm<0>(); }
       LATTE_TS(1)
-      __builtin_amdgcn_s_barrier();   // B_u: stage u is free
+      if constexpr (!A_NOWAIT) __builtin_amdgcn_s_barrier();   // B_u: stage u is free
       LATTE_TS(2)
       if (u + 2 < U) dma_b(wb.tn, wb.kt, sb);
       if (u + 3 < U) dma_a(wa.tm, wa.kt, sa);
@@ -541,7 +551,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     const int fr = le & 15;
     const int ncol = tn_ * BN + wn * WTN + (le >> 4) * 4;
     const int mbase = tm_ * BM + grp * 128 + fr;
-    if constexpr (TRACE) {
+    if constexpr (TRACE || A_NOEPI) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -599,7 +609,28 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
           b4[j] = *(const float4*)(g.bias + ncol + j * 16);
           g1[j] = *(const float4*)(gr + j * 16);
         }
-        constexpr int NF = 8 * FN, AHEAD = 2;
+        if constexpr ((ABL & 64) != 0) {   // ladder experiment: the read-modify-write as fire-and-forget fp32 atomic adds (L2-side add)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool ok = mbase + i * 16 < g.M;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              float* dst = outp + (size_t)min(mbase + i * 16, g.M - 1) * g.N + ncol + j * 16;
+              const float v0 = g1[j].x * (acc[i][j][0] + b4[j].x), v1 = g1[j].y * (acc[i][j][1] + b4[j].y);
+              const float v2 = g1[j].z * (acc[i][j][2] + b4[j].z), v3 = g1[j].w * (acc[i][j][3] + b4[j].w);
+              if (ok) {
+                typedef __attribute__((address_space(1))) float gfloat;
+                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)dst, v0);
+                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(dst + 1), v1);
+                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(dst + 2), v2);
+                __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(dst + 3), v3);
+              }
+              acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          return;
+        }
+        constexpr int NF = 8 * FN, AHEAD = (ABL & 128) ? 6 : (ABL & 256) ? 12 : 2;   // (ladder experiment: deeper residual look-ahead)
         auto frag_ptr = [&](int f) -> float* {
           const int mc = min(mbase + (f / FN) * 16, g.M - 1);
           return outp + (size_t)mc * g.N + ncol + (f % FN) * 16;
@@ -682,7 +713,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[0][j], af[i]);
-      af[i] = *(const u32x4*)(sA + ((a_off + i * 2048) ^ 64));
+      if constexpr (!A_NOLDS) af[i] = *(const u32x4*)(sA + ((a_off + i * 2048) ^ 64));
       __builtin_amdgcn_sched_barrier(0);
     }
     LATTE_TS(0)
@@ -692,11 +723,11 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!A_NOWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     LATTE_TS(1)
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!A_NOWAIT) __builtin_amdgcn_s_barrier();
     LATTE_TS(2)
-    if constexpr (LOOK) {
+    if constexpr (LOOK && !A_NOLDS) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) bf[0][j] = *(const u32x4*)(sBn + (b_off + j * 2048));
     }
@@ -705,10 +736,10 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     for (int i = 2; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) mfma16_ip<DT>(acc[i][j], bf[1][j], af[i]);
-      if constexpr (LOOK) af[i - 2] = *(const u32x4*)(sAn + (a_off + (i - 2) * 2048));
+      if constexpr (LOOK && !A_NOLDS) af[i - 2] = *(const u32x4*)(sAn + (a_off + (i - 2) * 2048));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (LOOK) {
+    if constexpr (LOOK && !A_NOLDS) {
       af[6] = *(const u32x4*)(sAn + (a_off + 6 * 2048));
       af[7] = *(const u32x4*)(sAn + (a_off + 7 * 2048));
 #pragma unroll
@@ -775,6 +806,18 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   };
 
   int it = 0, ia = 0;
+  if constexpr (A_ONE) {   // ladder rung: the whole walk as ONE K loop (no drain / epilogue / refill between output tiles)
+    const int total = ntile * nk;
+    for (; it + 1 < total; ++it) {
+      const char* sA = smem + ia * A_BYTES;
+      ia = ia == NA - 1 ? 0 : ia + 1;
+      ktile(sA, smem + ia * A_BYTES, smem + ((it + 1) & 1) * B_BYTES, std::true_type{});
+    }
+    ktile(smem + ia * A_BYTES, nullptr, nullptr, std::false_type{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    epilogue(tm, tn);
+    return;
+  }
   for (;;) {
     for (int kt = 0; kt + 1 < nk; ++kt, ++it) {
       const char* sA = smem + ia * A_BYTES;
@@ -1135,6 +1178,24 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     }                                                                                                \
   }
 #ifdef LATTE_GEMM_ABLATE
+  if (roll == 1 && a.rmw_mode > 0 && epi == EPI_GATE_RES_F32 && !a.A8) {   // the ladder rungs (GemmArgs::rmw_mode = ABL bits; LATTE_PWR_ABL)
+#define LATTE_ABL_CASE(MASK)                                                                        \
+    case MASK: {                                                                                    \
+      auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 1, false, MASK>;                            \
+      static std::atomic<uint64_t> attr_done{0};                                                    \
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;              \
+      hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                            \
+      break;                                                                                        \
+    }
+    switch (a.rmw_mode) {
+      LATTE_ABL_CASE(1) LATTE_ABL_CASE(3) LATTE_ABL_CASE(7) LATTE_ABL_CASE(15) LATTE_ABL_CASE(31) LATTE_ABL_CASE(63)
+      LATTE_ABL_CASE(4) LATTE_ABL_CASE(16) LATTE_ABL_CASE(32) LATTE_ABL_CASE(5) LATTE_ABL_CASE(35) LATTE_ABL_CASE(64) LATTE_ABL_CASE(128) LATTE_ABL_CASE(256)
+      default: return fail(LATTE_ERR_INVALID, "gemm (ladder): ablation mask not instantiated");
+    }
+#undef LATTE_ABL_CASE
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   if (roll == 3) {
     constexpr int LDS_DACC = 5 * 128 * 128 + 3 * 192 * 128 + 2 * 4 * 512;   // 5 A stages of 128 rows, 3 B stages, bias / gate slices
     if (a.K < 1152 || a.rows_per_sample % 128 != 0 || (uint64_t)a.M * a.N * 4 >= (1ull << 32))

@@ -30,13 +30,13 @@ def kernel_choice(lib):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1152), (300, 512, 256), (1024, 1152, 4608), (700, 384, 64),
                                    (8292, 2304, 192), (8292, 2432, 192),  # > 256 tiles, odd K-tile count (persistent kernel)
                                    (300, 288, 64), (130, 144, 128), (4096, 1152, 1152)])  # 144-wide tiles: 1 / 2 K tiles, B = 1 shape
 def test_gemm_epilogues(lib, dev, dt, variant, shape):
     M, N, K = shape
-    tile_n = {0: 64, 1: 128, 2: 128, 3: 256, 4: 128, 5: 192, 6: 256, 7: 32, 8: 48, 9: 64, 10: 192, 11: 192, 12: 144, 13: 144}[variant]   # 7-9: wave width
+    tile_n = {0: 64, 1: 128, 2: 128, 3: 256, 4: 128, 5: 192, 6: 256, 7: 32, 8: 48, 9: 64, 10: 192, 11: 192, 12: 144, 13: 144, 18: 144, 19: 144}[variant]   # 7-9: wave width
     if N % tile_n:
         pytest.skip(f"tile width {tile_n} does not divide N")
     if 7 <= variant <= 11 and K < 128 and (variant >= 10 or N % (4 * tile_n)):
