@@ -82,6 +82,21 @@ constexpr int K_OFF = 256 * RPQ, V_OFF = 2 * 256 * RPQ, IMG_END = V_OFF + 256 * 
 constexpr int A0_OFF = 0, A1_OFF = 61440, B1_OFF = 94208, B0_OFF = 122880, BIAS_OFF = B0_OFF + 224 * 128;
 constexpr int FUSED_LDS = BIAS_OFF + 288 * 4;
 
+// 4 x 4 transpose of one word per lane across the four 16-lane rows of a wave (gfx950: v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second, v_permlane16_swap the odd rows of the first with the even rows of the second): on
+// entry register d of lane row g holds word (d, g); on exit register k of lane row g holds word (g, k) -- the four words of ONE d-group
+// side by side in one lane.  The fp8 remainder of the attention output (SPLIT == 2) uses it: a lane's four bytes per d-group become
+// sixteen contiguous bytes per lane, one 16-byte store instead of four 4-byte ones on 16-byte row pieces (config 3: the attention
+// kernels' out8 stores cost 60 - 80 us per launch as dword stores, profiles/r6_bench_steps20_after_fp8_remainder.json).
+__device__ __forceinline__ void rows_transpose4(unsigned int& x0, unsigned int& x1, unsigned int& x2, unsigned int& x3) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  const u2 a = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);
+  const u2 b = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+  const u2 c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const u2 d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  x0 = c[0]; x1 = c[1]; x2 = d[0]; x3 = d[1];
+}
+
 // FLAGS bit 0 (EARLY): the next unit's K tile 0 is DMA'd into stage 0 right after the attention phase has fetched its Q
 //   fragments (one barrier, taken while the waves are still aligned), so the fill latency of the next unit's operand pipeline
 //   hides under the attention phase.
@@ -436,9 +451,11 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
           half_t* orow = a.out + (size_t)(row_base + q0 + gq * 16 + fr) * out_ld + head * HD;
+          unsigned int l8w[DF];   // SPLIT == 2: the fp8 remainder words of this row, one per d-group
 #pragma unroll
           for (int d = 0; d < DF; ++d) {
             const int dd = 16 * d + 4 * g;
+            l8w[d] = 0u;
             if (dd < HD) {
               if constexpr (SPLIT == 1) {   // [hi | lo]: the out-projection's K-concatenated operand
                 unsigned int h0_, l0_, h1_, l1_;
@@ -449,15 +466,20 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
                 *(u32x2*)(orow + D + dd) = lo;
               } else if constexpr (SPLIT == 2) {   // f16 + fp8 remainder: the out-projection's correction operand (GemmArgs::A8)
                 unsigned int h0_, h1_;
-                const unsigned int l8 = split8_f16(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq], h0_, h1_);
+                l8w[d] = split8_f16(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq], h0_, h1_);
                 *(u32x2*)(orow + dd) = (u32x2){h0_, h1_};
-                *(unsigned int*)(a.out8 + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD + dd) = l8;
               } else {
                 const u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
                                   pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
                 *(u32x2*)(orow + dd) = pk;
               }
             }
+          }
+          if constexpr (SPLIT == 2) {   // d-groups 0-3: sixteen contiguous bytes per lane (lane row g stores d-group g); d-group 4 (hd = 72) as words
+            unsigned char* o8 = a.out8 + (size_t)(row_base + q0 + gq * 16 + fr) * D + head * HD;
+            rows_transpose4(l8w[0], l8w[1], l8w[2], l8w[3]);
+            *(u32x4*)(o8 + 16 * g) = (u32x4){l8w[0], l8w[1], l8w[2], l8w[3]};
+            if constexpr (DF > 4) { if (64 + 4 * g < HD) *(unsigned int*)(o8 + 64 + 4 * g) = l8w[4]; }
           }
         }
       }
@@ -511,11 +533,13 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
+        unsigned int l8w[DF];   // SPLIT == 2: the fp8 remainder words of this token, one per d-group
 #pragma unroll
         for (int d = 0; d < DF; ++d) {
           f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
           oacc = mfma_k16h<DT>(vf[d], pb, oacc);                               // O^T[d = 16 d + 4g + r][q = fr]
           const int dd = 16 * d + 4 * g;
+          l8w[d] = 0u;
           if (dd < HD) {
             if constexpr (SPLIT == 1) {
               unsigned int h0_, l0_, h1_, l1_;
@@ -526,14 +550,19 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
               *(u32x2*)(orow + D + dd) = lo;
             } else if constexpr (SPLIT == 2) {
               unsigned int h0_, h1_;
-              const unsigned int l8 = split8_f16(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv, h0_, h1_);
+              l8w[d] = split8_f16(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv, h0_, h1_);
               *(u32x2*)(orow + dd) = (u32x2){h0_, h1_};
-              *(unsigned int*)(a.out8 + (size_t)(row_base + fr * T + p) * D + head * HD + dd) = l8;
             } else {
               const u32x2 pk = {pack2<DT>(oacc[0] * inv, oacc[1] * inv), pack2<DT>(oacc[2] * inv, oacc[3] * inv)};
               *(u32x2*)(orow + dd) = pk;
             }
           }
+        }
+        if constexpr (SPLIT == 2) {
+          unsigned char* o8 = a.out8 + (size_t)(row_base + fr * T + p) * D + head * HD;
+          rows_transpose4(l8w[0], l8w[1], l8w[2], l8w[3]);
+          *(u32x4*)(o8 + 16 * g) = (u32x4){l8w[0], l8w[1], l8w[2], l8w[3]};
+          if constexpr (DF > 4) { if (64 + 4 * g < HD) *(unsigned int*)(o8 + 64 + 4 * g) = l8w[4]; }
         }
       }
     }
