@@ -123,7 +123,8 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
  *   "xattn_flash"     1 = the generic flash kernel for text cross-attention instead of the whole-panel kernel
  *   "tn_kernel"       4 = the 4-wave weight-gradient GEMM;   "tn_wn" 4 = its 256 x 128 tile
  *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too
- *   "conv_kernel"     1 = the plain 128 x 128 implicit-GEMM convolution everywhere, 2 = the ping-pong 256-pixel kernel everywhere
+ *   "conv_kernel"     1 = the plain 128 x 128 implicit-GEMM convolution everywhere, 2 | 3 = the ping-pong 256-pixel kernel everywhere,
+ *                     4 = its persistent form (round 6: bit-identical, measured 6 - 13 % slower, not a default anywhere)
  * Anything else is refused (LATTE_ERR_INVALID).  Replaces the LATTE_* environment variables round 3 read at every launch; the
  * measurement ablations whose results are garbage (attention variants 7-9) exist only in a LATTE_DEBUG_BUILD=1 library. */
 int latte_debug_set_choice(const char* name, int value);

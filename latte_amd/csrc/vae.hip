@@ -359,6 +359,230 @@ __global__ void __launch_bounds__(512) conv3x3_pp_kernel(ConvArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: the ping-pong kernel above as a PERSISTENT kernel -- one workgroup per CU walks a sequence of output tiles (XCD-chunked
+// grouped order, as gemm_pps_kernel), and the K-tile counter runs ACROSS tiles: the gather / W DMA stays two K tiles ahead of the
+// multiplies through a tile boundary, so the first two K tiles of the next output tile are in flight under the epilogue of the current
+// one (the non-persistent kernel paid a serial two-K-tile fill, the epilogue and the workgroup launch per 18 ... 72 K tiles; DESIGN.md
+// section 4.3 named this as what separates the convolutions' 0.36 from the GEMMs' 0.45).  Two walkers: the DMA walker (tile + K tile of
+// the NEXT issue, with the per-lane gather state of ITS tile) and the compute walker (tile of the epilogue).  vmcnt retires in order
+// and counts stores: the wait behind C(kt) would also wait for the previous tile's epilogue stores, so the first K tile of a tile
+// that follows an epilogue skips it -- its DMA (K tile 1 of the tile) was issued BEFORE that epilogue, whose own bias load has been
+// consumed since, which proves it landed.  Same products, same K order, same epilogue arithmetic as conv3x3_pp_kernel: same bits.
+template <int BN, int DT>
+__global__ void __launch_bounds__(512) conv3x3_pps_kernel(ConvArgs g) {
+  constexpr int BM = 256;
+  constexpr int WTN = BN / 4, FN = WTN / 16;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int AH_INSTR = 4;
+  constexpr int BG_INSTR = BN / 8 / 4;
+  constexpr int GROUP_M = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int Hout = g.Hin << g.ups, Wout = g.Win << g.ups;
+  const int M = g.N * Hout * Wout;
+  const int K = (g.taps3 ? 3 : 9) * g.Cin;
+  const int nk = K / 64;
+
+  // ---- this workgroup's tile sequence
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = g.Cout / BN, nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  if (slot >= cnt) return;
+  auto decode = [&](int wg, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+  };
+  const int ntile = (cnt - slot + per - 1) / per;
+  const int U = ntile * nk;
+
+  const int lrow = lane >> 3, cpos = lane & 7;
+  const int srow = wn * 8 + lrow;
+  const int schunk = cpos ^ ((srow >> 1) & 7);
+  const bool fast = g.ups == 0;
+  const int ntap = g.taps3 ? 3 : 9;
+  int pyx[AH_INSTR], pbase[AH_INSTR];   // gather state of the DMA walker's tile (conv3x3_pp_kernel)
+  auto gather_state = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < AH_INSTR; ++j) {
+      const int m = m0 + grp * 128 + srow + 32 * j;
+      if (m < M) {
+        const int img = m / (Hout * Wout), rem = m - img * (Hout * Wout);
+        const int y = rem / Wout, x = rem - y * Wout;
+        if (fast) {
+          int mask = 0;
+          for (int tap = 0; tap < ntap; ++tap) {
+            const int yy = y + (g.taps3 ? tap - 1 : tap / 3 - 1), xx = x + (g.taps3 ? 0 : tap % 3 - 1);
+            if (yy >= 0 && yy < Hout && xx >= 0 && xx < Wout) mask |= 1 << tap;
+          }
+          pyx[j] = mask;
+          pbase[j] = (int)(((unsigned)(img * g.Hin * g.Win + y * g.Win + x) * (unsigned)g.Cin + (unsigned)(schunk * 8)) * 2u);
+        } else {
+          pyx[j] = (y << 16) | x;
+          pbase[j] = img * g.Hin * g.Win;
+        }
+      } else {
+        pyx[j] = fast ? 0 : (0x7ff0 << 16);
+        pbase[j] = 0;
+      }
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.in, 0, (unsigned)((size_t)g.N * g.Hin * g.Win * g.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (unsigned)((size_t)g.Cout * K * 2), 0x00020000);
+  const unsigned voff_b = ((unsigned)srow * (unsigned)K + (unsigned)(schunk * 8)) * 2u;
+  const unsigned b_step = 32u * (unsigned)K * 2u;
+  const int cpt = g.Cin >> 6;
+  typedef __attribute__((address_space(3))) void lds_void_c;
+
+  auto dma_a_half = [&](int kt, int stg) {
+    char* sA = smem + stg * STAGE + grp * 128 * 128 + wn * 1024;
+    const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+    const int dy = g.taps3 ? tap - 1 : tap / 3 - 1, dx = g.taps3 ? 0 : tap - (tap / 3) * 3 - 1;
+    if (fast) {
+      const int delta = ((dy * g.Win + dx) * g.Cin + c0) * 2;
+#pragma unroll
+      for (int j = 0; j < AH_INSTR; ++j) {
+        const unsigned voff = ((pyx[j] >> tap) & 1) ? (unsigned)(pbase[j] + delta) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_c*)(sA + j * 4 * 1024), 16, voff, 0u, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < AH_INSTR; ++j) {
+      const int yy = (pyx[j] >> 16) + dy, xx = (pyx[j] & 0xffff) + dx;
+      const bool ok = yy >= 0 && yy < Hout && xx >= 0 && xx < Wout;
+      const int sy = yy >> g.ups, sx = xx >> g.ups;
+      const unsigned voff = ok ? ((unsigned)(pbase[j] + sy * g.Win + sx) * (unsigned)g.Cin + (unsigned)(c0 + schunk * 8)) * 2u : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_c*)(sA + j * 4 * 1024), 16, voff, 0u, 0, 0);
+    }
+  };
+  auto dma_b_all = [&](int n0_, int kt, int stg) {
+    char* sB = smem + stg * STAGE + A_BYTES + wn * 1024;
+    const unsigned so = ((unsigned)n0_ * (unsigned)K + (unsigned)kt * 64u) * 2u;
+#pragma unroll
+    for (int j = 0; j < BG_INSTR; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_c*)(sB + j * 4 * 1024), 16, voff_b, so + (unsigned)j * b_step, 0, 0);
+  };
+
+  // ---- DMA walker: issues global K tile v (stage v & 1), then advances; entering a tile recomputes the gather state
+  int d_pos = slot, d_kt = 0, d_tm, d_tn, v = 0;
+  decode(chunk0 + d_pos, d_tm, d_tn);
+  gather_state(d_tm * BM);
+  auto issue_next = [&]() {
+    dma_a_half(d_kt, v & 1);
+    if (grp == 0) dma_b_all(d_tn * BN, d_kt, v & 1);
+    ++v;
+    if (++d_kt == nk) {
+      d_kt = 0;
+      d_pos += per;
+      if (d_pos < cnt) {
+        decode(chunk0 + d_pos, d_tm, d_tn);
+        gather_state(d_tm * BM);
+      }
+    }
+  };
+
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int chunk0b = ((lane >> 4) ^ sw) * 16;
+  const int a_off = (grp * 128 + frow) * 128 + chunk0b;
+  const int b_off = A_BYTES + (wn * WTN + frow) * 128 + chunk0b;
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue_next();                        // global K tile 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (U > 1) issue_next();             // global K tile 1 (stage 1 is untouched so far)
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
+
+  int pos = slot, tm, tn, u = 0;
+  decode(chunk0 + pos, tm, tn);
+  bool after_epilogue = false;
+  for (;;) {
+    for (int kt = 0; kt < nk; ++kt, ++u) {
+      const char* sbuf = smem + (u & 1) * STAGE;
+      u32x4 bf[2][FN], af[2][8];
+      // ---- L(u)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(sbuf + ((b_off + j * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[ks][i] = *(const u32x4*)(sbuf + ((a_off + i * 2048) ^ (ks << 6)));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- C(u)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      // own DMA of global K tile u + 1 landed.  Behind an epilogue the wait would include that epilogue's stores; the DMA in question
+      // was issued before the epilogue and the epilogue has consumed a load issued after it: it has landed (in-order retirement).
+      if (!(kt == 0 && after_epilogue)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (v < U) issue_next();         // global K tile u + 2 into the stage just consumed
+    }
+    // ---- epilogue of tile (tm, tn) (conv3x3_pp_kernel's), accumulators cleared
+    {
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + grp * 128 + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = ncol + j * 16;
+          const float4 b4 = *(const float4*)(g.bias + n);
+          float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m >= M) continue;
+          const size_t o = (size_t)m * g.Cout + n;
+          if (g.out32 != nullptr) {
+            if (g.res32 != nullptr) {
+              const float4 r4 = *(const float4*)(g.res32 + o);
+              v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
+            }
+            *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
+            continue;
+          }
+          if (g.res != nullptr) {
+            const u32x2 r2 = *(const u32x2*)(g.res + o);
+            float r0, r1, r2f, r3;
+            unpack2<DT>(r2[0], r0, r1);
+            unpack2<DT>(r2[1], r2f, r3);
+            v0 += r0; v1 += r1; v2 += r2f; v3 += r3;
+          }
+          const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+          *(u32x2*)(g.out + o) = p;
+        }
+      }
+    }
+    after_epilogue = true;
+    pos += per;
+    if (pos >= cnt) break;
+    decode(chunk0 + pos, tm, tn);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
+}
+
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // partial[n][slab][g] = (sum, sumsq) over the slab's pixels and the group's channels.  One thread owns 8 consecutive
 // channels of a pixel (16-byte loads); the per-thread sums are combined in a FIXED order (deterministic).
@@ -852,7 +1076,26 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
   // its gather addresses the input through 32-bit buffer offsets and, with the upsample, packs (y, x) into 16 bits each
   const bool pp_ok = (uint64_t)N * Hin * Win * Cin * 2 < (1ull << 32) && (uint64_t)Cout * 9 * Cin * 2 < (1ull << 32) &&
                      (!ups || ((Hin << ups) < 32768 && (Win << ups) < 65536));
-  if (pp_ok && debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) == 2)) {
+  // round 6: the persistent form of the ping-pong kernel (conv3x3_pps_kernel) is bit-identical and SLOWER (SD-VAE decode: convolutions
+  // 11.5 -> 12.2 ms; temporal decoder chunk 117 -> 137 ms, profiles/r6_vae_persistent_conv_ab.log): it runs only when conv_kernel 4 asks for it
+  if (pp_ok && debug_choice(DBG_CONV_KERNEL) == 4) {
+    const int nblk = pp_tiles >= 256 ? 256 : (pp_tiles + 7) / 8 * 8;
+    if (bn == 256) {
+      constexpr int LDS_PP = 2 * (256 + 256) * 128;
+      static std::atomic<uint64_t> attr_a{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_pps_kernel<256, LATTE_DTYPE_F16>, LDS_PP, attr_a)) return rc_;
+      hipLaunchKernelGGL((conv3x3_pps_kernel<256, LATTE_DTYPE_F16>), dim3(nblk), dim3(512), LDS_PP, st, a);
+    } else {
+      constexpr int LDS_PP = 2 * (256 + 128) * 128;
+      static std::atomic<uint64_t> attr_b{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_pps_kernel<128, LATTE_DTYPE_F16>, LDS_PP, attr_b)) return rc_;
+      hipLaunchKernelGGL((conv3x3_pps_kernel<128, LATTE_DTYPE_F16>), dim3(nblk), dim3(512), LDS_PP, st, a);
+    }
+    kprof_mark(VC_CONV3, st);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
+  if (pp_ok && debug_choice(DBG_CONV_KERNEL) != 1 && (pp_tiles >= 192 || debug_choice(DBG_CONV_KERNEL) >= 2)) {
     if (bn == 256) {
       constexpr int LDS_PP = 2 * (256 + 256) * 128;
       static std::atomic<uint64_t> attr_a{0};

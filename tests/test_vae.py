@@ -62,9 +62,10 @@ def test_engine_key_set_equals_oracle_key_set(lib):
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [1])
-@pytest.mark.parametrize("kernel", [1, 2], ids=["plain128", "pingpong256"])
+@pytest.mark.parametrize("kernel", [1, 3, 4], ids=["plain128", "pingpong256", "persistent256"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 0, False), (1, 16, 16, 128, 256, 1, False), (1, 8, 24, 256, 128, 0, True),
-                                  (3, 5, 7, 64, 128, 1, True), (2, 32, 32, 512, 512, 0, True), (1, 32, 32, 256, 256, 1, False)])
+                                  (3, 5, 7, 64, 128, 1, True), (2, 32, 32, 512, 512, 0, True), (1, 32, 32, 256, 256, 1, False),
+                                  (5, 128, 128, 128, 128, 0, True), (3, 64, 64, 256, 256, 1, False)])   # > 256 tiles: several per workgroup
 def test_conv3x3_kernel(lib, dt, case, kernel):
     """Both implicit-GEMM kernels (csrc/vae.hip: the plain 128 x 128 tile and the round-4 ping-pong 256-pixel tile; the launcher
     picks by tile count, latte_debug_set_choice("conv_kernel", ...) forces one) against torch's conv2d on the same half operands:
@@ -78,7 +79,7 @@ def test_conv3x3_kernel(lib, dt, case, kernel):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 2], ids=["plain128", "pingpong256"])
+@pytest.mark.parametrize("kernel", [1, 3, 4], ids=["plain128", "pingpong256", "persistent256"])
 @pytest.mark.parametrize("case", [(3, 70016, 64, 128), (14, 4096, 128, 256)])
 def test_conv3_rows_kernel_wide_images(lib, kernel, case):
     """The 3-tap form (AutoencoderKLTemporalDecoder's Conv3d (3,1,1): frames are the rows of an "image" whose width is the frame's
@@ -102,6 +103,32 @@ def test_conv3_rows_kernel_wide_images(lib, kernel, case):
         check(lib.latte_debug_set_choice(b"conv_kernel", 0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), want.cpu()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(5, 128, 128, 128, 128, 0), (2, 64, 64, 256, 256, 1), (6, 64, 64, 512, 256, 0)])
+def test_persistent_conv_is_the_pingpong_conv_bit_for_bit(lib, case):
+    """Round 6: conv3x3_pps_kernel walks several output tiles per workgroup with the gather two K tiles ahead across tile boundaries; same
+    products in the same order as conv3x3_pp_kernel -> identical fp32 outputs (320 / 512 / 192 tiles: more and fewer than one per CU)."""
+    from latte_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout, ups = case
+    dev = torch.device("cuda")
+    g = torch.Generator("cpu").manual_seed(N * H + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g).half().to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    r32 = torch.randn(N, H << ups, W << ups, Cout, generator=g).to(dev)
+    outs = {}
+    for kernel in (3, 4):
+        out = torch.zeros(N, H << ups, W << ups, Cout, device=dev)
+        check(lib.latte_debug_set_choice(b"conv_kernel", kernel))
+        try:
+            check(lib.latte_debug_conv3x3_f32(ptr(x), ptr(w), ptr(b), ptr(r32), ptr(out), N, H, W, Cin, Cout, ups, 1, stream_ptr()))
+        finally:
+            check(lib.latte_debug_set_choice(b"conv_kernel", 0))
+        torch.cuda.synchronize()
+        outs[kernel] = out
+    assert torch.equal(outs[3], outs[4])
 
 
 def _conv3x3_case(lib, dt, case):
