@@ -46,6 +46,11 @@ int latte_debug_qkv_attention_fusable(int D, int heads, int F, int T, int mode, 
 int latte_debug_gemm_tn_plan(int M, int N, int K, int* rows_per_split);
 int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int heads, int hd, int U,
                           int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, void* stream);
+/* latte_debug_attention with the f16 + fp8-remainder output of guided calls: out [rows, D] (bit for bit the plain call's output) and
+ * out8 [rows, D] bytes = e4m3(clamp((value - out) * 2^12, +-448)); f16 only, every kernel of the un-fused path (L <= 16, generic flash,
+ * 128 < L <= 256, L > 256). */
+int latte_debug_attention_split8(const void* qkv, void* out, void* out8, int num_seq, int L, int heads, int hd, int U, int64_t sample_stride,
+                                 int64_t seq_stride, int64_t row_stride, int dtype, void* stream);
 /* Fused QKV projection + attention core (csrc/qkv_attn.hip; latte.py:48-70 up to, not including, the output projection):
  * out[B F T, D] = attention(xn[B F T, D] W[3D, D]^T + bias[3D]) per (sequence, head), rows in the canonical [B, F, T] order.
  * mode 0: spatial sequences (needs T == 256), mode 1: temporal sequences (needs F == 16, T % 16 == 0); head_dim D / heads

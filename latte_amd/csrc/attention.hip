@@ -79,7 +79,36 @@ __device__ __forceinline__ u32x2 lds_tr16(const char* p) {   // 16-bit elements:
 
 // CROSS = true (LatteT2V attn2): queries from a [rows, q_ld] buffer, Lk keys / values per SAMPLE from a.kv ([K | V], 2D
 // columns), an optional additive score bias per (sample, key); everything else is the same kernel.
-template <int HD, int DT, bool CROSS = false>
+// (mfma_util.h: split8_f16, restated here: this file keeps its own fragment helpers) four values -> their nearest f16 and one word of four
+// OCP e4m3 codes of (v - hi) * 2^LO8_A_SHIFT, clamped to +-448
+__device__ __forceinline__ unsigned int split8_f16(float v0, float v1, float v2, float v3, unsigned int& hi01, unsigned int& hi23) {
+  const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
+  hi01 = pack2<LATTE_DTYPE_F16>((float)h0, (float)h1);
+  hi23 = pack2<LATTE_DTYPE_F16>((float)h2, (float)h3);
+  constexpr float S = (float)(1 << LO8_A_SHIFT);
+  auto cl = [](float r) { return __builtin_fminf(__builtin_fmaxf(r, -448.f), 448.f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v0 - (float)h0) * S), cl((v1 - (float)h1) * S), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(cl((v2 - (float)h2) * S), cl((v3 - (float)h3) * S), w, true);
+  return (unsigned int)w;
+}
+
+// One output piece of an attention kernel: four consecutive head-dim values of a token -> 8 bytes of half at `dst` (a.out based), and,
+// with LO8 (f16; guided calls, engine option guided_split bit 2), their fp8 remainder word at the same element offset of a.out8
+// (mfma_util.h: split8_f16) -- the correction operand of the out-projection's GEMM when the fused QKV + attention kernel does not take
+// the shape (round 6; round 5 dropped the split operand silently on this path).
+template <int DT, bool LO8>
+__device__ __forceinline__ void store_out4(const AttnArgs& a, half_t* dst, float v0, float v1, float v2, float v3) {
+  if constexpr (LO8) {
+    unsigned int h0_, h1_;
+    const unsigned int l8 = split8_f16(v0, v1, v2, v3, h0_, h1_);
+    *(u32x2*)dst = (u32x2){h0_, h1_};
+    *(unsigned int*)(a.out8 + (dst - a.out)) = l8;
+  } else {
+    *(u32x2*)dst = (u32x2){pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
+  }
+}
+
+template <int HD, int DT, bool CROSS = false, bool LO8 = false>
 __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;  // k-steps of the QK^T contraction (hd padded to 32)
   constexpr int DF = (HD + 15) / 16;  // 16-wide d fragments of the PV product
@@ -210,8 +239,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
     for (int d = 0; d < DF; ++d) {
       const int dd = 16 * d + 4 * g;
       if (dd < HD) {
-        u32x2 pk = {pack2<DT>(o[d][0] * inv, o[d][1] * inv), pack2<DT>(o[d][2] * inv, o[d][3] * inv)};
-        *(u32x2*)(orow + dd) = pk;
+        store_out4<DT, LO8>(a, orow + dd, o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv);
       }
     }
   }
@@ -230,7 +258,7 @@ __global__ void __launch_bounds__(256) attn_flash_kernel(AttnArgs a) {
 // inside every 16-lane service group) and for the tr reads (8 rows x 32 B tile the 64 banks).
 
 
-template <int HD, int DT>
+template <int HD, int DT, bool LO8 = false>
 __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
   constexpr int DF = (HD + 15) / 16;
@@ -423,9 +451,7 @@ __global__ void __launch_bounds__(256, 2) attn_full_kernel(AttnArgs a) {
         for (int d = 0; d < DF; ++d) {
           const int dd = 16 * d + 4 * g;
           if (dd < HD) {
-            u32x2 pk = {pack2<DT>(o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq]),
-                        pack2<DT>(o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq])};
-            *(u32x2*)(orow + dd) = pk;
+            store_out4<DT, LO8>(a, orow + dd, o[gq][d][0] * inv[gq], o[gq][d][1] * inv[gq], o[gq][d][2] * inv[gq], o[gq][d][3] * inv[gq]);
           }
         }
       }
@@ -459,7 +485,7 @@ __device__ __forceinline__ u32x2 lds_tr16_asm(const char* p) {
   return v;
 }
 
-template <int HD, int DT, int ABL = 0>
+template <int HD, int DT, int ABL = 0, bool LO8 = false>
 __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8;
   constexpr int RP = 160, KB = 128, NKT = KB / 16;     // keys per block, 16-key tiles per block
@@ -700,8 +726,7 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
       for (int d = 0; d < DF; ++d) {
         const int dd = 16 * d + 4 * g;
         if (dd < HD) {
-          u32x2 pk = {pack2<DT>(o[gq][d][0] * inv, o[gq][d][1] * inv), pack2<DT>(o[gq][d][2] * inv, o[gq][d][3] * inv)};
-          *(u32x2*)(orow + dd) = pk;
+          store_out4<DT, LO8>(a, orow + dd, o[gq][d][0] * inv, o[gq][d][1] * inv, o[gq][d][2] * inv, o[gq][d][3] * inv);
         }
       }
     }
@@ -884,7 +909,7 @@ __global__ void __launch_bounds__(512) attn_cross_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int HD, int DT>
+template <int HD, int DT, bool LO8 = false>
 __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
   constexpr int KS = (HD + 31) / 32;
   constexpr int DF = (HD + 15) / 16;
@@ -966,8 +991,7 @@ __global__ void __launch_bounds__(256) attn_small_kernel(AttnArgs a) {
     acc = mfma_k16<DT>(vf, pb, acc);  // O^T[d = 16 d + 4g + r][q = fl]
     const int dd = 16 * d + 4 * g;
     if (active && fl < a.L && dd < HD) {
-      u32x2 pk = {pack2<DT>(acc[0] * inv, acc[1] * inv), pack2<DT>(acc[2] * inv, acc[3] * inv)};
-      *(u32x2*)(orow + dd) = pk;
+      store_out4<DT, LO8>(a, orow + dd, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
     }
   }
 }
@@ -1024,6 +1048,28 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
     } else                                                                                                    \
       hipLaunchKernelGGL((attn_flash_kernel<HD, DT>), grid, block, 0, st, a);                                 \
   } while (0)
+  if (a.out8) {   // f16 + fp8 remainder output (guided calls; AttnArgs::out8)
+    if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "attention: the fp8-remainder output is f16 only");
+#define ATTN_LAUNCH8(HD)                                                                                                        \
+  do {                                                                                                                        \
+    if (small)                                                                                                                \
+      hipLaunchKernelGGL((attn_small_kernel<HD, LATTE_DTYPE_F16, true>), grid, block, 0, st, a);                              \
+    else if (stream) {                                                                                                        \
+      static std::atomic<uint64_t> attr_done_s8{0};                                                                           \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, LATTE_DTYPE_F16, 0, true>, STREAM_LDS, attr_done_s8)) return rc_; \
+      hipLaunchKernelGGL((attn_stream_kernel<HD, LATTE_DTYPE_F16, 0, true>), grid, block, STREAM_LDS, st, a);                 \
+    } else if (full) {                                                                                                        \
+      static std::atomic<uint64_t> attr_done8{0};                                                                             \
+      if (int rc_ = ensure_dynamic_lds((const void*)attn_full_kernel<HD, LATTE_DTYPE_F16, true>, FULL_LDS, attr_done8)) return rc_; \
+      hipLaunchKernelGGL((attn_full_kernel<HD, LATTE_DTYPE_F16, true>), grid, block, FULL_LDS, st, a);                        \
+    } else                                                                                                                    \
+      hipLaunchKernelGGL((attn_flash_kernel<HD, LATTE_DTYPE_F16, false, true>), grid, block, 0, st, a);                       \
+  } while (0)
+    if (a.hd == 64) ATTN_LAUNCH8(64); else ATTN_LAUNCH8(72);
+#undef ATTN_LAUNCH8
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   if (dtype == LATTE_DTYPE_BF16) {
     if (a.hd == 64) ATTN_LAUNCH(64, LATTE_DTYPE_BF16); else ATTN_LAUNCH(72, LATTE_DTYPE_BF16);
   } else if (dtype == LATTE_DTYPE_F16) {

@@ -139,6 +139,7 @@ struct AttnArgs {
   const half_t* kv;
   const float* kbias;
   int Lk, q_ld;
+  unsigned char* out8;    // f16 only, may be nullptr: [rows, D] bytes receive the fp8 remainder of the output (mfma_util.h: split8_f16)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t st);
 int launch_cross_attention(const AttnArgs& a, int dtype, hipStream_t st);

@@ -204,6 +204,15 @@ int latte_debug_attention(const void* qkv, void* out, int num_seq, int L, int he
   return launch_attention(a, dtype, (hipStream_t)stream);
 }
 
+int latte_debug_attention_split8(const void* qkv, void* out, void* out8, int num_seq, int L, int heads, int hd, int U, int64_t sample_stride,
+                                 int64_t seq_stride, int64_t row_stride, int dtype, void* stream) {
+  AttnArgs a{};
+  a.qkv = (const half_t*)qkv; a.out = (half_t*)out; a.out8 = (unsigned char*)out8; a.num_seq = num_seq; a.L = L; a.heads = heads; a.hd = hd;
+  a.D = heads * hd; a.U = U; a.sample_stride = sample_stride; a.seq_stride = seq_stride; a.row_stride = row_stride;
+  a.scale = 1.0f / sqrtf((float)hd);
+  return launch_attention(a, dtype, (hipStream_t)stream);
+}
+
 int latte_debug_qkv_attention(const void* xn, const void* w, const float* bias, void* out, void* dbg_qkv, int B, int F, int T, int D,
                               int heads, int mode, int flags, int dtype, void* stream) {
   return latte_debug_qkv_attention_trace(xn, w, bias, out, dbg_qkv, nullptr, B, F, T, D, heads, mode, flags, dtype, stream);

@@ -347,6 +347,11 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
       a.sample_stride = rps; a.scale = 1.0f / std::sqrt((float)e->hd);
       if (spatial) { a.num_seq = B * F; a.L = T; a.U = F; a.seq_stride = T; a.row_stride = 1; }
       else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
+      if (gsplit & 4) {   // the un-fused attention kernels carry the fp8 remainder too (round 6); the f16-pair form (bit 0) exists in the fused kernel only
+        a.out8 = e->lo8;
+        split_proj = true;
+        gactive |= 4;
+      }
       if ((rc = launch_attention(a, dt, st))) return rc;
       tm.mark(spatial ? C_ATTN_S : C_ATTN_T);
     }

@@ -99,6 +99,39 @@ def test_fused_qkv_attention_fp8_remainder(lib, dev, case, mode):
     assert rel < 0.05
 
 
+@pytest.mark.parametrize("case", [(2, 4, 64, 6, 64), (1, 3, 200, 2, 72), (1, 2, 300, 2, 72), (2, 16, 1024, 2, 64), (2, 4, 16, 2, 64), (1, 3, 5, 3, 72)])
+@pytest.mark.parametrize("mode", ["spatial", "temporal"])
+def test_unfused_attention_fp8_remainder(lib, dev, case, mode):
+    """The un-fused attention kernels (generic flash, 128 < L <= 256, L > 256 streaming, L <= 16) with the fp8-remainder output: the f16
+    half is the plain call's output bit for bit, and f16 + remainder is >= 8 x closer to the fp32 attention on the same half q | k | v
+    than the f16 output alone (what the out-projection's correction pass then removes)."""
+    B, F, T, H, hd = case
+    D, rows = H * hd, B * F * T
+    g = torch.Generator("cpu").manual_seed(rows + hd)
+    qkv = torch.randn(rows, 3 * D, generator=g).to(dev).to(torch.float16)
+    args = (B * F, T, H, hd, F, F * T, T, 1) if mode == "spatial" else (B * T, F, H, hd, T, F * T, 1, T)
+    L = T if mode == "spatial" else F
+    plain = torch.zeros(rows, D, dtype=torch.float16, device=dev)
+    check(lib.latte_debug_attention(ptr(qkv), ptr(plain), *args, 1, stream_ptr()))
+    hi = torch.zeros(rows, D, dtype=torch.float16, device=dev)
+    lo8 = torch.zeros(rows, D, dtype=torch.uint8, device=dev)
+    check(lib.latte_debug_attention_split8(ptr(qkv), ptr(hi), ptr(lo8), *args, 1, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(hi.view(torch.int16), plain.view(torch.int16))
+    q, k, v = qkv.float().reshape(B, F, T, 3, H, hd).unbind(3)
+    if mode == "spatial":
+        q, k, v = (t_.permute(0, 1, 3, 2, 4) for t_ in (q, k, v))
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(rows, D)
+    else:
+        q, k, v = (t_.permute(0, 2, 3, 1, 4) for t_ in (q, k, v))
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(rows, D)
+    e_plain = float((plain.float() - ref).norm() / ref.norm())
+    e_pair = float((hi.float() + lo8.view(F8).float() * 2.0 ** -A_SHIFT - ref).norm() / ref.norm())
+    print(case, mode, L, e_plain, e_pair)
+    # what is left with the remainder is the kernel's own P rounding (the probabilities feed the MFMA as f16), as for the f16 pair of round 5
+    assert e_pair < 0.75 * e_plain and e_pair < 6e-4
+
+
 LO_SHAPES = [(512, 384, 1152, 256), (300, 192, 256, 100), (256, 192, 128, 256), (11520, 1152, 1152, 256), (4096, 4608, 1152, 4096)]
 
 
