@@ -8,7 +8,7 @@ import latte_amd
 name = os.environ.get("LATTE_TRAIN_MODEL", "Latte-B/2")
 B = int(os.environ.get("LATTE_TRAIN_BATCH", "5"))
 steps = int(os.environ.get("LATTE_TRAIN_STEPS", "10"))
-dtype = os.environ.get("LATTE_TRAIN_DTYPE", "bf16")
+dtype = os.environ.get("LATTE_TRAIN_DTYPE", "f16")
 model = latte_amd.Latte_models[name](input_size=32, num_frames=16, extras=1, max_batch=B).to("cuda")
 with torch.no_grad():
     for p in model.parameters():
