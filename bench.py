@@ -596,8 +596,9 @@ def config4_rate(device, n_steps=4):
             ach = 14 * vae_temporal_decoder_flops(64)[1] / (ms * 1e-3) / 1e12
             row.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                         "algorithmic_flops": 14 * vae_temporal_decoder_flops(64)[1],
-                        "kernel": "conv3x3_pp_kernel / conv3x3_kernel: implicit-GEMM 3x3 and (3,1,1) convolutions; spatial ones run twice (activation "
-                                  "remainder pass), temporal ones three times (hi.hi + lo.hi + hi.lo) for the 1e-3 parity of this decoder"})
+                        "kernel": "conv3x3_pp_kernel / conv3x3_kernel: implicit-GEMM 3x3 and (3,1,1) convolutions; the split-operand passes of the default "
+                                  "mask 0x319c03 (csrc/vae_engine.cpp: vae_split_mask -- activation and weight f16 rounding residuals on the mid block, "
+                                  "up block 0 and its upsampler) are cost, not counted work"})
         table.append(row)
     table.sort(key=lambda r: -r["share_of_decode"])
     res["temporal_decoder"]["roofline_table"] = table

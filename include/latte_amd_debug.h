@@ -130,6 +130,9 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
  *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too
  *   "conv_kernel"     1 = the plain 128 x 128 implicit-GEMM convolution everywhere, 2 | 3 = the ping-pong 256-pixel kernel everywhere,
  *                     4 = its persistent form (round 6: bit-identical, measured 6 - 13 % slower, not a default anywhere)
+ *   "vae_split"       1024 + m: which stages of the temporal decoder run split-operand convolutions -- bits 0..4 of m = the spatial resnets of
+ *                     {mid block, up block 0..3} add the pass on the activation's f16 rounding residual, bits 5..9 = the temporal resnets of the
+ *                     same stages run three passes (hi*hi + lo*hi + hi*lo) instead of one (csrc/vae_engine.cpp: vae_split_mask)
  * Anything else is refused (LATTE_ERR_INVALID).  Replaces the LATTE_* environment variables round 3 read at every launch; the
  * measurement ablations whose results are garbage (attention variants 7-9) exist only in a LATTE_DEBUG_BUILD=1 library. */
 int latte_debug_set_choice(const char* name, int value);

@@ -205,7 +205,7 @@ int launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
 // Kernel-choice overrides of the A/B tests (latte_debug_set_choice, include/latte_amd_debug.h; engine.cpp).  Process-global, 0 = the
 // library's own choice.  Every value selects another implementation of the SAME function; nothing here can change a result beyond
 // rounding.  (Round 3 read environment variables at every launch instead, among them ablations with garbage results.)
-enum DebugChoice { DBG_ATTN_VARIANT = 0, DBG_XATTN_FLASH, DBG_TN_KERNEL, DBG_TN_WN, DBG_ATTN_BWD_TILES, DBG_CONV_KERNEL, DBG_NUM_CHOICES };
+enum DebugChoice { DBG_ATTN_VARIANT = 0, DBG_XATTN_FLASH, DBG_TN_KERNEL, DBG_TN_WN, DBG_ATTN_BWD_TILES, DBG_CONV_KERNEL, DBG_VAE_SPLIT, DBG_NUM_CHOICES };
 int debug_choice(DebugChoice c);
 int set_debug_choice(const char* name, int value);   // 0 = ok, -1 = unknown name / value not offered by this build
 
@@ -219,6 +219,7 @@ int launch_t2v_guided_ddim(float* x, const float* model_out, int b, int C, int C
 int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st);   // bias = (1 - mask) * -10000
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
+int launch_convert_f32_to_h16_split(const float* in, half_t* out, half_t* out_lo, int64_t n, int dtype, hipStream_t st);   // + the f16 rounding residual
 int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);
 int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);
 // Philox4x32-10 + Box-Muller standard normals; element i depends only on (seed, offset + i).
@@ -240,9 +241,9 @@ int groupnorm_max_slabs();
 int launch_post_quant(const float* z, const float* w, const float* b, float* out, int N, int hw, float z_scale, hipStream_t st);
 int launch_conv_in(const float* x, const float* wt, const float* bias, float* out, int N, int H, int W, int Cout, hipStream_t st);
 int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* out, int N, int H, int W, int C, int out_mode,
-                    int dtype, hipStream_t st);
+                    int dtype, hipStream_t st, const half_t* x_lo = nullptr);   // x_lo: the f16 rounding residual of x (split input), or nullptr
 int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale, int dtype, hipStream_t st);
-int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st);
+int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st, half_t* out_lo = nullptr);   // out_lo: the f16 rounding residual
 int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int transpose, hipStream_t st);
 
 // ---- training-step kernels (train.hip, train_attn.hip) --------------------------------------------------------------

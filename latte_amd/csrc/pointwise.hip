@@ -725,6 +725,16 @@ __global__ void convert_kernel(const float* __restrict__ in, half_t* __restrict_
   }
 }
 
+// fp32 -> nearest f16 and the f16 of the rounding residual (the split operand of the VAE's shortcut / upsampler products)
+__global__ void convert_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, half_t* __restrict__ out_lo, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = in[i];
+    const _Float16 h = (_Float16)v;
+    out[i] = __builtin_bit_cast(half_t, h);
+    out_lo[i] = __builtin_bit_cast(half_t, (_Float16)(v - (float)h));
+  }
+}
+
 template <int DT>
 __global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1071,6 +1081,13 @@ int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype
     hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
   else
     hipLaunchKernelGGL(convert_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, (size_t)n);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+int launch_convert_f32_to_h16_split(const float* in, half_t* out, half_t* out_lo, int64_t n, int dtype, hipStream_t st) {
+  if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "convert_split: f16 only");
+  hipLaunchKernelGGL(convert_split_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, out_lo, (size_t)n);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

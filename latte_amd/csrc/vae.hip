@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
 template <int DT>
 __global__ void __launch_bounds__(256) conv_out_kernel(const half_t* __restrict__ x, const float* __restrict__ wt,
                                                        const float* __restrict__ bias, void* __restrict__ out, int N, int H,
-                                                       int W, int C, int out_mode) {
+                                                       int W, int C, int out_mode, const half_t* __restrict__ x_lo) {
   extern __shared__ float wl[];   // [3][9 * C]
   for (int i = threadIdx.x; i < 27 * C; i += 256) wl[i] = wt[i];
   __syncthreads();
@@ -822,6 +822,14 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const half_t* __restrict_
       float f[8];
       unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
       unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+      if (x_lo != nullptr) {   // split input: the f16 rounding residual of the GroupNorm output (the weights here are fp32 already)
+        const u32x4 l = *(const u32x4*)(x_lo + (px - x) + c);
+        float g[8];
+        unpack2<DT>(l[0], g[0], g[1]); unpack2<DT>(l[1], g[2], g[3]);
+        unpack2<DT>(l[2], g[4], g[5]); unpack2<DT>(l[3], g[6], g[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         a0 = fmaf(f[e], w0[c + e], a0);
@@ -857,7 +865,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const half_t* __restrict_
 template <int DT>
 __global__ void __launch_bounds__(256) conv_out_c128_kernel(const half_t* __restrict__ x, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, void* __restrict__ out, int N, int H,
-                                                            int W, int out_mode) {
+                                                            int W, int out_mode, const half_t* __restrict__ x_lo) {
   constexpr int C = 128;
   extern __shared__ float wl[];   // [3][9 * C]
   for (int i = threadIdx.x; i < 27 * C; i += 256) wl[i] = wt[i];
@@ -889,6 +897,14 @@ __global__ void __launch_bounds__(256) conv_out_c128_kernel(const half_t* __rest
       float f[8];
       unpack2<DT>(v[0], f[0], f[1]); unpack2<DT>(v[1], f[2], f[3]);
       unpack2<DT>(v[2], f[4], f[5]); unpack2<DT>(v[3], f[6], f[7]);
+      if (x_lo != nullptr && xx >= 0 && xx < W) {   // split input (see conv_out_kernel)
+        const u32x4 l = *(const u32x4*)(x_lo + (rowp - x) + (size_t)xx * C);
+        float q[8];
+        unpack2<DT>(l[0], q[0], q[1]); unpack2<DT>(l[1], q[2], q[3]);
+        unpack2<DT>(l[2], q[4], q[5]); unpack2<DT>(l[3], q[6], q[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += q[e];
+      }
 #pragma unroll
       for (int o = 0; o < 3; ++o)
 #pragma unroll
@@ -963,7 +979,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
 
 // [Cout, Cin, 3, 3] fp32 -> [Cout, 9 * Cin] half, k = (ky * 3 + kx) * Cin + ci
 template <int DT>
-__global__ void pack_conv_w_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin, half_t* __restrict__ out_lo) {
   const size_t total = (size_t)Cout * Cin * 9;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int co = (int)(i / ((size_t)Cin * 9));
@@ -976,6 +992,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, half_t* __restri
     } else {
       const _Float16 h = (_Float16)v;
       out[i] = __builtin_bit_cast(half_t, h);
+      if (out_lo != nullptr) out_lo[i] = __builtin_bit_cast(half_t, (_Float16)(v - (float)h));   // the weight's f16 rounding residual
     }
   }
 }
@@ -1159,14 +1176,14 @@ int launch_conv_in(const float* x, const float* wt, const float* bias, float* ou
 }
 
 int launch_conv_out(const half_t* x, const float* wt, const float* bias, void* out, int N, int H, int W, int C, int out_mode,
-                    int dtype, hipStream_t st) {
+                    int dtype, hipStream_t st, const half_t* x_lo) {
   const int total = N * H * W;
   const size_t lds = (size_t)27 * C * sizeof(float);
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "conv_out: the VAE kernels are built for f16 operands only");
   if (C == 128 && W % 16 == 0)   // 64 pixels per workgroup (4 waves x 16)
-    hipLaunchKernelGGL(conv_out_c128_kernel<LATTE_DTYPE_F16>, dim3((total + 63) / 64), dim3(256), lds, st, x, wt, bias, out, N, H, W, out_mode);
+    hipLaunchKernelGGL(conv_out_c128_kernel<LATTE_DTYPE_F16>, dim3((total + 63) / 64), dim3(256), lds, st, x, wt, bias, out, N, H, W, out_mode, x_lo);
   else
-    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode);
+    hipLaunchKernelGGL(conv_out_kernel<LATTE_DTYPE_F16>, dim3((total + 255) / 256), dim3(256), lds, st, x, wt, bias, out, N, H, W, C, out_mode, x_lo);
   kprof_mark(VC_SMALL, st);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -1180,10 +1197,10 @@ int launch_softmax_rows(const float* s, half_t* p, int rows, int L, float scale,
   return LATTE_OK;
 }
 
-int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st) {
+int launch_pack_conv_w(const float* w, half_t* out, int Cout, int Cin, int dtype, hipStream_t st, half_t* out_lo) {
   const size_t n = (size_t)Cout * Cin * 9;
   if (dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "pack_conv_w: the VAE kernels are built for f16 operands only");
-  hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin);
+  hipLaunchKernelGGL(pack_conv_w_kernel<LATTE_DTYPE_F16>, dim3(grid_for(n, 256)), dim3(256), 0, st, w, out, Cout, Cin, out_lo);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }

@@ -48,11 +48,13 @@ struct VSlot {
   void* dst;
   int cout, cin;
   bool loaded = false;
+  void* dst_lo = nullptr;   // VP_CONV3 / VP_LINEAR_H16: the f16 rounding residual of the packed weight (split-operand passes), or nullptr
 };
 struct Resnet {
   int cin, cout;
   float *n1w, *n1b, *n2w, *n2b, *c1b, *c2b, *scb = nullptr;
   half_t *c1w, *c2w, *scw = nullptr;
+  half_t *c1w_lo = nullptr, *c2w_lo = nullptr, *scw_lo = nullptr;   // f16 rounding residuals of the weights (temporal decoder's split passes)
 };
 // TemporalResnetBlock + AlphaBlender of a SpatioTemporalResBlock (AutoencoderKLTemporalDecoder): Conv3d (3,1,1) weights as
 // [C][3 C] half; conv2 and its bias are kept in fp32 too and folded with sigmoid(mix_factor) before the first decode
@@ -74,6 +76,7 @@ struct latte_vae {
   Resnet mid[2];
   Resnet up[4][3];
   half_t* upc_w[3];
+  half_t* upc_w_lo[3] = {nullptr, nullptr, nullptr};   // temporal decoder: f16 rounding residual of the upsampler weights
   float* upc_b[3];
   float *agn_w, *agn_b, *aq_b, *ak_b, *av_b, *ao_b, *ao_b_eff, *zero_bias;
   float* ao_w_f32;     // to_out weight in fp32 (for the folded bias  Wo bv + bo)
@@ -124,14 +127,19 @@ int make_resnet(latte_vae* v, Resnet& r, const std::string& p, int cin, int cout
   vslot(v, p + "norm1.weight", cin, VP_F32, r.n1w);
   vslot(v, p + "norm1.bias", cin, VP_F32, r.n1b);
   vslot(v, p + "conv1.weight", (int64_t)cout * cin * 9, VP_CONV3, r.c1w, cout, cin);
+  if ((rc = valloc(v, &r.c1w_lo, (size_t)cout * cin * 9)) || (rc = valloc(v, &r.c2w_lo, (size_t)cout * cout * 9))) return rc;
+  v->slots.back().dst_lo = r.c1w_lo;
   vslot(v, p + "conv1.bias", cout, VP_F32, r.c1b);
   vslot(v, p + "norm2.weight", cout, VP_F32, r.n2w);
   vslot(v, p + "norm2.bias", cout, VP_F32, r.n2b);
   vslot(v, p + "conv2.weight", (int64_t)cout * cout * 9, VP_CONV3, r.c2w, cout, cout);
+  v->slots.back().dst_lo = r.c2w_lo;
   vslot(v, p + "conv2.bias", cout, VP_F32, r.c2b);
   if (cin != cout) {
     if ((rc = valloc(v, &r.scw, (size_t)cout * cin)) || (rc = valloc(v, &r.scb, cout))) return rc;
     vslot(v, p + "conv_shortcut.weight", (int64_t)cout * cin, VP_LINEAR_H16, r.scw);
+    if ((rc = valloc(v, &r.scw_lo, (size_t)cout * cin))) return rc;
+    v->slots.back().dst_lo = r.scw_lo;
     vslot(v, p + "conv_shortcut.bias", cout, VP_F32, r.scb);
   }
   return LATTE_OK;
@@ -159,11 +167,26 @@ int make_tresnet(latte_vae* v, TResnet& t, const std::string& p, int c) {
   return LATTE_OK;
 }
 
+// Which convolutions of the temporal decoder run as split-operand products (round 6).  Bits 0..4: the spatial resnets of {mid block, up block
+// 0..3} add the pass on the activation's f16 rounding residual; bits 5..9: the temporal resnets of the same stages run hi*hi + lo*hi + hi*lo
+// instead of one pass; bit 10: the 1x1 shortcuts' half copy of the stream as hi + lo (a second GEMM pass); bit 11: conv_out reads its input as
+// hi + lo; bits 12..14: the upsampler convolution of up block 0..2 adds the pass on the residual of its half copy of the stream; bits 15..19: the
+// spatial resnets of the five stages add the pass on the WEIGHTS' f16 rounding residual; bit 20: the shortcuts' weight residual; bits 21..23: the
+// upsamplers' weight residual.
+// latte_debug_set_choice("vae_split", (1 << 24) | mask) overrides the default (measurement / parity sweeps).
+constexpr int VAE_SPLIT_DEFAULT_TEMPORAL = 0x319c03, VAE_SPLIT_DEFAULT_SPATIAL = 0x301c00;
+int vae_split_mask(const latte_vae* v) {
+  const int c = debug_choice(DBG_VAE_SPLIT);
+  return (c >> 24) == 1 ? (c & 0xffffff) : (v->temporal ? VAE_SPLIT_DEFAULT_TEMPORAL : VAE_SPLIT_DEFAULT_SPATIAL);
+}
+
 int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, const half_t* res, int M, int N, int K, int epi,
              int dtype, hipStream_t st) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.res = res; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M;
-  const int rc_ = launch_gemm(g, epi, dtype, 1, st);   // plain 128 x 128 kernel: small, oddly shaped problems
+  // plain 128 x 128 kernel: small, oddly shaped problems (round 6: the library's own tile choice for the 1x1 shortcuts of the large maps
+  // measured the same decode time, profiles/r6_vae_split_sweep.log)
+  const int rc_ = launch_gemm(g, epi, dtype, 1, st);
   kprof_mark(VC_ATTN, st);                              // (only the mid-block attention and the 1x1 shortcuts come through here)
   return rc_;
 }
@@ -171,41 +194,72 @@ int gemm_h16(const half_t* A, const half_t* W, const float* bias, void* out, con
 // ResnetBlock2D on the fp32 stream: x = *s -> *s (in place when cin == cout, else through *s2 and the two are swapped);
 // b, c, d: half scratch.  [N, H, W, C]
 int run_resnet(latte_vae* v, const Resnet& r, float** s, float** s2, half_t* b, half_t* c, half_t* d, int N, int H, int W,
-               hipStream_t st) {
+               hipStream_t st, int stage) {
   int rc;
   const int HW = H * W, dt = v->dtype;
   float* x = *s;
   // temporal-decoder mode: the activation operand of both 3x3 convolutions is split hi + lo (b = the f16 rounding residual of the
   // GroupNorm output) and a second pass adds conv(lo): the decoder with twice as many blocks per stage stays under the 1e-3 bar
-  half_t* lo = v->temporal ? b : nullptr;
+  // (round 6: per decoder stage -- split_mask bit `stage`, 0 = mid block, 1 + i = up block i; vae_split_mask())
+  half_t* lo = ((vae_split_mask(v) >> stage) & 1) ? b : nullptr;
+  const bool wlo = (vae_split_mask(v) >> (15 + stage)) & 1;   // + the pass hi * (weight residual)
+  if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result (first: b is free here)
+    float* y = *s2;
+    if ((vae_split_mask(v) >> 10) & 1) {   // the half copy as hi + lo: y = hi W^T + b, then y += lo W^T (gated-residual epilogue, gate = 1)
+      if ((rc = launch_convert_f32_to_h16_split(x, d, b, (int64_t)N * HW * r.cin, dt, st))) return rc;
+      kprof_mark(VC_SMALL, st);
+      if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
+      GemmArgs g{};
+      g.A = b; g.W = r.scw; g.bias = v->zero_bias; g.out = y; g.gate = v->ones; g.gate_stride = 0;
+      g.M = N * HW; g.N = r.cout; g.K = r.cin; g.rows_per_sample = N * HW;
+      const int sc_variant = 1;
+      if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, sc_variant, st))) return rc;
+      kprof_mark(VC_ATTN, st);
+      if (r.scw_lo && ((vae_split_mask(v) >> 20) & 1)) {   // + hi * (weight residual)
+        g.A = d; g.W = r.scw_lo;
+        if ((rc = launch_gemm(g, EPI_GATE_RES_F32, dt, sc_variant, st))) return rc;
+        kprof_mark(VC_ATTN, st);
+      }
+    } else {
+      if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
+      kprof_mark(VC_SMALL, st);
+      if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
+    }
+  }
   if ((rc = launch_groupnorm(x, 1, c, r.n1w, r.n1b, v->gn_partial, v->gn_stats, N, HW, r.cin, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
   if ((rc = launch_conv3x3(c, r.c1w, r.c1b, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, nullptr, v->tbuf))) return rc;
   if (lo && (rc = launch_conv3x3(lo, r.c1w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, v->tbuf, v->tbuf))) return rc;
+  if (wlo && (rc = launch_conv3x3(c, r.c1w_lo, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cin, r.cout, 0, dt, st, v->tbuf, v->tbuf))) return rc;
   if ((rc = launch_groupnorm(v->tbuf, 1, c, r.n2w, r.n2b, v->gn_partial, v->gn_stats, N, HW, r.cout, 1, dt, st, 1e-6f, groupnorm_max_slabs(), lo))) return rc;
-  if (r.cin != r.cout) {   // conv_shortcut 1x1 = a GEMM over pixels on a half copy of the stream, fp32 result
+  if (r.cin != r.cout) {
     float* y = *s2;
-    if ((rc = launch_convert_f32_to_h16(x, d, (int64_t)N * HW * r.cin, dt, st))) return rc;
-    kprof_mark(VC_SMALL, st);
-    if ((rc = gemm_h16(d, r.scw, r.scb, y, nullptr, N * HW, r.cout, r.cin, EPI_BIAS_F32, dt, st))) return rc;
     if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     if (lo && (rc = launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
+    if (wlo && (rc = launch_conv3x3(c, r.c2w_lo, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, y, y))) return rc;
     std::swap(*s, *s2);
     return LATTE_OK;
   }
   if ((rc = launch_conv3x3(c, r.c2w, r.c2b, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x))) return rc;
-  if (lo) return launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
+  if (lo && (rc = launch_conv3x3(lo, r.c2w, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x))) return rc;
+  if (wlo) return launch_conv3x3(c, r.c2w_lo, v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, r.cout, r.cout, 0, dt, st, x, x);
   return LATTE_OK;
 }
 
 // TemporalResnetBlock + AlphaBlender on the fp32 stream of ONE video [T, H, W, C]: the frames are the rows of an "image"
 // [T][H W], so the Conv3d (3,1,1) is the implicit-GEMM conv kernel with 3 taps along the rows and GroupNorm sees T H W pixels
-int run_tresnet(latte_vae* v, const TResnet& t, float* x, half_t* c, half_t* clo, int T, int H, int W, hipStream_t st) {
+int run_tresnet(latte_vae* v, const TResnet& t, float* x, half_t* c, half_t* clo, int T, int H, int W, hipStream_t st, int stage) {
   // The two Conv3d run as SPLIT-OPERAND convolutions: activation = hi + lo and weight = hi + lo in f16 (lo = the rounding
   // residual), three MFMA passes hi*hi + lo*hi + hi*lo accumulated in the fp32 output -- the temporal branch then adds ~1e-6 of
   // error instead of one more f16 roundoff per block (with single-pass convolutions the decode measured 1.04e-3 against the
   // fp32 restatement, above the 1e-3 bar; a 3-tap convolution costs a third of a 3x3 one, so three passes cost one)
   int rc;
   const int HW = H * W, dt = v->dtype, C = t.c;
+  if (!((vae_split_mask(v) >> (5 + stage)) & 1)) {   // single-pass temporal convolutions at this stage (split_mask bit 5 + stage clear)
+    if ((rc = launch_groupnorm(x, 1, c, t.n1w, t.n1b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, groupnorm_max_slabs() * T, nullptr))) return rc;
+    if ((rc = launch_conv3x3(c, t.c1w, t.c1b, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, nullptr, v->tbuf, 1))) return rc;
+    if ((rc = launch_groupnorm(v->tbuf, 1, c, t.n2w, t.n2b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, groupnorm_max_slabs() * T, nullptr))) return rc;
+    return launch_conv3x3(c, t.c2w, t.c2b_eff, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, x, x, 1);
+  }
   if ((rc = launch_groupnorm(x, 1, c, t.n1w, t.n1b, v->gn_partial, v->gn_stats, 1, T * HW, C, 1, dt, st, 1e-5f, groupnorm_max_slabs() * T, clo))) return rc;
   if ((rc = launch_conv3x3(c, t.c1w, t.c1b, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, nullptr, v->tbuf, 1))) return rc;
   if ((rc = launch_conv3x3(clo, t.c1w, v->zero_bias, nullptr, nullptr, v->zeros, 1, T, HW, C, C, 0, dt, st, v->tbuf, v->tbuf, 1))) return rc;
@@ -296,6 +350,8 @@ int vae_create_impl(int latent_size, int max_frames, int compute_dtype, bool tem
       TRY(valloc(v, &v->upc_b[i], cout));
       const std::string p = "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       vslot(v, p + "weight", (int64_t)cout * cout * 9, VP_CONV3, v->upc_w[i], cout, cout);
+      TRY(valloc(v, &v->upc_w_lo[i], (size_t)cout * cout * 9));
+      v->slots.back().dst_lo = v->upc_w_lo[i];
       vslot(v, p + "bias", cout, VP_F32, v->upc_b[i]);
     }
   }
@@ -363,8 +419,11 @@ int latte_vae_load_tensor(latte_vae_t* v, const char* key, const float* data, in
   int rc = LATTE_OK;
   switch (s.kind) {
     case VP_F32: LATTE_HIP(hipMemcpyAsync(s.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, st)); break;
-    case VP_CONV3: rc = launch_pack_conv_w(src, (half_t*)s.dst, s.cout, s.cin, v->dtype, st); break;
-    case VP_LINEAR_H16: rc = launch_convert_f32_to_h16(src, (half_t*)s.dst, numel, v->dtype, st); break;
+    case VP_CONV3: rc = launch_pack_conv_w(src, (half_t*)s.dst, s.cout, s.cin, v->dtype, st, (half_t*)s.dst_lo); break;
+    case VP_LINEAR_H16:
+      rc = s.dst_lo ? launch_convert_f32_to_h16_split(src, (half_t*)s.dst, (half_t*)s.dst_lo, numel, v->dtype, st)
+                    : launch_convert_f32_to_h16(src, (half_t*)s.dst, numel, v->dtype, st);
+      break;
     case VP_SMALL_T: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 1, st); break;
     case VP_SMALL: rc = launch_pack_small_w(src, (float*)s.dst, s.cout, s.cin, 0, st); break;
     case VP_CONVT: {
@@ -467,8 +526,8 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
   if ((rc = launch_post_quant(z, v->pq_w, v->pq_b, v->pq_out, N, H * W, z_scale, st))) return rc;
   if ((rc = launch_conv_in(v->pq_out, v->ci_wt, v->ci_b, a, N, H, W, top, st))) return rc;
   if (traced(rc)) return rc;
-  if ((rc = run_resnet(v, v->mid[0], &a, &a2, b, c, d, N, H, W, st))) return rc;
-  if (v->temporal && (rc = run_tresnet(v, v->tmid[0], a, c, d, N, H, W, st))) return rc;
+  if ((rc = run_resnet(v, v->mid[0], &a, &a2, b, c, d, N, H, W, st, 0))) return rc;
+  if (v->temporal && (rc = run_tresnet(v, v->tmid[0], a, c, d, N, H, W, st, 0))) return rc;
   if (traced(rc)) return rc;
   {  // mid-block attention: 1 head, dim 512, tokens = H*W per frame
     const int L = H * W;
@@ -497,21 +556,27 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     }
   }
   if (traced(rc)) return rc;
-  if ((rc = run_resnet(v, v->mid[1], &a, &a2, b, c, d, N, H, W, st))) return rc;
-  if (v->temporal && (rc = run_tresnet(v, v->tmid[1], a, c, d, N, H, W, st))) return rc;
+  if ((rc = run_resnet(v, v->mid[1], &a, &a2, b, c, d, N, H, W, st, 0))) return rc;
+  if (v->temporal && (rc = run_tresnet(v, v->tmid[1], a, c, d, N, H, W, st, 0))) return rc;
   if (traced(rc)) return rc;
   for (int i = 0; i < 4; ++i) {
     for (int r = 0; r < 3; ++r) {
-      if ((rc = run_resnet(v, v->up[i][r], &a, &a2, b, c, d, N, H, W, st))) return rc;
-      if (v->temporal && (rc = run_tresnet(v, v->tup[i][r], a, c, d, N, H, W, st))) return rc;
+      if ((rc = run_resnet(v, v->up[i][r], &a, &a2, b, c, d, N, H, W, st, 1 + i))) return rc;
+      if (v->temporal && (rc = run_tresnet(v, v->tup[i][r], a, c, d, N, H, W, st, 1 + i))) return rc;
       cur_c = v->up[i][r].cout;
       if (traced(rc)) return rc;
     }
     if (i < 3) {  // Upsample2D: nearest x2 folded into the conv's gather (on a half copy of the stream), fp32 result
       const int cch = v->ch[3 - i];
-      if ((rc = launch_convert_f32_to_h16(a, d, (int64_t)N * H * W * cch, dt, st))) return rc;
+      const bool ups_lo = (vae_split_mask(v) >> (12 + i)) & 1;   // the half copy as hi + lo, a second pass on lo
+      if (ups_lo) rc = launch_convert_f32_to_h16_split(a, d, c, (int64_t)N * H * W * cch, dt, st);
+      else rc = launch_convert_f32_to_h16(a, d, (int64_t)N * H * W * cch, dt, st);
+      if (rc) return rc;
       kprof_mark(VC_SMALL, st);
       if ((rc = launch_conv3x3(d, v->upc_w[i], v->upc_b[i], nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, nullptr, a2))) return rc;
+      if (ups_lo && (rc = launch_conv3x3(c, v->upc_w[i], v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, a2, a2))) return rc;
+      if (v->upc_w_lo[i] && ((vae_split_mask(v) >> (21 + i)) & 1) &&
+          (rc = launch_conv3x3(d, v->upc_w_lo[i], v->zero_bias, nullptr, nullptr, v->zeros, N, H, W, cch, cch, 1, dt, st, a2, a2))) return rc;
       std::swap(a, a2);
       H *= 2;
       W *= 2;
@@ -519,10 +584,11 @@ static int vae_decode_impl(latte_vae_t* v, const float* z, int n_frames, float z
     }
   }
   if (stop_after >= 0) return fail(LATTE_ERR_INVALID, "vae_trace: stage index beyond the last traced stage");
-  if ((rc = launch_groupnorm(a, 1, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st))) return rc;
-  if (!v->temporal) return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st);
+  half_t* co_lo = ((vae_split_mask(v) >> 11) & 1) ? b : nullptr;   // conv_out reads the GroupNorm output as hi + lo (its weights are fp32)
+  if ((rc = launch_groupnorm(a, 1, c, v->no_w, v->no_b, v->gn_partial, v->gn_stats, N, H * W, v->ch[0], 1, dt, st, 1e-6f, groupnorm_max_slabs(), co_lo))) return rc;
+  if (!v->temporal) return launch_conv_out(c, v->co_w, v->co_b, out, N, H, W, v->ch[0], out_mode, dt, st, co_lo);
   // conv_out to fp32 NCHW frames, then time_conv_out over the frames of the chunk
-  if ((rc = launch_conv_out(c, v->co_w, v->co_b, v->tbuf, N, H, W, v->ch[0], 0, dt, st))) return rc;
+  if ((rc = launch_conv_out(c, v->co_w, v->co_b, v->tbuf, N, H, W, v->ch[0], 0, dt, st, co_lo))) return rc;
   return launch_time_conv_out(v->tbuf, v->tco_w, v->tco_b, out, N, H * W, out_mode, st);
 }
 

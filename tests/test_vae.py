@@ -292,3 +292,60 @@ def test_vae_full_size_frame_independence(lib):
     for f in (0, 7, 15):
         one = vae.decode(z[f:f + 1]).sample
         assert torch.equal(one[0], full[f])
+
+
+SD_SPLIT_MASKS = [0x0, 0xc00, 0x100c00, 0x301c00, 0x319c00, 0x319c03, 0x31bc07, 0xffffff & ~0x3e0]
+
+
+@pytest.mark.gpu
+def test_vae_split_mask_sweep(lib):
+    """Round 6: the split-operand passes of csrc/vae_engine.cpp (vae_split_mask: activation / weight f16 rounding residuals per stage, the
+    1x1 shortcuts, the upsampler convolutions, conv_out's input) on the SD-VAE decoder -- decode error against the fp32 restatement over
+    five (weights, latent) draws and the time of a 16-frame 256 x 256 decode per mask.  RECORDED in gpurun_out/vae_split_sweep_sd.json
+    (-> profiles/); asserted: the library's default mask holds the 1e-3 bar on every draw."""
+    import json
+    import os
+    import time
+    from _util import ROOT
+    from latte_amd._lib import check
+    from latte_amd.vae import AutoencoderKL
+    draws = [(1, 2, 16, 5), (6, 2, 32, 11), (7, 1, 32, 3), (8, 2, 16, 4), (9, 1, 32, 6)]
+    table = {f"{m:#08x}": {} for m in SD_SPLIT_MASKS}
+    table["default"] = {}
+    try:
+        for seed, frames, latent, zseed in draws:
+            sd = vo.init_state_dict(seed=seed)
+            z = torch.randn(frames, 4, latent, latent, generator=torch.Generator().manual_seed(zseed))
+            want = vo.decode(sd, z)
+            vae = AutoencoderKL(latent_size=latent, max_frames=frames)
+            vae.load_state_dict(sd)
+            vae.to("cuda")
+            for m in SD_SPLIT_MASKS + [None]:
+                check(lib.latte_debug_set_choice(b"vae_split", 0 if m is None else (1 << 24) | m))
+                got = vae.decode(z.cuda()).sample
+                torch.cuda.synchronize()
+                table["default" if m is None else f"{m:#08x}"][f"seed{seed}_{frames}x{latent}"] = rel_l2(got, want)
+            del vae
+        big = AutoencoderKL(latent_size=32, max_frames=16)
+        big.load_state_dict(vo.init_state_dict(seed=4))
+        big.to("cuda")
+        zb = torch.randn(16, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+        for m in SD_SPLIT_MASKS + [None]:
+            check(lib.latte_debug_set_choice(b"vae_split", 0 if m is None else (1 << 24) | m))
+            big.decode(zb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                big.decode(zb)
+            torch.cuda.synchronize()
+            table["default" if m is None else f"{m:#08x}"]["ms_per_16_frame_decode"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    finally:
+        check(lib.latte_debug_set_choice(b"vae_split", 0))
+    for k, row in table.items():
+        errs = [v for kk, v in row.items() if kk.startswith("seed")]
+        row["max"] = max(errs)
+        print(k, f"max {row['max']:.3e}", " ".join(f"{e:.2e}" for e in errs), row["ms_per_16_frame_decode"], "ms")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "vae_split_sweep_sd.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    assert table["default"]["max"] < TOL

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from _util import rel_l2
+from latte_amd._lib import check
 from oracle import vae_oracle as vo
 from oracle import vae_temporal_oracle as vt
 
@@ -93,3 +94,60 @@ def test_temporal_decoder_chunks_and_pipeline_path(lib):
     lat = torch.randn(1, 4, 16, 16, 16, generator=torch.Generator().manual_seed(1)).cuda() * 0.18215
     vid = latte_amd.LattePipeline.decode_latents_with_temporal_decoder(SimpleNamespace(vae=vae), lat)   # 14 + 2 frames
     assert vid.shape == (1, 16, 128, 128, 3) and vid.dtype == torch.uint8
+
+
+SPLIT_MASKS = [0x3ff, 0x0, 0x319c03, 0x31bc63, 0x318c03, 0x301c00, 0xffffff]
+
+
+@pytest.mark.gpu
+def test_temporal_decoder_split_mask_sweep(lib):
+    """Which split-operand passes the 1e-3 bar needs (round 6; csrc/vae_engine.cpp: vae_split_mask): the decode error against the fp32
+    restatement for stage masks of the spatial residual pass (bits 0..4: mid block, up blocks 0..3) and of the three-pass temporal
+    convolutions (bits 5..9), over four (weights, latent) draws, with the time of one full-size 14-frame chunk beside it.  RECORDED in
+    gpurun_out/vae_split_sweep.json (-> profiles/); asserted: the library's default mask holds the bar on every draw."""
+    import json
+    import os
+    import time
+    from _util import ROOT
+    from latte_amd import AutoencoderKLTemporalDecoder
+    from latte_amd.random_init import vae_temporal_decoder_state_dict
+    draws = [(5, 3, 16), (5, 14, 16), (5, 2, 32), (6, 4, 16), (7, 2, 32)]
+    table = {f"{m:#08x}": {} for m in SPLIT_MASKS}
+    table["default"] = {}
+    try:
+        for seed, frames, latent in draws:
+            sd = vt.init_state_dict(seed=seed)
+            z = torch.randn(frames, 4, latent, latent, generator=torch.Generator().manual_seed(frames + seed))
+            want = vt.decode(sd, z, num_frames=frames)
+            vae = AutoencoderKLTemporalDecoder(latent_size=latent, max_frames=frames)
+            vae.load_state_dict(sd)
+            vae.to("cuda")
+            for m in SPLIT_MASKS + [None]:
+                check(lib.latte_debug_set_choice(b"vae_split", 0 if m is None else (1 << 24) | m))
+                got = vae.decode(z.cuda(), num_frames=frames).sample
+                torch.cuda.synchronize()
+                table["default" if m is None else f"{m:#08x}"][f"seed{seed}_{frames}x{latent}"] = rel_l2(got, want)
+            del vae
+        big = AutoencoderKLTemporalDecoder(latent_size=64, max_frames=14)
+        big.load_state_dict(vae_temporal_decoder_state_dict(0))
+        big.to("cuda")
+        zb = torch.randn(14, 4, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        for m in SPLIT_MASKS + [None]:
+            check(lib.latte_debug_set_choice(b"vae_split", 0 if m is None else (1 << 24) | m))
+            big.decode(zb, num_frames=14)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                big.decode(zb, num_frames=14)
+            torch.cuda.synchronize()
+            table["default" if m is None else f"{m:#08x}"]["ms_per_14_frame_chunk_64x64"] = round((time.perf_counter() - t0) / 2 * 1e3, 2)
+    finally:
+        check(lib.latte_debug_set_choice(b"vae_split", 0))
+    for k, row in table.items():
+        errs = [v for kk, v in row.items() if kk.startswith("seed")]
+        row["max"] = max(errs)
+        print(k, f"max {row['max']:.3e}", " ".join(f"{e:.2e}" for e in errs), row["ms_per_14_frame_chunk_64x64"], "ms")
+    assert table["default"]["max"] < TOL
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "vae_split_sweep.json"), "w") as f:
+        json.dump(table, f, indent=1)
