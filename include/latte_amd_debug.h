@@ -18,6 +18,11 @@ extern "C" {
  * GEMM (0 attention out-projection, 1 fc2: separate kernel symbols for the profiler). */
 int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out, const float* gate, int M, int N,
                      int K, int gate_stride, int rows_per_sample, int epi, int dtype, int variant, void* stream);
+/* The training step's GELU epilogues of the rolling 12-wave GEMM (csrc/gemm_pw.hip; needs N % 192 == 0, K % 64 == 0, K >= 128):
+ * epi 13: out = u = A W^T + bias (half) and aux = gelu_tanh(u) of the rounded u (latte.py:170 through fc1, one launch);
+ * epi 14: out = (A W^T + bias) * gelu_tanh'(aux) with aux = u read only (the fc2 input-gradient GEMM of train.py's backward). */
+int latte_debug_gemm_gelu(const void* A, const void* W, const float* bias, void* out, void* aux, int M, int N, int K, int epi, int dtype,
+                          void* stream);
 /* The same product with the FP8 CORRECTION PASS of a split operand (round 6; engine option guided_split bits 2 / 3): the tile's
  * accumulators also collect  dec(A8) 2^-12 . (dec(W8) 2^-6)^T  -- A8 [Mpad, K] / W8 [N, K] bytes of OCP e4m3 codes -- on the block-
  * scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 behind the half-precision K loop (csrc/gemm_pw.hip, rolling 12-wave kernel; f16,

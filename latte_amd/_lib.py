@@ -119,6 +119,7 @@ PROTOTYPES = {
                                                  c_void]),
     "latte_debug_gemm": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void]),
+    "latte_debug_gemm_gelu": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
     "latte_debug_gemm_choice": (c_int, [c_int, c_int, c_int, c_int]),
     "latte_debug_qkv_attention_fusable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_i64]),
     "latte_debug_gemm_tn_plan": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int)]),

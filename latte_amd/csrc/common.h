@@ -79,6 +79,9 @@ enum GemmEpi : int {
   EPI_ABLATE_DMA_B = 11,    // only the B operand is DMA'd in the loop
   EPI_ABLATE_TRACE = 12,    // full loop, no stores; workgroup 0 writes per-wave phase times (s_memtime ticks) to `out`:
                             // int64 [8 waves][8] = {L, barrier-1 wait, C issue, vmcnt wait, barrier-2 wait, DMA issue, total, K tiles}
+  // training step (round 6; rolling 12-wave kernel only, gemm_pw.hip -- launch_gemm_pw): the GELU passes of the MLP inside the GEMMs
+  EPI_BIAS_GELU_DUAL_H16 = 13,  // out(half) = u = acc + bias AND aux(half) = gelu_tanh(u) (of the ROUNDED u: what a separate GELU pass reads)
+  EPI_DGELU_H16 = 14,           // out(half) = (acc + bias) * gelu_tanh'(aux(half)[m,n])     (the fc2 input-gradient GEMM: du = dh gelu'(u))
 };
 struct GemmArgs {
   const half_t* A;    // [Mpad, K]   (rows >= M may hold anything finite or not; never read back)
@@ -102,6 +105,7 @@ struct GemmArgs {
   // pair (mfma_util.h: split2) at a quarter of the operand bytes and half the MFMA time of the [hi | lo] . [W | W] form.
   const uint8_t* A8;  // [Mpad, K] bytes: e4m3(lo * 2^LO8_A_SHIFT)
   const uint8_t* W8;  // [N, K]    bytes: e4m3(W * 2^LO8_W_SHIFT)
+  half_t* aux;        // EPI_BIAS_GELU_DUAL_H16: second output [Mpad, N]; EPI_DGELU_H16: the pre-activation u [Mpad, N] (read only)
 };
 // constant block scales of the correction pass: A8 holds the rounding remainder of a half operand (|lo| <= 2^-11 |x|), W8 weights of
 // |w| < 7; the MFMA multiplies the products back by 2^-(LO8_A_SHIFT + LO8_W_SHIFT) (E8M0 scale bytes 127 - shift)

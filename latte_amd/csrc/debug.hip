@@ -152,6 +152,15 @@ int latte_debug_gemm(const void* A, const void* W, const float* bias, void* out,
   return launch_gemm(g, epi, dtype, variant, (hipStream_t)stream);
 }
 
+int latte_debug_gemm_gelu(const void* A, const void* W, const float* bias, void* out, void* aux, int M, int N, int K, int epi, int dtype,
+                          void* stream) {
+  if (epi != EPI_BIAS_GELU_DUAL_H16 && epi != EPI_DGELU_H16) return fail(LATTE_ERR_INVALID, "gemm_gelu: epi 13 (dual GELU) or 14 (dGELU)");
+  GemmArgs g{};
+  g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = out; g.aux = (half_t*)aux;
+  g.M = M; g.N = N; g.K = K; g.rows_per_sample = M;
+  return launch_gemm_pw(g, epi, dtype, 1, (hipStream_t)stream);
+}
+
 int latte_debug_gemm_lo8(const void* A, const void* W, const void* A8, const void* W8, const float* bias, void* out, const float* gate,
                          int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype, void* stream) {
   if (!A8 || !W8) return fail(LATTE_ERR_INVALID, "gemm_lo8: null fp8 operand");

@@ -31,6 +31,20 @@
 namespace latte {
 namespace {
 
+template <int DT>
+__device__ __forceinline__ void unpack2pw(unsigned int u, float& a, float& b) {   // two halves of a word -> fp32
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    a = __builtin_bit_cast(float, u << 16);
+    b = __builtin_bit_cast(float, u & 0xffff0000u);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    const f16x2_ h = __builtin_bit_cast(f16x2_, u);
+    a = (float)h[0];
+    b = (float)h[1];
+  }
+}
+
+
 typedef __attribute__((address_space(3))) void lds_void_pw;
 __device__ __forceinline__ void pw_bload_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_pw*)lds_wave_base, 16, voff, soff, 0, 0);
@@ -558,10 +572,12 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
         for (int j = 0; j < FN; ++j) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       return;
     }
-    if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16) {
+    if constexpr (EPI == EPI_BIAS_H16 || EPI == EPI_BIAS_GELU_H16 || EPI == EPI_BIAS_GELU_DUAL_H16 || EPI == EPI_DGELU_H16) {
       // Half-precision outputs: a fragment row (16 rows x 48 columns = 96 B per row) goes through a wave-private LDS patch
       // (pitch 112 B, behind the operand rings) so that the global stores are 16 B per lane on contiguous 96-byte row
       // segments: 1.5 store instructions per fragment row instead of 3 with 8 B per lane on 32-byte pieces.
+      // Training forms (round 6): EPI_BIAS_GELU_DUAL_H16 stores u and, through the same patch a second time, gelu(u) to g.aux;
+      // EPI_DGELU_H16 multiplies by gelu'(u) with u read from g.aux (8 B per lane: the fragment's own elements).
       char* patch = smem + B_BASE + 2 * B_BYTES + wave * PATCH_BYTES;
       const int ncol0 = tn_ * BN + wn * WTN;
       const int gq = le >> 4;
@@ -572,29 +588,64 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       const int r1 = (le + 64) / 6, p1 = (le + 64) - r1 * 6; // piece le + 64 (lanes 0-31)
       half_t* const outp = (half_t*)g.out;
       const int mrow0 = tm_ * BM + grp * 128;
+      auto gelu = [](float x) {
+        const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+        return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
+      };
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        u32x2 side[FN];   // DUAL: gelu(u) of this fragment row, DGELU: its u
+        if constexpr (EPI == EPI_DGELU_H16) {
+          const int mu = min(mrow0 + i * 16 + fr, g.M - 1);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) side[j] = *(const u32x2*)(g.aux + (size_t)mu * g.N + ncol0 + j * 16 + gq * 4);
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
           if constexpr (EPI == EPI_BIAS_GELU_H16) {
-            auto gelu = [](float x) {
-              const float p = __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
-              return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * x));
-            };
             v0 = gelu(v0); v1 = gelu(v1); v2 = gelu(v2); v3 = gelu(v3);
+          }
+          if constexpr (EPI == EPI_DGELU_H16) {   // train.hip: gelu_kernel<BWD>, the same arithmetic on the unrounded product
+            float x[4];
+            unpack2pw<DT>(side[j][0], x[0], x[1]);
+            unpack2pw<DT>(side[j][1], x[2], x[3]);
+            auto dgelu = [](float xx) {
+              const float p = __builtin_fmaf(xx * xx, -0.10294324f, -2.3022082f);
+              const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * xx));
+              const float du = 0.7978845608f * (1.0f + 0.134145f * xx * xx);
+              return sg + xx * sg * (1.0f - sg) * 2.0f * du;
+            };
+            v0 *= dgelu(x[0]); v1 *= dgelu(x[1]); v2 *= dgelu(x[2]); v3 *= dgelu(x[3]);
           }
           const u32x2 pk = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
           *(u32x2*)(patch + fr * 112 + j * 32 + gq * 8) = pk;
+          if constexpr (EPI == EPI_BIAS_GELU_DUAL_H16) {   // the GELU of the ROUNDED pre-activation (what gelu_kernel<FWD> computes from u)
+            float x[4];
+            unpack2pw<DT>(pk[0], x[0], x[1]);
+            unpack2pw<DT>(pk[1], x[2], x[3]);
+            side[j] = (u32x2){pack2<DT>(gelu(x[0]), gelu(x[1])), pack2<DT>(gelu(x[2]), gelu(x[3]))};
+          }
           acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
-        const int m0_ = mrow0 + i * 16 + r0;
-        if (m0_ < g.M) *(u32x4*)(outp + (size_t)m0_ * g.N + ncol0 + p0 * 8) = w0;
-        if (le < 32) {
-          const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1 * 16);
-          const int m1_ = mrow0 + i * 16 + r1;
-          if (m1_ < g.M) *(u32x4*)(outp + (size_t)m1_ * g.N + ncol0 + p1 * 8) = w1;
+        const int m0_ = mrow0 + i * 16 + r0, m1_ = mrow0 + i * 16 + r1;
+        {
+          const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
+          if (m0_ < g.M) *(u32x4*)(outp + (size_t)m0_ * g.N + ncol0 + p0 * 8) = w0;
+          if (le < 32) {
+            const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1 * 16);
+            if (m1_ < g.M) *(u32x4*)(outp + (size_t)m1_ * g.N + ncol0 + p1 * 8) = w1;
+          }
+        }
+        if constexpr (EPI == EPI_BIAS_GELU_DUAL_H16) {   // second trip through the patch (LDS operations of a wave execute in order)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) *(u32x2*)(patch + fr * 112 + j * 32 + gq * 8) = side[j];
+          const u32x4 w0 = *(const u32x4*)(patch + r0 * 112 + p0 * 16);
+          if (m0_ < g.M) *(u32x4*)(g.aux + (size_t)m0_ * g.N + ncol0 + p0 * 8) = w0;
+          if (le < 32) {
+            const u32x4 w1 = *(const u32x4*)(patch + r1 * 112 + p1 * 16);
+            if (m1_ < g.M) *(u32x4*)(g.aux + (size_t)m1_ * g.N + ncol0 + p1 * 8) = w1;
+          }
         }
       }
       return;
@@ -1240,6 +1291,20 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
   else if (epi == EPI_BIAS_F32) LATTE_PW_CASE(EPI_BIAS_F32, 0)
   else if (epi == EPI_BIAS_H16) LATTE_PW_CASE(EPI_BIAS_H16, 0)
   else if (epi == EPI_BIAS_GELU_H16) LATTE_PW_CASE(EPI_BIAS_GELU_H16, 0)
+  else if (epi == EPI_BIAS_GELU_DUAL_H16 || epi == EPI_DGELU_H16) {   // training epilogues: rolling kernel only
+    if (!roll || !a.aux) return fail(LATTE_ERR_INVALID, "gemm (producer-wave kernel): the GELU training epilogues need the rolling kernel and GemmArgs::aux");
+    if (epi == EPI_BIAS_GELU_DUAL_H16) {
+      auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_DUAL_H16, DT, 0>;
+      static std::atomic<uint64_t> attr_done{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+      hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+    } else {
+      auto kern = gemm_pwr_kernel<EPI_DGELU_H16, DT, 0>;
+      static std::atomic<uint64_t> attr_done{0};
+      if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+      hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+    }
+  }
 #ifdef LATTE_GEMM_ABLATE
   else if (epi == EPI_ABLATE_TRACE) LATTE_PW_CASE(EPI_ABLATE_TRACE, 0)
 #endif

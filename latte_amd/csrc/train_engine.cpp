@@ -50,6 +50,7 @@ struct latte_trainer {
   // training-step counter of a continued run says; torch.optim.AdamW keeps its own count too).
   float loss_scale = 1.0f;       // initial / static value (host copy; the live value is scaler[0])
   int dynamic_scale = 0;
+  int fuse_gelu = 1;        // the MLP's GELU passes inside the fc1 forward / fc2 input-gradient GEMMs (round 6; "fuse_gelu" option, A/B tests)
   float growth_interval = 2000.0f;
   float* scaler = nullptr;
   std::vector<ParamInfo> params;
@@ -106,6 +107,19 @@ int gemm_half(latte_trainer* e, const half_t* A, const half_t* W, const float* b
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M; g.gate_stride = 0;
   return launch_gemm(g, EPI_BIAS_H16, e->dt, 0, st);
+}
+
+// The rolling 12-wave kernel's training epilogues (gemm_pw.hip: EPI_BIAS_GELU_DUAL_H16 / EPI_DGELU_H16) take the shape
+bool gelu_fusable(const latte_trainer* e, int M, int N, int K) {
+  return e->fuse_gelu && N % 192 == 0 && K % 64 == 0 && K >= 128 && (uint64_t)((M + 255) / 256 * 256) * K * 2 < (1ull << 32) &&
+         (uint64_t)N * K * 2 < (1ull << 32);
+}
+// out = A W^T + bias with the GELU pass fused: epi EPI_BIAS_GELU_DUAL_H16 (out = u, aux = gelu(u)) or EPI_DGELU_H16 (out = (A W^T) gelu'(aux))
+int gemm_gelu(latte_trainer* e, int epi, const half_t* A, const half_t* W, const float* bias, half_t* out, half_t* aux, int M, int N, int K,
+              hipStream_t st) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.aux = aux; g.M = M; g.N = N; g.K = K; g.rows_per_sample = M; g.gate_stride = 0;
+  return launch_gemm_pw(g, epi, e->dt, 1, st);
 }
 
 // dW[N, K] = dY[M, N]^T X[M, K] on the transposed-operand GEMM (gemm_tn.hip: no transposed copies), the contraction split so
@@ -366,8 +380,12 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
     if ((rc = gemm_half(e, b.att, b.proj_w, P_(e, p + "attn.proj.bias"), b.y1, M, D, D, st))) return rc;
     if ((rc = launch_gated_add(x0, b.y1, mb + 2 * D, nmod, x1, M, D, rps, dt, st))) return rc;
     if ((rc = launch_ln_modulate(x1, x1, b.xn2, mb + 3 * D, mb + 4 * D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
-    if ((rc = gemm_half(e, b.xn2, b.fc1_w, P_(e, p + "mlp.fc1.bias"), b.u, M, Hm, D, st))) return rc;
-    if ((rc = launch_gelu_fwd(b.u, b.h, (size_t)M * Hm, dt, st))) return rc;
+    if (gelu_fusable(e, M, Hm, D)) {   // u and h = gelu(u) out of one launch (bit-identical to the separate pass)
+      if ((rc = gemm_gelu(e, EPI_BIAS_GELU_DUAL_H16, b.xn2, b.fc1_w, P_(e, p + "mlp.fc1.bias"), b.u, b.h, M, Hm, D, st))) return rc;
+    } else {
+      if ((rc = gemm_half(e, b.xn2, b.fc1_w, P_(e, p + "mlp.fc1.bias"), b.u, M, Hm, D, st))) return rc;
+      if ((rc = launch_gelu_fwd(b.u, b.h, (size_t)M * Hm, dt, st))) return rc;
+    }
     if ((rc = gemm_half(e, b.h, b.fc2_w, P_(e, p + "mlp.fc2.bias"), b.y2, M, D, Hm, st))) return rc;
     if ((rc = launch_gated_add(x1, b.y2, mb + 5 * D, nmod, x2, M, D, rps, dt, st))) return rc;
   }
@@ -459,6 +477,10 @@ int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value)
     e->growth_interval = (float)value;
     return upload_scaler(e, 2);
   }
+  if (std::string(name) == "fuse_gelu") {   // 0: separate GELU passes (rounds 2 - 5), 1: inside the GEMM epilogues (default)
+    e->fuse_gelu = value != 0.0 ? 1 : 0;
+    return LATTE_OK;
+  }
   return fail(LATTE_ERR_INVALID, std::string("trainer_set_option: unknown option '") + name + "'");
 }
 
@@ -502,8 +524,12 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
     if ((rc = launch_gate_bwd(e->dx, b.y2, mb + 5 * D, nmod, e->dyD, e->part_rows, dm + 5 * D, nmod, M, D, rps, dt, st))) return rc;
     if ((rc = launch_colsum_half(e->dyD, M, D, e->part_cols, G_(e, p + "mlp.fc2.bias"), 0, dt, st))) return rc;
     if ((rc = wgrad(e, e->dyD, b.h, M, D, Hm, G_(e, p + "mlp.fc2.weight"), st))) return rc;
-    if ((rc = gemm_half(e, e->dyD, b.fc2_wt, e->zeros, e->dhH, M, Hm, D, st))) return rc;
-    if ((rc = launch_gelu_bwd(b.u, e->dhH, e->dhH, (size_t)M * Hm, dt, st))) return rc;
+    if (gelu_fusable(e, M, Hm, D)) {   // du = (dy W2) gelu'(u) in the GEMM's epilogue (the product is not rounded to half in between)
+      if ((rc = gemm_gelu(e, EPI_DGELU_H16, e->dyD, b.fc2_wt, e->zeros, e->dhH, b.u, M, Hm, D, st))) return rc;
+    } else {
+      if ((rc = gemm_half(e, e->dyD, b.fc2_wt, e->zeros, e->dhH, M, Hm, D, st))) return rc;
+      if ((rc = launch_gelu_bwd(b.u, e->dhH, e->dhH, (size_t)M * Hm, dt, st))) return rc;
+    }
     if ((rc = launch_colsum_half(e->dhH, M, Hm, e->part_cols, G_(e, p + "mlp.fc1.bias"), 0, dt, st))) return rc;
     if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st))) return rc;
     if ((rc = gemm_half(e, e->dhH, b.fc1_wt, e->zeros, e->dxnH, M, D, Hm, st))) return rc;

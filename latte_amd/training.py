@@ -126,6 +126,11 @@ class LatteTrainer:
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
 
+    def set_option(self, name, value):
+        """Engine options of the trainer (latte_trainer_set_option): "loss_scale", "dynamic_loss_scale", "loss_scale_growth_interval",
+        "fuse_gelu" (0: separate GELU passes, 1: inside the fc1 / fc2-gradient GEMMs -- the default)."""
+        check(load_library().latte_trainer_set_option(self._h, name.encode(), float(value)))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

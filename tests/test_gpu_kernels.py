@@ -124,6 +124,43 @@ def test_gemm_producer_wave_kernel(lib, dev, dt, shape):
     assert all(torch.equal(outs[v], outs[8]) for v in (10, 1010, 11, 1011))
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(4096, 3072, 768), (20480, 1536, 384), (33000, 384, 1536), (300, 192, 128)])
+def test_gemm_gelu_training_epilogues(lib, dev, dt, shape):
+    """Round 6: the MLP's GELU passes inside the rolling 12-wave GEMM (gemm_pw.hip; train_engine.cpp uses them for fc1's forward and fc2's
+    input gradient).  epi 13: out = the plain launch's half output bit for bit, aux = gelu_tanh of THAT half (the separate pass's result up
+    to the last half bit of the fast exp2 / rcp forms on both sides: the same expressions -> equal); epi 14: (A W^T) * gelu'(u) against
+    fp32 torch on the same half operands.  Partial last tile rows, > 256 and < 256 tiles."""
+    M, N, K = shape
+    g = torch.Generator("cpu").manual_seed(M + N)
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, K, generator=g).to(dev).to(TD[dt])
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(TD[dt])
+    bias = torch.randn(N, generator=g).to(dev)
+    plain = torch.zeros(Mp, N, device=dev, dtype=TD[dt])
+    check(lib.latte_debug_gemm(ptr(A), ptr(W), ptr(bias), ptr(plain), None, M, N, K, 0, M, 0, dt, 11, stream_ptr()))
+    u = torch.full((Mp, N), 7.0, device=dev, dtype=TD[dt])
+    h = torch.full((Mp, N), 7.0, device=dev, dtype=TD[dt])
+    check(lib.latte_debug_gemm_gelu(ptr(A), ptr(W), ptr(bias), ptr(u), ptr(h), M, N, K, 13, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(u[:M], plain[:M])
+    assert bool((u[M:] == 7.0).all()) and bool((h[M:] == 7.0).all())          # rows beyond M are never written
+    want_h = torch.nn.functional.gelu(u[:M].float(), approximate="tanh")
+    assert float((h[:M].float() - want_h).norm() / want_h.norm()) < (3e-3 if dt == 0 else 4e-4)
+    # the in-engine separate pass on the same u: identical halves
+    sep = torch.nn.functional.gelu(u[:M].float(), approximate="tanh").to(TD[dt])
+    assert float((h[:M].float() - sep.float()).abs().max()) <= float(sep.float().abs().max()) * (2 ** -7 if dt == 0 else 2 ** -10)
+    # epi 14: du = (A W^T + bias) * gelu'(u)
+    du = torch.full((Mp, N), 7.0, device=dev, dtype=TD[dt])
+    check(lib.latte_debug_gemm_gelu(ptr(A), ptr(W), ptr(bias), ptr(du), ptr(u), M, N, K, 14, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    uf = u[:M].float().requires_grad_(True)
+    torch.nn.functional.gelu(uf, approximate="tanh").sum().backward()
+    want = (A.float()[:M] @ W.float().t() + bias) * uf.grad
+    assert float((du[:M].float() - want).norm() / want.norm()) < (4e-3 if dt == 0 else 5e-4)
+    assert bool((du[M:] == 7.0).all())
+
+
 CASES = [(1, 4, 16, 2, 64), (2, 16, 256, 16, 72), (1, 4, 64, 6, 64), (1, 3, 100, 2, 72), (1, 16, 1024, 6, 64),
          (2, 4, 4, 2, 64), (1, 2, 200, 2, 72), (1, 3, 144, 3, 64), (2, 2, 256, 4, 64), (1, 2, 129, 1, 72),
          # L > 256: the 256-key-block kernel with the online softmax (whole blocks, ragged last block, partial query block)

@@ -15,6 +15,10 @@ with torch.no_grad():
         if p.requires_grad and float(p.abs().max()) == 0.0:
             p.normal_(0, 0.02)
 tr = latte_amd.LatteTrainer(model, latte_amd.create_diffusion(""), max_batch=B, compute_dtype=dtype)
+for kv in os.environ.get("LATTE_TRAIN_OPTIONS", "").split(","):   # e.g. LATTE_TRAIN_OPTIONS=fuse_gelu=0
+    if kv:
+        k, v = kv.split("=")
+        tr.set_option(k, float(v))
 g = torch.Generator("cpu").manual_seed(0)
 x = torch.randn(B, 16, 4, 32, 32, generator=g).cuda()
 for _ in range(2):
