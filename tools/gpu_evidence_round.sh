@@ -8,7 +8,7 @@ TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5 > $O/${TAG}_pytest_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -5 > $O/${TAG}_pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
 timeout 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 timeout 900 bash tools/pmc_round.sh $TAG > $O/${TAG}_pmc_round.log 2>&1

@@ -26,8 +26,9 @@ def classify(name):
         return "gemm_fc1"
     if "gemm_pps_kernel<192,2," in n:
         return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
-    if "gemm_pwr_kernel<2," in n or "gemm_pw_kernel<2," in n:   # 12-wave kernels: <EPI, DT, TAG>
-        return "gemm_fc2" if n.split(">(")[0].endswith(",1") else "gemm_proj"
+    if "gemm_pwr_kernel<2," in n or "gemm_pw_kernel<2," in n:   # 12-wave kernels: <EPI, DT, TAG[, LO, ABL]> (round 6 added LO / ABL)
+        args = n.split("_kernel<")[1].split(">(")[0].split(",")
+        return "gemm_fc2" if args[2] == "1" else "gemm_proj"
     if "qkv_attn_kernel<" in n:   # fused QKV projection + attention: <HD, DT, MODE, FLAGS>
         return "qkv_attn_temporal" if n.split("qkv_attn_kernel<")[1].split(",")[2] == "1" else "qkv_attn_spatial"
     if "attn_full_kernel" in n:
