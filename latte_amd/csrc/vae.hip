@@ -684,12 +684,23 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
                                                           float eps) {
   __shared__ double red[256 * 2];
   const int n = blockIdx.x, gi = threadIdx.x & 31, part = threadIdx.x >> 5;
-  double s = 0.0, q = 0.0;
-  for (int k = part; k < slabs; k += 8) {
-    const float* p = partial + (((size_t)n * slabs + k) * 32 + gi) * 2;
-    s += p[0];
-    q += p[1];
+  // (round 6: four independent chains per thread -- the temporal decoder's GroupNorm is ONE sample of up to 3584 slabs, 448 dependent
+  //  load + fp64 add steps per thread were 25 us per launch, 116 launches per video; the order stays fixed for a given slab count)
+  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+  int k = part;
+  for (; k + 24 < slabs; k += 32) {
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const float2*)(partial + (((size_t)n * slabs + k + 8 * u) * 32 + gi) * 2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s4[u] += v[u].x; q4[u] += v[u].y; }
   }
+  for (int u = 0; k < slabs; k += 8, ++u) {
+    const float* p = partial + (((size_t)n * slabs + k) * 32 + gi) * 2;
+    s4[u & 3] += p[0];
+    q4[u & 3] += p[1];
+  }
+  double s = (s4[0] + s4[1]) + (s4[2] + s4[3]), q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   red[threadIdx.x * 2] = s;
   red[threadIdx.x * 2 + 1] = q;
   __syncthreads();
