@@ -31,6 +31,17 @@ int latte_debug_gemm_lo8(const void* A, const void* W, const void* A8, const voi
                          int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype, void* stream);
 /* W8 of an f16 weight: out8[i] = e4m3(clamp(w[i] * 2^6, +-448)) (n % 4 == 0). */
 int latte_debug_pack_w8(const void* w, void* out8, int64_t n, int dtype, void* stream);
+/* FP4 form of the correction pass (round 6): OCP e2m1 codes, two per byte (element k in bits 4 (k & 1) of byte k >> 1), rows of
+ * ((K + 255) / 256) * 128 bytes (zero padded) with ONE E8M0 scale byte per row (value = code * 2^(scale - 127)); the block-scaled MFMA runs
+ * them at twice the fp8 rate.  latte_debug_pack_w4: [N, K] f16 weights -> codes + row scales; latte_debug_ln_modulate_split4: LayerNorm-
+ * modulate with y [M, D] = the nearest f16 (the plain call's bits) + y4 / y4s = codes and row scales of the remainder; latte_debug_gemm_lo4:
+ * the GEMM of latte_debug_gemm (epi 1 or 2) with  (A4 2^A4s) . (W4 2^W4s)^T  collected behind its f16 K loop. */
+int latte_debug_pack_w4(const void* w, void* out4, void* out_scale, int N, int K, int dtype, void* stream);
+int latte_debug_ln_modulate_split4(const float* x, void* y, void* y4, void* y4s, const float* shift, const float* scale, int mod_stride, int M,
+                                   int D, int rows_per_sample, int dtype, void* stream);
+int latte_debug_gemm_lo4(const void* A, const void* W, const void* A4, const void* A4s, const void* W4, const void* W4s, const float* bias,
+                         void* out, const float* gate, int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype,
+                         void* stream);
 /* latte_debug_ln_modulate with the split output of the fp8 form: y [M, D] = the nearest f16 (bit for bit the plain kernel's output),
  * y8 [M, D] bytes = e4m3(clamp((value - y) * 2^12, +-448)). */
 int latte_debug_ln_modulate_split8(const float* x, void* y, void* y8, const float* shift, const float* scale, int mod_stride, int M, int D,

@@ -113,6 +113,10 @@ PROTOTYPES = {
     "latte_debug_gemm_lo8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void]),
     "latte_debug_attention_split8": (c_int, [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_void]),
+    "latte_debug_pack_w4": (c_int, [c_void, c_void, c_void, c_int, c_int, c_int, c_void]),
+    "latte_debug_ln_modulate_split4": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
+    "latte_debug_gemm_lo4": (c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_void]),
     "latte_debug_pack_w8": (c_int, [c_void, c_void, c_i64, c_int, c_void]),
     "latte_debug_ln_modulate_split8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
     "latte_debug_qkv_attention_split8": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

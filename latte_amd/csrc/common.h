@@ -105,12 +105,22 @@ struct GemmArgs {
   // pair (mfma_util.h: split2) at a quarter of the operand bytes and half the MFMA time of the [hi | lo] . [W | W] form.
   const uint8_t* A8;  // [Mpad, K] bytes: e4m3(lo * 2^LO8_A_SHIFT)
   const uint8_t* W8;  // [N, K]    bytes: e4m3(W * 2^LO8_W_SHIFT)
+  // FP4 correction pass (round 6, second form; rolling kernel, LO = 2): A4 / W4 hold OCP e2m1 codes, two per byte (element k in bits
+  // 4 (k & 1) of byte k >> 1), rows of lo4_pitch(K) bytes (K rounded up to 256, zero padded), with ONE E8M0 scale byte per ROW
+  // (A4s [Mpad], W4s [N]): value = code * 2^(scale - 127).  v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 runs at twice the
+  // fp8 rate and a K tile of 128 row bytes is K = 256 (mfma_util.h: quant4; tools/mx_probe.hip layout H0).
+  const uint8_t* A4;
+  const uint8_t* W4;
+  const uint8_t* A4s;
+  const uint8_t* W4s;
   half_t* aux;        // EPI_BIAS_GELU_DUAL_H16: second output [Mpad, N]; EPI_DGELU_H16: the pre-activation u [Mpad, N] (read only)
 };
 // constant block scales of the correction pass: A8 holds the rounding remainder of a half operand (|lo| <= 2^-11 |x|), W8 weights of
 // |w| < 7; the MFMA multiplies the products back by 2^-(LO8_A_SHIFT + LO8_W_SHIFT) (E8M0 scale bytes 127 - shift)
 constexpr int LO8_A_SHIFT = 12, LO8_W_SHIFT = 6;
-bool gemm_lo8_ok(int M, int N, int K);   // the shape takes the correction pass (whole 192-wide tile columns, K % 128 == 0, 32-bit offsets)
+inline int lo4_pitch(int K) { return (K + 255) / 256 * 128; }   // bytes per row of an fp4 correction operand
+bool gemm_lo8_ok(int M, int N, int K);
+bool gemm_lo4_ok(int M, int N, int K);   // the shape takes the fp4 correction pass (whole 192-wide tile columns, K % 64 == 0, 32-bit offsets)   // the shape takes the correction pass (whole 192-wide tile columns, K % 128 == 0, 32-bit offsets)
 // variant: 0 = pick for the shape; simple double-buffered kernel: 1 = 128x128 tile, 2 = 256x128, 3 = 256x256;
 // ping-pong kernel: 4 = 256x128, 5 = 256x192, 6 = 256x256; persistent ping-pong kernel: 7 = 256x128,
 // 8 = 256x192, 9 = 256x256   (N % tileN == 0 required)
@@ -174,6 +184,9 @@ int launch_qkv_attention(const QkvAttnArgs& a, int dtype, hipStream_t st);
 // ---- pointwise / small kernels ------------------------------------------------------------------
 // y(half)[m, :] = LN(x[m, :]) * (1 + scale[s(m), :]) + shift[s(m), :], eps 1e-6, no affine.
 // If temp_embed != nullptr: x[m,:] += temp_embed[frame(m), :] first and is written back (latte.py:357-358).
+// LayerNorm-modulate with the f16 + FP4-remainder output (y4: [M, lo4_pitch(D)] e2m1 codes, y4s: [M] E8M0 row scales; GemmArgs::A4 / A4s)
+int launch_ln_modulate_split4(const float* x_in, half_t* y, unsigned char* y4, unsigned char* y4s, const float* shift, const float* scale,
+                              int mod_stride, int M, int D, int rows_per_sample, int dtype, hipStream_t st);
 int launch_ln_modulate(const float* x_in, float* x_rw, half_t* y, const float* shift, const float* scale,
                        int mod_stride, int M, int D, int rows_per_sample, const float* temp_embed, int T,
                        int F, int dtype, hipStream_t st, int split = 0,   // split 1: y is [M, 2 D] = [hi | lo] (mfma_util.h: split2)
@@ -223,6 +236,8 @@ int launch_t2v_guided_ddim(float* x, const float* model_out, int b, int C, int C
 int launch_mask_bias(const float* mask, float* bias, size_t n, hipStream_t st);   // bias = (1 - mask) * -10000
 int launch_cfg_combine(float* out, int half_batch, int F, int Cout, int HW, float cfg_scale, hipStream_t st);
 int launch_convert_f32_to_h16(const float* in, half_t* out, int64_t n, int dtype, hipStream_t st);
+// W4 image of a [N, K] half weight: e2m1 codes [N, lo4_pitch(K)] + one E8M0 scale byte per row (GemmArgs::W4 / W4s)
+int launch_pack_w4(const half_t* in, unsigned char* out4, unsigned char* out_scale, int N, int K, int dtype, hipStream_t st);
 int launch_convert_f32_to_h16_split(const float* in, half_t* out, half_t* out_lo, int64_t n, int dtype, hipStream_t st);   // + the f16 rounding residual
 int launch_convert_h16_to_f32(const half_t* in, float* out, int64_t n, int dtype, hipStream_t st);
 int launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t st);

@@ -171,6 +171,27 @@ int latte_debug_gemm_lo8(const void* A, const void* W, const void* A8, const voi
   return launch_gemm(g, epi, dtype, 0, (hipStream_t)stream);
 }
 
+int latte_debug_gemm_lo4(const void* A, const void* W, const void* A4, const void* A4s, const void* W4, const void* W4s, const float* bias,
+                         void* out, const float* gate, int M, int N, int K, int gate_stride, int rows_per_sample, int epi, int dtype,
+                         void* stream) {
+  if (!A4 || !A4s || !W4 || !W4s) return fail(LATTE_ERR_INVALID, "gemm_lo4: null fp4 operand");
+  GemmArgs g{};
+  g.A = (const half_t*)A; g.W = (const half_t*)W; g.bias = bias; g.out = out; g.gate = gate;
+  g.M = M; g.N = N; g.K = K; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample;
+  g.A4 = (const uint8_t*)A4; g.A4s = (const uint8_t*)A4s; g.W4 = (const uint8_t*)W4; g.W4s = (const uint8_t*)W4s;
+  return launch_gemm(g, epi, dtype, 0, (hipStream_t)stream);
+}
+
+int latte_debug_pack_w4(const void* w, void* out4, void* out_scale, int N, int K, int dtype, void* stream) {
+  return launch_pack_w4((const half_t*)w, (unsigned char*)out4, (unsigned char*)out_scale, N, K, dtype, (hipStream_t)stream);
+}
+
+int latte_debug_ln_modulate_split4(const float* x, void* y, void* y4, void* y4s, const float* shift, const float* scale, int mod_stride, int M,
+                                   int D, int rows_per_sample, int dtype, void* stream) {
+  return launch_ln_modulate_split4(x, (half_t*)y, (unsigned char*)y4, (unsigned char*)y4s, shift, scale, mod_stride, M, D, rows_per_sample,
+                                   dtype, (hipStream_t)stream);
+}
+
 int latte_debug_pack_w8(const void* w, void* out8, int64_t n, int dtype, void* stream) {
   return launch_pack_w8((const half_t*)w, (unsigned char*)out8, n, dtype, (hipStream_t)stream);
 }

@@ -1421,6 +1421,10 @@ int launch_gemm(const GemmArgs& a_in, int epi, int dtype, int variant, hipStream
     }
   }
 #endif
+  if (a.A4) {   // fp4 correction pass (GemmArgs::A4 / W4 + row scales): rolling 12-wave kernel, any K % 64 == 0 (rows are padded to K % 256 == 0)
+    if (!gemm_lo4_ok(a.M, a.N, a.K)) return fail(LATTE_ERR_INVALID, "gemm: the fp4 correction pass needs N % 192 == 0, K % 64 == 0, K >= 128");
+    return launch_gemm_pw(a, epi, dtype, 1, st);
+  }
   if (a.A8) {   // correction pass of a split operand (GemmArgs::A8 / W8): the rolling 12-wave kernel is the one that has it
     if (!gemm_lo8_ok(a.M, a.N, a.K)) return fail(LATTE_ERR_INVALID, "gemm: the fp8 correction pass needs N % 192 == 0 and K % 128 == 0");
     return launch_gemm_pw(a, epi, dtype, 1, st);

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(768) gemm_pw_kernel(GemmArgs g) {
 // the production kernel one at a time, top down:  1 = no epilogue (accumulators dropped at a tile boundary), 2 = no tile boundaries (the
 // K walk never drains / refills), 4 = operands from an L2-resident pool (tile 0, K tiles 0-3) instead of their real addresses, 8 = no
 // vmcnt / lgkmcnt waits and no barrier inside the K walk, 16 = fragments read from the LDS once and reused, 32 = no operand DMA.
-template <int EPI, int DT, int TAG, bool LO = false, int ABL = 0>
+template <int EPI, int DT, int TAG, int LO = 0, int ABL = 0>
 __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   constexpr int BM = 256, BN = 192, FN = 3, WTN = 48;
   constexpr bool A_NOEPI = (ABL & 1) != 0, A_ONE = (ABL & 2) != 0, A_HOT = (ABL & 4) != 0, A_NOWAIT = (ABL & 8) != 0,
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     tn = in_group / gsz;
   };
   const int nk = K / 64;
-  const int nk8 = LO ? K / 128 : 0;               // correction K tiles behind the nk half-precision ones
+  const int nk8 = LO == 2 ? (K + 255) / 256 : LO ? K / 128 : 0;   // correction K tiles behind the nk half-precision ones (fp4: K = 256 per 128 row bytes)
   const int nkt = nk + nk8;                       // K tiles of the walk per output tile
   const int ntile = (cnt - slot + per - 1) / per;
   constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
@@ -470,11 +470,11 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     unsigned step32 = 32u * row_bytes;
     asm volatile("" : "+s"(step32));
     // correction operands: rows of K bytes
-    const unsigned row_bytes8 = (unsigned)K;
-    const __amdgpu_buffer_rsrc_t rsA8 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? (const void*)g.A8 : (const void*)g.A), 0, (unsigned)tiles_m * BM * row_bytes8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB8 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(LO ? (const void*)g.W8 : (const void*)g.W), 0, (unsigned)g.N * row_bytes8, 0x00020000);
+    const unsigned row_bytes8 = LO == 2 ? (unsigned)((K + 255) / 256 * 128) : (unsigned)K;   // fp4: two codes per byte, rows padded to K % 256 == 0
+    const __amdgpu_buffer_rsrc_t rsA8 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(LO == 2 ? (const void*)g.A4 : LO ? (const void*)g.A8 : (const void*)g.A), 0, (unsigned)tiles_m * BM * row_bytes8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB8 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(LO == 2 ? (const void*)g.W4 : LO ? (const void*)g.W8 : (const void*)g.W), 0, (unsigned)g.N * row_bytes8, 0x00020000);
     const unsigned voff8 = (unsigned)lrow * row_bytes8 + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
     unsigned step32_8 = 32u * row_bytes8;
     asm volatile("" : "+s"(step32_8));
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
   //   rows 6-7, with LOOK the pairs of stage u + 1 roll in behind the MFMAs that free their registers (A rows 0-3, then B)
   u32x8 b8[FN], a8[4];
   unsigned sc_w = 0, sc_a = 0;
-  if constexpr (LO) {
+  if constexpr (LO == 1) {
     sc_w = 127u - LO8_W_SHIFT;
     sc_a = 127u - LO8_A_SHIFT;
     asm volatile("" : "+v"(sc_w), "+v"(sc_a));
@@ -856,6 +856,87 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     if constexpr (LOOK) a8[3] = pair_a(sAn, 3);
   };
 
+  // ---- FP4 correction K tiles (LO == 2, round 6): a K tile is 128 row bytes = K 256; the two 16-byte reads of a fragment row are two
+  // operands of v_mfma_scale_f32_16x16x128_f8f6f4 (cbsz = blgp = 4: 4 passes, layout H0 of tools/mx_probe.hip -- lane (row, g) holds the 32
+  // consecutive K of chunk g), so a stage is walked as two HALVES (chunks 0-3, then 4-7) with half-size register sets; the scale operand
+  // of a lane is the E8M0 byte of ITS row (GemmArgs::A4s / W4s), eight + three per tile, packed four to a register and shifted into byte 0.
+  u32x4 b4[FN], a4[4];
+  unsigned sa_pk[2] = {0u, 0u}, sw_pk = 0u;
+  auto rd_a4 = [&](const char* sA, int i, int h) { return *(const u32x4*)(sA + ((a_off + i * 2048) ^ (h << 6))); };
+  auto rd_b4 = [&](const char* sB, int j, int h) { return *(const u32x4*)(sB + ((b_off + j * 2048) ^ (h << 6))); };
+  auto mfma4_ip = [](f32x4& c, const u32x4& a, const u32x4& b, unsigned sa_, unsigned sb_) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                 : "+v"(c) : "v"(a), "v"(b), "v"(sa_), "v"(sb_));
+  };
+  auto lo4_scales = [&](int tm_, int tn_) {
+    if constexpr (LO == 2) {
+      const int r = lane & 15;
+      const unsigned char* as = g.A4s + (size_t)tm_ * BM + grp * 128 + r;
+      const unsigned char* ws = g.W4s + (size_t)tn_ * BN + wn * WTN + r;
+      sa_pk[0] = (unsigned)as[0] | ((unsigned)as[16] << 8) | ((unsigned)as[32] << 16) | ((unsigned)as[48] << 24);
+      sa_pk[1] = (unsigned)as[64] | ((unsigned)as[80] << 8) | ((unsigned)as[96] << 16) | ((unsigned)as[112] << 24);
+      sw_pk = (unsigned)ws[0] | ((unsigned)ws[16] << 8) | ((unsigned)ws[32] << 16);
+    }
+  };
+  auto lo4_fill = [&](const char* sA, const char* sB) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b4[j] = rd_b4(sB, j, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a4[i] = rd_a4(sA, i, 0);
+  };
+  auto lo4_tile = [&](const char* sA, const char* sB, const char* sAn, const char* sBn, auto look) {
+    constexpr bool LOOK = decltype(look)::value;
+    // half 0: rows 0-3 (rows 4-7 of the half roll in), rows 4-7 (rows 0-3 of half 1 roll in; B of half 1 behind row 7's MFMAs)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma4_ip(acc[i][j], b4[j], a4[i], sw_pk >> (8 * j), sa_pk[0] >> (8 * i));
+      a4[i] = rd_a4(sA, i + 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        mfma4_ip(acc[i][j], b4[j], a4[i & 3], sw_pk >> (8 * j), sa_pk[1] >> (8 * (i & 3)));
+        if (i == 7) b4[j] = rd_b4(sB, j, 1);
+      }
+      a4[i & 3] = rd_a4(sA, i - 4, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // half 1: as the fp8 tile -- rows 0-3 | rows 4-5 | lgkmcnt(0), B_u | rows 6-7 with the look-ahead of stage u + 1 (half 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma4_ip(acc[i][j], b4[j], a4[i], sw_pk >> (8 * j), sa_pk[0] >> (8 * i));
+      a4[i] = rd_a4(sA, i + 4, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 4; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma4_ip(acc[i][j], b4[j], a4[i & 3], sw_pk >> (8 * j), sa_pk[1] >> (8 * (i & 3)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (LOOK) {
+      a4[0] = rd_a4(sAn, 0, 0);
+      a4[1] = rd_a4(sAn, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) mfma4_ip(acc[6][j], b4[j], a4[2], sw_pk >> (8 * j), sa_pk[1] >> 16);
+    if constexpr (LOOK) a4[2] = rd_a4(sAn, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      mfma4_ip(acc[7][j], b4[j], a4[3], sw_pk >> (8 * j), sa_pk[1] >> 24);
+      if constexpr (LOOK) b4[j] = rd_b4(sBn, j, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (LOOK) a4[3] = rd_a4(sAn, 3, 0);
+  };
+
   int it = 0, ia = 0;
   if constexpr (A_ONE) {   // ladder rung: the whole walk as ONE K loop (no drain / epilogue / refill between output tiles)
     const int total = ntile * nk;
@@ -880,7 +961,19 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       ia = ia == NA - 1 ? 0 : ia + 1;
       ktile(sA, nullptr, nullptr, std::false_type{});
       ++it;
-      if constexpr (LO) {   // the correction K tiles: stage `it` landed at the barrier of the tile above
+      if constexpr (LO == 2) {   // the fp4 correction K tiles (see lo4_tile)
+        lo4_scales(tm, tn);
+        lo4_fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
+        for (int k8 = 0; k8 + 1 < nk8; ++k8, ++it) {
+          const char* sA8 = smem + ia * A_BYTES;
+          ia = ia == NA - 1 ? 0 : ia + 1;
+          lo4_tile(sA8, smem + (it & 1) * B_BYTES, smem + ia * A_BYTES, smem + ((it + 1) & 1) * B_BYTES, std::true_type{});
+        }
+        const char* sA8 = smem + ia * A_BYTES;
+        ia = ia == NA - 1 ? 0 : ia + 1;
+        lo4_tile(sA8, smem + (it & 1) * B_BYTES, nullptr, nullptr, std::false_type{});
+        ++it;
+      } else if constexpr (LO) {   // the correction K tiles: stage `it` landed at the barrier of the tile above
         lo_fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
         for (int k8 = 0; k8 + 1 < nk8; ++k8, ++it) {
           const char* sA8 = smem + ia * A_BYTES;
@@ -1267,17 +1360,36 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     return LATTE_OK;
   }
 #endif
+  if (a.A4) {   // fp4 correction pass (GemmArgs::A4 / W4 + row scales): the rolling kernel's LO = 2 instantiations
+    if (!roll || !a.W4 || !a.A4s || !a.W4s || !(epi == EPI_GATE_RES_F32 || epi == EPI_BIAS_GELU_H16) || DT != LATTE_DTYPE_F16)
+      return fail(LATTE_ERR_INVALID, "gemm: the fp4 correction pass needs the rolling kernel, f16 operands, both code images with their row scales, and the gated / GELU epilogue");
+    if constexpr (DT == LATTE_DTYPE_F16) {
+      if (epi == EPI_GATE_RES_F32) {
+        auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 0, 2>;
+        static std::atomic<uint64_t> attr_done{0};
+        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+      } else {
+        auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_H16, DT, 0, 2>;
+        static std::atomic<uint64_t> attr_done{0};
+        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
+        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
+      }
+    }
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   if (a.A8) {   // correction pass (GemmArgs::A8 / W8): the rolling kernel's LO instantiations, out-projection and fc1 of guided calls
     if (!roll || !a.W8 || a.K % 128 != 0 || !(epi == EPI_GATE_RES_F32 || epi == EPI_BIAS_GELU_H16) || DT != LATTE_DTYPE_F16)
       return fail(LATTE_ERR_INVALID, "gemm (correction pass): rolling kernel, f16 operands, K % 128 == 0, gated-residual or GELU epilogue only");
     if constexpr (DT == LATTE_DTYPE_F16) {
       if (epi == EPI_GATE_RES_F32) {
-        auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 0, true>;
+        auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 0, 1>;
         static std::atomic<uint64_t> attr_done{0};
         if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
       } else {
-        auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_H16, DT, 0, true>;
+        auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_H16, DT, 0, 1>;
         static std::atomic<uint64_t> attr_done{0};
         if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
@@ -1316,6 +1428,10 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
 
 }  // namespace
 
+bool gemm_lo4_ok(int M, int N, int K) {
+  return M > 0 && N % 192 == 0 && K % 64 == 0 && K >= 128 && (uint64_t)((M + 255) / 256 * 256) * K * 2 < (1ull << 32) &&
+         (uint64_t)N * K * 2 < (1ull << 32);
+}
 bool gemm_lo8_ok(int M, int N, int K) {
   return M > 0 && N % 192 == 0 && K % 128 == 0 && K >= 128 && (uint64_t)((M + 255) / 256 * 256) * K * 2 < (1ull << 32) &&
          (uint64_t)N * K * 2 < (1ull << 32);
