@@ -62,6 +62,7 @@ struct BlockW {
   half_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
   float *qkv_b, *proj_b, *fc1_b, *fc2_b;
   half_t *proj_w2 = nullptr, *fc1_w2 = nullptr;   // [N, 2 K] = [W | W]: the weight of a split-operand linear (guided_split bits 0 / 1), built lazily
+  unsigned char *fc1_w4 = nullptr, *fc1_w4s = nullptr;    // fp4 image of fc1's weight + its row scales (guided_split bit 4; GemmArgs::W4 / W4s)
   unsigned char *proj_w8 = nullptr, *fc1_w8 = nullptr;   // [N, K] e4m3(W 2^LO8_W_SHIFT): the weight of a GEMM's fp8 correction pass (bits 2 / 3)
 };
 
@@ -97,15 +98,18 @@ struct latte_engine {
   // half the MFMA time and a quarter of the operand bytes of the [hi | lo] . [W | W] form; the remainder term is 2^-12 of the product,
   // so its own fp8 rounding (2^-4 relative) is 2^-16 -- below the weight operand's f16 rounding.  A bit-2/3 setting wins over bit 0/1
   // for its operand.  Guided calls of f16 engines only (bf16 cannot reach 1e-3 with or without it: default 0 there); where a shape
+  // Round 6, second form: bit 4 = fc1's operand with the remainder in FP4 (e2m1 codes, one E8M0 scale per row: ln_modulate's SPLIT4 output,
+  // GemmArgs::A4) -- the block-scaled MFMA runs fp4 x fp4 at twice the fp8 rate and a code row is half the bytes; wins over bits 1 / 3.
   // has no split form (un-fused attention, N % 192, K % 128) that operand stays plain -- latte_engine_get_info("guided_split_active")
   // reports what the last guided forward really ran.
-  int guided_split = 12;
+  int guided_split = 20;
   int guided_split_active = 0;             // what the last guided forward used (bits as above)
   bool split_failed = false;               // an allocation for the split operands failed once: guided calls run plain from then on
   bool split_w_ready = false;              // the derived weight copies (proj_w2 / fc1_w2 / proj_w8 / fc1_w8) hold the current weights
   hipEvent_t load_event = nullptr;         // recorded behind every weight conversion on ITS stream: the derived copies wait for it
   half_t* xn2 = nullptr;                   // [rows_pad, 2 D]: split LayerNorm-modulate output (lazily allocated)
   unsigned char* lo8 = nullptr;            // [rows_pad, D] bytes: the fp8 remainder of the attention output, then of fc1's operand
+  unsigned char *lo4 = nullptr, *lo4s = nullptr;   // [rows_pad, lo4_pitch(D)] e2m1 codes + [rows_pad] row scales: the fp4 remainder of fc1's operand (bit 4)
   float *split_ws = nullptr, *zero_bias = nullptr;   // partial products of the split gated GEMMs, a zero bias row for them
   std::vector<BlockW> blocks;
   float *ada_w = nullptr, *ada_b = nullptr, *pos = nullptr, *temp = nullptr, *pe_wt = nullptr, *pe_b = nullptr,
@@ -229,11 +233,17 @@ int ensure_split_weights(latte_engine* e, int need, hipStream_t st) {
   bool fresh = false;
   if ((need & 2) && !e->xn2 && dev_alloc(e, &e->xn2, (size_t)e->rows_pad * 2 * D)) return give_up("the [rows, 2 D] operand buffer");
   if ((need & 12) && !e->lo8 && dev_alloc(e, &e->lo8, (size_t)e->rows_pad * D)) return give_up("the fp8 remainder buffer");
+  if ((need & 16) && !e->lo4 && (dev_alloc(e, &e->lo4, (size_t)e->rows_pad * lo4_pitch(D)) || dev_alloc(e, &e->lo4s, (size_t)e->rows_pad)))
+    return give_up("the fp4 remainder buffer");   // (dev_alloc zero-fills: the padding columns of a code row stay zero codes)
   for (auto& w : e->blocks) {
     if ((need & 1) && !w.proj_w2) { if (dev_alloc(e, &w.proj_w2, (size_t)D * 2 * D, false)) return give_up("[W | W] of the out-projection"); fresh = true; }
     if ((need & 2) && !w.fc1_w2) { if (dev_alloc(e, &w.fc1_w2, (size_t)Hm * 2 * D, false)) return give_up("[W | W] of fc1"); fresh = true; }
     if ((need & 4) && !w.proj_w8) { if (dev_alloc(e, &w.proj_w8, (size_t)D * D, false)) return give_up("W8 of the out-projection"); fresh = true; }
     if ((need & 8) && !w.fc1_w8) { if (dev_alloc(e, &w.fc1_w8, (size_t)Hm * D, false)) return give_up("W8 of fc1"); fresh = true; }
+    if ((need & 16) && !w.fc1_w4) {
+      if (dev_alloc(e, &w.fc1_w4, (size_t)Hm * lo4_pitch(D), false) || dev_alloc(e, &w.fc1_w4s, (size_t)Hm, false)) return give_up("W4 of fc1");
+      fresh = true;
+    }
   }
   if (e->split_w_ready && !fresh) return need;
   if (e->load_event && hipStreamWaitEvent(st, e->load_event, 0) != hipSuccess) return give_up("the wait for the weight conversion");
@@ -247,6 +257,7 @@ int ensure_split_weights(latte_engine* e, int need, hipStream_t st) {
     }
     if (w.proj_w8 && launch_pack_w8(w.proj_w, w.proj_w8, (int64_t)D * D, dt, st)) return give_up("the W8 pack");
     if (w.fc1_w8 && launch_pack_w8(w.fc1_w, w.fc1_w8, (int64_t)Hm * D, dt, st)) return give_up("the W8 pack");
+    if (w.fc1_w4 && launch_pack_w4(w.fc1_w, w.fc1_w4, w.fc1_w4s, Hm, D, dt, st)) return give_up("the W4 pack");
   }
   e->split_w_ready = true;
   return need;
@@ -304,14 +315,16 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
   tm.mark(C_PATCH);
   // split-operand linears of a guided call (latte_engine::guided_split); the K' = 2 K operands must stay inside the 32-bit buffer offsets
   int gsplit = cfg_dup ? e->guided_split : 0;
-  if (dt != LATTE_DTYPE_F16) gsplit &= 3;                                          // the fp8 remainder exists beside f16 only
-  if (gsplit & 4) gsplit &= ~1;                                                    // one form per operand: fp8 wins
+  if (dt != LATTE_DTYPE_F16) gsplit &= 3;                                          // the fp8 / fp4 remainders exist beside f16 only
+  if ((gsplit & 16) && !gemm_lo4_ok(M, e->Hm, D)) gsplit = (gsplit & ~16) | 8;     // no fp4 form for the shape: the fp8 one
+  if (gsplit & 16) gsplit &= ~10;                                                  // one form per operand: fp4 wins for fc1's
+  if (gsplit & 4) gsplit &= ~1;                                                    // fp8 wins over the f16 pair
   if (gsplit & 8) gsplit &= ~2;
   if ((gsplit & 4) && !gemm_lo8_ok(M, D, D)) gsplit = (gsplit & ~4) | 1;          // no fp8 form for the shape (N % 192, K % 128): the f16 pair
   if ((gsplit & 8) && !gemm_lo8_ok(M, e->Hm, D)) gsplit = (gsplit & ~8) | 2;
   if ((gsplit & 3) && (uint64_t)e->rows_pad * 2 * D * 2 >= (1ull << 32)) gsplit &= ~3;
   if (gsplit) gsplit = ensure_split_weights(e, gsplit, st);
-  int gactive = gsplit & 10;   // bits 1 / 3 always apply; bits 0 / 2 once a fused attention kernel has produced the pair
+  int gactive = gsplit & 26;   // bits 1 / 3 / 4 always apply; bits 0 / 2 once a fused attention kernel has produced the pair
 
   for (int i = 0; i < c.depth; ++i) {
     const bool spatial = (i % 2) == 0;  // latte.py:345-346
@@ -362,15 +375,18 @@ int run_forward(latte_engine* e, const float* x, const int64_t* t, const int64_t
     if ((rc = gated_gemm(e, g, dt, e->gemm_variant_of[1] ? e->gemm_variant_of[1] : e->gemm_variant, st))) return rc;
     g.A8 = nullptr; g.W8 = nullptr;
     tm.mark(C_PROJ);
-    const int split_fc1 = (gsplit & 8) ? 2 : (gsplit & 2) ? 1 : 0;
-    if ((rc = launch_ln_modulate(e->xres, e->xres, split_fc1 == 1 ? e->xn2 : e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st,
-                                 split_fc1, e->lo8))) return rc;
+    const int split_fc1 = (gsplit & 16) ? 3 : (gsplit & 8) ? 2 : (gsplit & 2) ? 1 : 0;
+    if (split_fc1 == 3) rc = launch_ln_modulate_split4(e->xres, e->xn, e->lo4, e->lo4s, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, dt, st);
+    else rc = launch_ln_modulate(e->xres, e->xres, split_fc1 == 1 ? e->xn2 : e->xn, mb + 3 * D, mb + 4 * D, mstride, M, D, rps, nullptr, T, F, dt, st,
+                                 split_fc1, e->lo8);
+    if (rc) return rc;
     tm.mark(C_LN);
     g.A = e->xn; g.W = w.fc1_w; g.bias = w.fc1_b; g.out = e->hbuf; g.gate = nullptr; g.N = e->Hm; g.K = D;
     if (split_fc1 == 1) { g.A = e->xn2; g.W = w.fc1_w2; g.K = 2 * D; }
     if (split_fc1 == 2) { g.A8 = e->lo8; g.W8 = w.fc1_w8; }
+    if (split_fc1 == 3) { g.A4 = e->lo4; g.A4s = e->lo4s; g.W4 = w.fc1_w4; g.W4s = w.fc1_w4s; }
     if ((rc = launch_gemm(g, EPI_BIAS_GELU_H16, dt, e->gemm_variant_of[2] ? e->gemm_variant_of[2] : e->gemm_variant, st))) return rc;
-    g.A8 = nullptr; g.W8 = nullptr;
+    g.A8 = nullptr; g.W8 = nullptr; g.A4 = nullptr; g.A4s = nullptr; g.W4 = nullptr; g.W4s = nullptr;
     tm.mark(C_FC1);
     g.A = e->hbuf; g.W = w.fc2_w; g.bias = w.fc2_b; g.out = e->xres; g.gate = mb + 5 * D; g.N = D; g.K = e->Hm; g.tag = 1;
 
@@ -622,8 +638,8 @@ int latte_engine_set_option(latte_engine_t* e, const char* name, int64_t value) 
     return LATTE_OK;
   }
   if (k == "guided_split") {
-    if (value < 0 || value > 15)
-      return fail(LATTE_ERR_INVALID, "guided_split: bit 0 / 1 = attention output / fc1 operand as f16 split pairs, bit 2 / 3 = the same with an fp8 remainder, in guided calls (0..15)");
+    if (value < 0 || value > 31)
+      return fail(LATTE_ERR_INVALID, "guided_split: bit 0 / 1 = attention output / fc1 operand as f16 split pairs, bit 2 / 3 = the same with an fp8 remainder, bit 4 = fc1's operand with an fp4 remainder, in guided calls (0..31)");
     e->guided_split = (int)value;
     return LATTE_OK;
   }

@@ -884,6 +884,9 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a4[i] = rd_a4(sA, i, 0);
   };
+  // (A run-time choice of a half-size walk for the last tile of a row whose codes end inside its first half -- K % 256 <= 128: K = 1152 --
+  //  was built and removed: behind the branch the register allocator no longer keeps the in-place accumulators where they are, 532 bytes
+  //  of scratch per lane, fc1 with the pass +340 us per launch.  The zero half costs 10 % of the pass's MFMAs instead.)
   auto lo4_tile = [&](const char* sA, const char* sB, const char* sAn, const char* sBn, auto look) {
     constexpr bool LOOK = decltype(look)::value;
     // half 0: rows 0-3 (rows 4-7 of the half roll in), rows 4-7 (rows 0-3 of half 1 roll in; B of half 1 behind row 7's MFMAs)

@@ -240,17 +240,17 @@ def test_guided_forward_at_trained_scale_gates(gate_std, t_val, seed):
     with torch.no_grad():
         ref = lo.latte_forward_with_cfg(sd, cfg, x, t, y, 7.0)
     assert m.operand_dtype(guided=True) == "f16"
-    assert m.get_engine_option("guided_split", 2, guided=True) == 12       # the default: both operands with an fp8 remainder
+    assert m.get_engine_option("guided_split", 2, guided=True) == 20       # the default: attention output + fp8 remainder, fc1's operand + fp4 remainder
     out = m.forward_with_cfg(x.cuda(), t.cuda(), y=y.cuda(), cfg_scale=7.0)
-    assert m.get_engine_option("guided_split_active", 2, guided=True) == 12
+    assert m.get_engine_option("guided_split_active", 2, guided=True) == 20
     e = (rel_l2(out, ref), rel_l2(out[:, :, :4], ref[:, :, :4]))
     rec = {"f16": e[0], "f16_eps": e[1]}
     # measured beside it, not asserted: the f16-pair form of round 5 (3), one operand only (4: attention output, 8: fc1's), plain f16 (0)
-    for gs in (3, 4, 8, 1, 0):
+    for gs in (3, 4, 8, 16, 12, 1, 0):       # 12: both remainders as fp8 (the first form of round 6); 16: fc1's operand with the fp4 remainder only
         m.set_engine_option("guided_split", gs, 2, guided=True)
         o = m.forward_with_cfg(x.cuda(), t.cuda(), y=y.cuda(), cfg_scale=7.0)
         rec[f"guided_split_{gs}"] = rel_l2(o, ref)
-    m.set_engine_option("guided_split", 12, 2, guided=True)
+    m.set_engine_option("guided_split", 20, 2, guided=True)
     _record_gate(f"guided_forward::Latte-XL/2::32x16::gate_std={gate_std}::t={t_val}::seed={seed}", rec)
     print(gate_std, t_val, seed, rec)
     assert e[0] < TOL and e[1] < TOL, e
@@ -281,7 +281,7 @@ def test_guided_forward_latte_l2_width():
 
 
 def test_guided_split_contract():
-    """Engine option guided_split (round 5; round 6: bits 2 / 3 = the fp8-remainder form, the default 12): (a) unguided calls do not
+    """Engine option guided_split (round 5; round 6: bits 2 / 3 = the fp8-remainder form, bit 4 = fc1's operand with an fp4 remainder; default 20): (a) unguided calls do not
     depend on it; (b) guided_split = 0 is the plain f16 path: the guided output is the guidance combination of the SAME engine's
     unguided outputs of the doubled batch, bit for bit; (c) the split operands move the guided output by no more than an operand
     rounding (they remove one) and closer to the fp32 oracle, and the fp8 remainder does what the f16 remainder does; (d) the derived
@@ -300,14 +300,14 @@ def test_guided_split_contract():
     m = m.cuda()
     plain = m(x, t, y=y)
     outs = {}
-    assert m.get_engine_option("guided_split", 2, guided=True) == 12            # the default of an f16 engine
-    for gs in (0, 1, 2, 3, 4, 8, 12, 15):
+    assert m.get_engine_option("guided_split", 2, guided=True) == 20            # the default of an f16 engine
+    for gs in (0, 1, 2, 3, 4, 8, 12, 15, 16, 20, 31):
         m.set_engine_option("guided_split", gs, 2, guided=True)
         outs[gs] = m.forward_with_cfg(x, t, y=y, cfg_scale=7.0)
         assert torch.equal(m(x, t, y=y), plain), gs                               # (a)
-        assert m.get_engine_option("guided_split_active", 2, guided=True) == (12 if gs == 15 else gs)   # (e): fp8 wins per operand
+        assert m.get_engine_option("guided_split_active", 2, guided=True) == {15: 12, 31: 20}.get(gs, gs)   # (e): fp8 wins over the pair, fp4 over fp8
     assert m.get_engine_option("guided_split_failed", 2, guided=True) == 0
-    assert torch.equal(outs[15], outs[12])
+    assert torch.equal(outs[15], outs[12]) and torch.equal(outs[31], outs[20])
     cond, uncond = plain[:1, :, :4], plain[1:, :, :4]
     eps = uncond + 7.0 * (cond - uncond)
     want0 = torch.cat([torch.cat([eps, eps]), plain[:, :, 4:]], dim=2)
@@ -316,7 +316,8 @@ def test_guided_split_contract():
     print(e)
     assert e[3] < e[0] and e[1] < e[0] and e[2] < e[0] and e[3] < TOL               # (c)
     assert e[12] < e[0] and e[4] < e[0] and e[8] < e[0] and e[12] < TOL
-    assert all(rel_l2(outs[gs], outs[0]) < 3e-3 for gs in (1, 2, 3, 4, 8, 12))
+    assert e[20] < e[0] and e[16] < e[0] and e[20] < TOL and abs(e[20] - e[12]) < 0.1 * e[12] and abs(e[16] - e[8]) < 0.1 * e[8]   # the fp4 remainder does what the fp8 one does
+    assert all(rel_l2(outs[gs], outs[0]) < 3e-3 for gs in (1, 2, 3, 4, 8, 12, 16, 20))
     # the fp8 remainder keeps 4 bits of a term that is 2^-12 of the product: against the oracle the two forms are the same (their
     # outputs still differ by a few 1e-4 from each other: any change upstream re-draws the roundings of every operand downstream)
     assert abs(e[12] - e[3]) < 0.05 * e[3] and abs(e[4] - e[1]) < 0.05 * e[1] and abs(e[8] - e[2]) < 0.05 * e[2]
@@ -328,7 +329,7 @@ def test_guided_split_contract():
     m.mark_weights_dirty() if hasattr(m, "mark_weights_dirty") else None
     with torch.no_grad():
         ref2 = lo.latte_forward_with_cfg(sd2, cfg, x.cpu(), t.cpu(), y.cpu(), 7.0)
-    for gs in (3, 12):
+    for gs in (3, 12, 20):
         m.set_engine_option("guided_split", gs, 2, guided=True)
         got2 = m.forward_with_cfg(x, t, y=y, cfg_scale=7.0)
         assert rel_l2(got2[:, :, :4], ref2[:, :, :4]) < TOL and rel_l2(got2, outs[gs]) > 1e-2

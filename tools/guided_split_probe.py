@@ -24,7 +24,7 @@ t = torch.full((rows,), 500, device="cuda", dtype=torch.int64)
 y = torch.cat([torch.randint(0, 101, (rows // 2,), device="cuda"), torch.full((rows // 2,), 101, device="cuda")])
 res, outs = {}, {}
 for rep in range(4):
-    for gs in (0, 1, 2, 3, 4, 8, 12):
+    for gs in (0, 1, 2, 3, 4, 8, 12, 16, 20):
         m.set_engine_option("guided_split", gs, rows, guided=True)
         o = m.forward_with_cfg(x, t, y=y, cfg_scale=7.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
