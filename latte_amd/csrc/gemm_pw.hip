@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     tn = in_group / gsz;
   };
   const int nk = K / 64;
-  const int nk8 = LO == 2 ? (K + 255) / 256 : LO ? K / 128 : 0;   // correction K tiles behind the nk half-precision ones (fp4: K = 256 per 128 row bytes)
+  const int nk8 = LO >= 2 ? (K + 255) / 256 : LO ? K / 128 : 0;   // correction K tiles behind the nk half-precision ones (fp4: K = 256 per 128 row bytes)
   const int nkt = nk + nk8;                       // K tiles of the walk per output tile
   const int ntile = (cnt - slot + per - 1) / per;
   constexpr bool TRACE = EPI == EPI_ABLATE_TRACE;
@@ -470,11 +470,11 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
     unsigned step32 = 32u * row_bytes;
     asm volatile("" : "+s"(step32));
     // correction operands: rows of K bytes
-    const unsigned row_bytes8 = LO == 2 ? (unsigned)((K + 255) / 256 * 128) : (unsigned)K;   // fp4: two codes per byte, rows padded to K % 256 == 0
+    const unsigned row_bytes8 = LO >= 2 ? (unsigned)((K + 255) / 256 * 128) : (unsigned)K;   // fp4: two codes per byte, rows padded to K % 256 == 0
     const __amdgpu_buffer_rsrc_t rsA8 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(LO == 2 ? (const void*)g.A4 : LO ? (const void*)g.A8 : (const void*)g.A), 0, (unsigned)tiles_m * BM * row_bytes8, 0x00020000);
+        (void*)(LO >= 2 ? (const void*)g.A4 : LO ? (const void*)g.A8 : (const void*)g.A), 0, (unsigned)tiles_m * BM * row_bytes8, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB8 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(LO == 2 ? (const void*)g.W4 : LO ? (const void*)g.W8 : (const void*)g.W), 0, (unsigned)g.N * row_bytes8, 0x00020000);
+        (void*)(LO >= 2 ? (const void*)g.W4 : LO ? (const void*)g.W8 : (const void*)g.W), 0, (unsigned)g.N * row_bytes8, 0x00020000);
     const unsigned voff8 = (unsigned)lrow * row_bytes8 + (unsigned)((cpos ^ (((pw * 8 + lrow) >> 1) & 7)) * 16);
     unsigned step32_8 = 32u * row_bytes8;
     asm volatile("" : "+s"(step32_8));
@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
                  : "+v"(c) : "v"(a), "v"(b), "v"(sa_), "v"(sb_));
   };
   auto lo4_scales = [&](int tm_, int tn_) {
-    if constexpr (LO == 2) {
+    if constexpr (LO >= 2) {
       const int r = lane & 15;
       const unsigned char* as = g.A4s + (size_t)tm_ * BM + grp * 128 + r;
       const unsigned char* ws = g.W4s + (size_t)tn_ * BN + wn * WTN + r;
@@ -884,9 +884,25 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a4[i] = rd_a4(sA, i, 0);
   };
-  // (A run-time choice of a half-size walk for the last tile of a row whose codes end inside its first half -- K % 256 <= 128: K = 1152 --
-  //  was built and removed: behind the branch the register allocator no longer keeps the in-place accumulators where they are, 532 bytes
-  //  of scratch per lane, fc1 with the pass +340 us per launch.  The zero half costs 10 % of the pass's MFMAs instead.)
+  // LO == 3: the last fp4 tile of a row whose codes end inside its first half (0 < K % 256 <= 128: K = 1152) walks half 0 only -- a
+  // COMPILE-TIME choice (the launcher picks the instantiation): as a run-time branch it cost 532 bytes of scratch per lane (behind the
+  // branch the register allocator no longer keeps the in-place accumulators where they are) and +340 us per fc1 launch.
+  auto lo4_tail = [&](const char* sA) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma4_ip(acc[i][j], b4[j], a4[i], sw_pk >> (8 * j), sa_pk[0] >> (8 * i));
+      a4[i] = rd_a4(sA, i + 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma4_ip(acc[i][j], b4[j], a4[i & 3], sw_pk >> (8 * j), sa_pk[1] >> (8 * (i & 3)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
   auto lo4_tile = [&](const char* sA, const char* sB, const char* sAn, const char* sBn, auto look) {
     constexpr bool LOOK = decltype(look)::value;
     // half 0: rows 0-3 (rows 4-7 of the half roll in), rows 4-7 (rows 0-3 of half 1 roll in; B of half 1 behind row 7's MFMAs)
@@ -964,7 +980,7 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
       ia = ia == NA - 1 ? 0 : ia + 1;
       ktile(sA, nullptr, nullptr, std::false_type{});
       ++it;
-      if constexpr (LO == 2) {   // the fp4 correction K tiles (see lo4_tile)
+      if constexpr (LO >= 2) {   // the fp4 correction K tiles (see lo4_tile)
         lo4_scales(tm, tn);
         lo4_fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
         for (int k8 = 0; k8 + 1 < nk8; ++k8, ++it) {
@@ -974,7 +990,8 @@ __global__ void __launch_bounds__(768) gemm_pwr_kernel(GemmArgs g) {
         }
         const char* sA8 = smem + ia * A_BYTES;
         ia = ia == NA - 1 ? 0 : ia + 1;
-        lo4_tile(sA8, smem + (it & 1) * B_BYTES, nullptr, nullptr, std::false_type{});
+        if constexpr (LO == 3) lo4_tail(sA8);
+        else lo4_tile(sA8, smem + (it & 1) * B_BYTES, nullptr, nullptr, std::false_type{});
         ++it;
       } else if constexpr (LO) {   // the correction K tiles: stage `it` landed at the barrier of the tile above
         lo_fill(smem + ia * A_BYTES, smem + (it & 1) * B_BYTES);
@@ -1367,17 +1384,17 @@ int launch_pw_dt(const GemmArgs& a, int epi, int roll, hipStream_t st) {
     if (!roll || !a.W4 || !a.A4s || !a.W4s || !(epi == EPI_GATE_RES_F32 || epi == EPI_BIAS_GELU_H16) || DT != LATTE_DTYPE_F16)
       return fail(LATTE_ERR_INVALID, "gemm: the fp4 correction pass needs the rolling kernel, f16 operands, both code images with their row scales, and the gated / GELU epilogue");
     if constexpr (DT == LATTE_DTYPE_F16) {
-      if (epi == EPI_GATE_RES_F32) {
-        auto kern = gemm_pwr_kernel<EPI_GATE_RES_F32, DT, 0, 2>;
-        static std::atomic<uint64_t> attr_done{0};
-        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
-        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
-      } else {
-        auto kern = gemm_pwr_kernel<EPI_BIAS_GELU_H16, DT, 0, 2>;
-        static std::atomic<uint64_t> attr_done{0};
-        if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;
-        hipLaunchKernelGGL(kern, grid, block, LDS, st, a);
-      }
+      const bool half_tail = (a.K & 255) != 0 && (a.K & 255) <= 128;   // the last code tile ends inside its first half: LO = 3
+#define LATTE_PW_LO4(E, L)                                                                   \
+  {                                                                                          \
+    auto kern = gemm_pwr_kernel<E, DT, 0, L>;                                                \
+    static std::atomic<uint64_t> attr_done{0};                                               \
+    if (int rc_ = ensure_dynamic_lds((const void*)kern, LDS, attr_done)) return rc_;         \
+    hipLaunchKernelGGL(kern, grid, block, LDS, st, a);                                       \
+  }
+      if (epi == EPI_GATE_RES_F32) { if (half_tail) LATTE_PW_LO4(EPI_GATE_RES_F32, 3) else LATTE_PW_LO4(EPI_GATE_RES_F32, 2) }
+      else { if (half_tail) LATTE_PW_LO4(EPI_BIAS_GELU_H16, 3) else LATTE_PW_LO4(EPI_BIAS_GELU_H16, 2) }
+#undef LATTE_PW_LO4
     }
     LATTE_HIP(hipGetLastError());
     return LATTE_OK;
