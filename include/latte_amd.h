@@ -93,7 +93,7 @@ void latte_engine_destroy(latte_engine_t* e);
  * OFF one default schedule feature of the fused kernel each -- the next unit's first operand tile fetched under the attention
  * phase, the attention-phase issue priority of wave group 0, the four-heads-per-XCD unit order of 16-head models (A/B hooks);
  * every setting gives the same bits),
- * "guided_split" (bits; guided calls -- latte_forward_with_cfg and the guided sample loop -- only; default 12 on f16 engines, ignored
+ * "guided_split" (bits; guided calls -- latte_forward_with_cfg and the guided sample loop -- only; default 20 on f16 engines, ignored
  * beyond bits 0 / 1 on bf16 ones: bit 0 = the attention output
  * that feeds the out-projection, bit 1 = the LayerNorm-modulate output that feeds fc1 are carried as SPLIT operand pairs [hi | lo] (two
  * halves per value) against weights stored [W | W], i.e. those two linears run on K' = 2 K without rounding their activation operand.
@@ -102,7 +102,10 @@ void latte_engine_destroy(latte_engine_t* e);
  * for +31 % of the guided step at XL/2.  Bits 2 / 3 (round 6) carry the same two operands as f16 + an FP8
  * remainder (e4m3 of lo * 2^12, one byte per value) whose product with an fp8 copy of the weight is collected by a block-scaled fp8
  * MFMA pass behind the f16 K loop of the SAME GEMM launch: the same parity margin at half the extra MFMA time and a quarter of the
- * extra operand bytes; a bit-2 / 3 setting wins over bit 0 / 1 for its operand.  0 = the plain f16 operands of the unguided path.
+ * extra operand bytes; a bit-2 / 3 setting wins over bit 0 / 1 for its operand.  Bit 4 (round 6) carries fc1's operand as f16 + an FP4
+ * remainder (e2m1 codes, two per byte, ONE E8M0 scale per row) -- the block-scaled MFMA runs fp4 x fp4 at twice the fp8 rate; it wins
+ * over bits 1 / 3.  12 = both remainders as fp8 (+15 % per guided forward), 20 = the default (+11 %), 3 = round 5's f16 pairs (+30 %), all
+ * at the same parity.  0 = the plain f16 operands of the unguided path.
  * Operands whose shape has no split form stay plain: latte_engine_get_option("guided_split_active") reports the bits the last
  * guided forward really used),
  * "seed" (Philox seed of the engine's own noise stream, used by latte_sample_loop when no noise
