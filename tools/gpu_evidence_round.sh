@@ -17,3 +17,10 @@ LATTE_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 4 --warmup
 # what bounds the MFMA kernels: the same launches on random / quiet operands with rocm-smi power and clock beside them
 timeout 200 python tools/operand_power_probe.py 1.2 > $O/${TAG}_operand_power_probe_gemm.log 2>&1
 timeout 200 python tools/operand_power_probe.py 1.5 fused > $O/${TAG}_operand_power_probe_fused_and_forward.log 2>&1
+# round 6: rocprofv3 kernel statistics of the side configurations (configs 5 and 4) on the closing code
+export TMPDIR=/tmp
+for pair in "train_step_B2_batch5:tools/train_bench.py" "temporal_decoder:tools/t2v_decode_bench.py" "t2v_forward:tools/t2v_bench.py --steps 4"; do
+  n=${pair%%:*}; c=${pair#*:}
+  (cd /tmp && LATTE_DECODE_PROFILE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$n -o $n -- python $R/$c > $O/${TAG}_prof_$n.log 2>&1)
+  cp $(find /tmp/prof_$n -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats_$n.csv
+done
