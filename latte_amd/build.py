@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "liblatte_amd_dbg.so" if DEBUG_BUILD else "liblatte_a
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-SOURCES = ["gemm.hip", "gemm_pw.hip", "gemm_tn.hip", "train.hip", "train_attn.hip", "attention.hip", "qkv_attn.hip", "pointwise.hip", "debug.hip", "vae.hip", "engine.cpp", "train_engine.cpp", "vae_engine.cpp", "t2v_engine.cpp", "schedule.cpp"]
+SOURCES = ["gemm.hip", "gemm_pw.hip", "gemm_tn.hip", "train.hip", "train_fin.hip", "train_attn.hip", "attention.hip", "qkv_attn.hip", "pointwise.hip", "debug.hip", "vae.hip", "engine.cpp", "train_engine.cpp", "vae_engine.cpp", "t2v_engine.cpp", "schedule.cpp"]
 COMMON = ["--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if DEBUG_BUILD:   # measurement build: main-loop / epilogue ablation instantiations of the GEMM
     COMMON.append("-DLATTE_GEMM_ABLATE")

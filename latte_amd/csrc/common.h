@@ -269,16 +269,43 @@ int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int trans
 int train_rows_per_run(int rps);
 int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, int M, int D, int rps,
                      int dtype, hipStream_t st);
+// dgate == nullptr: no finalize launch (the stage's finalize kernel reads the partial rows);  bias_partial != 0: partial is
+// [M / (4 R)][2][D] and row 1 of a run holds sum_rows gate * dx (the bias gradient of the branch's output linear)
 int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
-                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st);
+                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st, int bias_partial = 0);
 int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_stride, const float* dx_in, float* dx_out, float* partial,
                   float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st);
 int launch_gelu_fwd(const half_t* u, half_t* h, size_t n, int dtype, hipStream_t st);
 int launch_gelu_bwd(const half_t* u, const half_t* dh, half_t* du, size_t n, int dtype, hipStream_t st);
 int colsum_chunks(int M);
 int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* out, int accumulate, int dtype, hipStream_t st);
-int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st);
+// inv_scale_dev: optional device float; the sum is multiplied by 1 / *inv_scale_dev (the loss scale, a power of two) on the way out
+int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st,
+                        const float* inv_scale_dev = nullptr);
 int launch_pack_weight(const float* w, half_t* wn, half_t* wt, int N, int K, int dtype, hipStream_t st);
+// ---- small-kernel consolidation of the training step (train_fin.hip)
+struct StageFinArgs {
+  const float* mod_src[6];   // per modulation chunk: row-run partials [B rows_per_sample][nsum][D]
+  int mod_nsum[6], mod_which[6];
+  int n_mod, rows_per_sample, B, D;
+  float* dmod;               // [B][dmod_stride], this linear's first column (assigned, loss-scaled domain)
+  int dmod_stride;
+  const float* csilu;        // [B][D]
+  float *dW, *db;            // adaLN linear gradients [n_mod D][D], [n_mod D]
+  int n_bias;                // column sums: out[col] = sum_r src[r stride + col]
+  const float* bias_src[4];
+  int bias_rows[4], bias_stride[4], bias_cols[4];
+  float* bias_out[4];
+  int bias_blk[5];           // (filled by the launcher)
+  const float* scaler;       // device loss scale or nullptr: dW, db and the bias sums leave the scaled domain
+};
+int launch_stage_finalize(const StageFinArgs& a, hipStream_t st);
+int adaln_dc_splits(int nmod);
+int launch_adaln_dc(const float* dmod, int nmod, int B, const float* w_blocks, long blk_stride, int depth, int rows6, const float* w_final,
+                    int D, float* ws, float* dc, hipStream_t st);
+struct PackDesc { const float* w; half_t* wn; half_t* wt; int N, K; };
+struct PackPlan { int tiles_per_block; int tile0[4]; };
+int launch_pack_weights(const PackDesc* descs_dev, int blocks, const PackPlan& pl, int dtype, hipStream_t st);
 int launch_naive_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm, long scn, int M, int N,
                       int K, float alpha, int accumulate, hipStream_t st, int splits = 1, float* ws = nullptr);
 int launch_tfreq(const int64_t* t, float* out, int B, hipStream_t st);

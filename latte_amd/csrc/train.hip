@@ -73,21 +73,23 @@ __global__ void __launch_bounds__(256) gated_add_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------- gated residual, backward
 // one wave per run of R consecutive rows of one sample: dy = gate * dx (half), partial[run][col] = sum_rows dx * y
-template <int DT>
+template <int DT, bool BIAS>
 __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ dx, const half_t* __restrict__ y,
                                                        const float* __restrict__ gate, int gate_stride, half_t* __restrict__ dy,
                                                        float* __restrict__ partial, int M, int D, int rps, int R) {
+  constexpr int NS = BIAS ? 2 : 1;   // partial rows per block: sum dx * y [, sum gate * dx = the output linear's bias gradient]
   const int lane = threadIdx.x & 63;
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row0 = run * R;          // (launcher: M / R is a multiple of 4, so no wave of a block is out of range)
   const int nt = D >> 2;
   const float4* g4 = (const float4*)(gate + (size_t)(row0 / rps) * gate_stride);
-  float4 g[NQ_MAX], acc[NQ_MAX];
+  float4 g[NQ_MAX], acc[NQ_MAX], accb[BIAS ? NQ_MAX : 1];
 #pragma unroll
   for (int c = 0; c < NQ_MAX; ++c) {
     const int ch = c * 64 + lane;
     g[c] = ch < nt ? g4[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
     acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BIAS) accb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int r = 0; r < R; ++r) {
     const size_t ro = (size_t)(row0 + r) * nt;
@@ -99,20 +101,25 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
         float a, b, cc, e;
         unpack4<DT>(((const uint2*)y)[ro + ch], a, b, cc, e);
         acc[c].x += d.x * a; acc[c].y += d.y * b; acc[c].z += d.z * cc; acc[c].w += d.w * e;
+        const float4 gd = make_float4(g[c].x * d.x, g[c].y * d.y, g[c].z * d.z, g[c].w * d.w);
+        if constexpr (BIAS) { accb[c].x += gd.x; accb[c].y += gd.y; accb[c].z += gd.z; accb[c].w += gd.w; }
         uint2 o;
-        o.x = pack2t<DT>(g[c].x * d.x, g[c].y * d.y);
-        o.y = pack2t<DT>(g[c].z * d.z, g[c].w * d.w);
+        o.x = pack2t<DT>(gd.x, gd.y);
+        o.y = pack2t<DT>(gd.z, gd.w);
         ((uint2*)dy)[ro + ch] = o;
       }
     }
   }
-  // the block's 4 waves (4 consecutive runs of one sample) are added through LDS: one partial row per block
-  extern __shared__ __attribute__((aligned(16))) float red_t[];
+  // the block's 4 waves (4 consecutive runs of one sample) are added through LDS: NS partial rows per block
+  extern __shared__ __attribute__((aligned(16))) float red_t[];   // [3 waves][NS][D]
   const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < NQ_MAX; ++c) {
     const int ch = c * 64 + lane;
-    if (ch < nt && wv > 0) ((float4*)(red_t + (size_t)(wv - 1) * D))[ch] = acc[c];
+    if (ch < nt && wv > 0) {
+      ((float4*)(red_t + ((size_t)(wv - 1) * NS + 0) * D))[ch] = acc[c];
+      if constexpr (BIAS) ((float4*)(red_t + ((size_t)(wv - 1) * NS + 1) * D))[ch] = accb[c];
+    }
   }
   __syncthreads();
   if (wv == 0) {
@@ -123,10 +130,19 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
         float4 a = acc[c];
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-          const float4 o = ((const float4*)(red_t + (size_t)w * D))[ch];
+          const float4 o = ((const float4*)(red_t + ((size_t)w * NS + 0) * D))[ch];
           a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
         }
-        ((float4*)(partial + (size_t)blockIdx.x * D))[ch] = a;
+        ((float4*)(partial + ((size_t)blockIdx.x * NS + 0) * D))[ch] = a;
+        if constexpr (BIAS) {
+          float4 b = accb[c];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            const float4 o = ((const float4*)(red_t + ((size_t)w * NS + 1) * D))[ch];
+            b.x += o.x; b.y += o.y; b.z += o.z; b.w += o.w;
+          }
+          ((float4*)(partial + ((size_t)blockIdx.x * NS + 1) * D))[ch] = b;
+        }
       }
     }
   }
@@ -319,20 +335,25 @@ __global__ void __launch_bounds__(256) colsum_half_kernel(const half_t* __restri
   }
 }
 // out[i] (+)= sum_s partial[s * stride + i]
+// (inv_scale: optional device loss scale; the SUM -- not the accumulated-into value -- leaves the scaled domain: x 1 / scale, exact)
 __global__ void split_reduce_kernel(const float* __restrict__ partial, int splits, size_t stride, size_t n, float* __restrict__ out,
-                                    int accumulate) {
+                                    int accumulate, const float* __restrict__ inv_scale) {
+  const float f = inv_scale ? 1.0f / inv_scale[0] : 1.0f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float a = accumulate ? out[i] : 0.f;
+    float a = (accumulate && !inv_scale) ? out[i] : 0.f;
     for (int s = 0; s < splits; ++s) a += partial[(size_t)s * stride + i];
+    if (inv_scale) a = accumulate ? out[i] + a * f : a * f;
     out[i] = a;
   }
 }
 // the same sum in the same (slab) order on 16-byte accesses, four slabs in flight per step (n, stride multiples of 4, 16-byte
 // aligned buffers: every weight matrix): the reductions of the weight-gradient partial products are bandwidth-bound streams
 __global__ void __launch_bounds__(256) split_reduce4_kernel(const float4* __restrict__ partial, int splits, size_t stride4, size_t n4,
-                                                            float4* __restrict__ out, int accumulate) {
+                                                            float4* __restrict__ out, int accumulate,
+                                                            const float* __restrict__ inv_scale) {
+  const float f = inv_scale ? 1.0f / inv_scale[0] : 1.0f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 a = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = (accumulate && !inv_scale) ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
     for (; s + 4 <= splits; s += 4) {
       const float4 p0 = partial[(size_t)s * stride4 + i], p1 = partial[(size_t)(s + 1) * stride4 + i];
@@ -343,6 +364,13 @@ __global__ void __launch_bounds__(256) split_reduce4_kernel(const float4* __rest
     for (; s < splits; ++s) {
       const float4 p = partial[(size_t)s * stride4 + i];
       a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    if (inv_scale) {   // the sum leaves the loss-scaled domain (power of two: exact)
+      a.x *= f; a.y *= f; a.z *= f; a.w *= f;
+      if (accumulate) {
+        const float4 o = out[i];
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
     }
     out[i] = a;
   }
@@ -703,17 +731,23 @@ int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int 
   return LATTE_OK;
 }
 
-// partial: float [M / R][D];  dgate: [B][out_stride] (assigned)
+// partial: float [M / (4 R)][1 or 2][D];  dgate: [B][out_stride] (assigned) or nullptr (no finalize launch)
 int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
-                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
+                    int out_stride, int M, int D, int rps, int dtype, hipStream_t st, int bias_partial) {
   if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "gate_bwd: need D % 4 == 0 and D <= 1280");
   const int R = train_rows_per_run(rps), runs = M / R;
   if (rps % (4 * R)) return fail(LATTE_ERR_INVALID, "gate_bwd: rows per sample must be a multiple of 4 runs");
-#define CALL(DT) hipLaunchKernelGGL(gate_bwd_kernel<DT>, dim3(runs / 4), dim3(256), 3 * D * sizeof(float), st, dx, y, gate, gate_stride, dy, partial, M, D, rps, R)
+  const int ns = bias_partial ? 2 : 1;
+#define CALL(DT)                                                                                                                          \
+  if (bias_partial) hipLaunchKernelGGL((gate_bwd_kernel<DT, true>), dim3(runs / 4), dim3(256), 3 * ns * D * sizeof(float), st, dx, y, gate, \
+                                       gate_stride, dy, partial, M, D, rps, R);                                                           \
+  else hipLaunchKernelGGL((gate_bwd_kernel<DT, false>), dim3(runs / 4), dim3(256), 3 * ns * D * sizeof(float), st, dx, y, gate, gate_stride, \
+                          dy, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 1, 0, D, dgate,
-                     out_stride);
+  if (dgate)
+    hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), ns, 0, D, dgate,
+                       out_stride);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -727,10 +761,12 @@ int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_
 #define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3(runs / 4), dim3(256), 6 * D * sizeof(float), st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 0, D, dshift,
-                     out_stride);
-  hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 1, D, dscale,
-                     out_stride);
+  if (dshift) {   // nullptr: the stage's finalize kernel reads the partial rows
+    hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 0, D, dshift,
+                       out_stride);
+    hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 1, D, dscale,
+                       out_stride);
+  }
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -760,18 +796,21 @@ int launch_colsum_half(const half_t* in, int M, int C, float* partial, float* ou
 #define CALL(DT) hipLaunchKernelGGL(colsum_half_kernel<DT>, dim3((C + 127) / 128, chunks), dim3(256), 0, st, in, M, C, partial)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for((size_t)C)), dim3(256), 0, st, partial, chunks, (size_t)C, (size_t)C, out, accumulate);
+  if (out)   // nullptr: the chunk partials [colsum_chunks(M)][C] are reduced by the stage's finalize kernel
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for((size_t)C)), dim3(256), 0, st, partial, chunks, (size_t)C, (size_t)C, out, accumulate,
+                       (const float*)nullptr);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
-int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st) {
+int launch_split_reduce(const float* partial, int splits, size_t stride, size_t n, float* out, int accumulate, hipStream_t st,
+                        const float* inv_scale_dev) {
   if (n % 4 == 0 && stride % 4 == 0 && ((uintptr_t)partial & 15) == 0 && ((uintptr_t)out & 15) == 0 && n >= 4096) {
     hipLaunchKernelGGL(split_reduce4_kernel, dim3(blocks_for(n / 4, 8192)), dim3(256), 0, st, (const float4*)partial, splits, stride / 4, n / 4,
-                       (float4*)out, accumulate);
+                       (float4*)out, accumulate, inv_scale_dev);
     LATTE_HIP(hipGetLastError());
     return LATTE_OK;
   }
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, partial, splits, stride, n, out, accumulate);
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, partial, splits, stride, n, out, accumulate, inv_scale_dev);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
@@ -795,7 +834,7 @@ int launch_naive_gemm(const float* A, long sam, long sak, const float* B, long s
     hipLaunchKernelGGL(naive_gemm_kernel, dim3((N + 63) / 64, (M + 3) / 4, ns), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, ws, (long)N, 1L, M,
                        N, K, alpha, 0, chunk, (long)M * N);
     hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, st, ws, ns, (size_t)M * N, (size_t)M * N, C,
-                       accumulate);
+                       accumulate, (const float*)nullptr);
   } else {
     hipLaunchKernelGGL(naive_gemm_kernel, dim3((N + 63) / 64, (M + 3) / 4, 1), dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, scm, scn, M, N,
                        K, alpha, accumulate, 0, 0L);

@@ -51,6 +51,13 @@ struct latte_trainer {
   float loss_scale = 1.0f;       // initial / static value (host copy; the live value is scaler[0])
   int dynamic_scale = 0;
   int fuse_gelu = 1;        // the MLP's GELU passes inside the fc1 forward / fc2 input-gradient GEMMs (round 6; "fuse_gelu" option, A/B tests)
+  // round 6b ("fuse_small" option, default 1; train_fin.hip): one finalize launch per block stage instead of ~25 tiny ones -- the
+  // row-run / column partials of a stage stay in their own buffers until its end, the adaLN linear's input gradient is one batched
+  // product at the last stage, the loss-scale pass of the block slices rides on the kernels that write them, one weight-pack launch
+  int fuse_small = 1;
+  float *pg1 = nullptr, *pl1 = nullptr, *pg2 = nullptr, *pl2 = nullptr, *pc_fc1 = nullptr, *pc_qkv = nullptr, *dc_ws = nullptr;
+  PackDesc* pack_descs = nullptr;
+  PackPlan pack_plan{};
   float growth_interval = 2000.0f;
   float* scaler = nullptr;
   std::vector<ParamInfo> params;
@@ -124,12 +131,13 @@ int gemm_gelu(latte_trainer* e, int epi, const half_t* A, const half_t* W, const
 
 // dW[N, K] = dY[M, N]^T X[M, K] on the transposed-operand GEMM (gemm_tn.hip: no transposed copies), the contraction split so
 // that about four workgroups per CU are in flight; the partial products are reduced in a fixed order; result ASSIGNED to dW
-int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st) {
+// (unscale: the reduction also takes the result out of the loss-scaled domain, x 1 / scaler[0])
+int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st, bool unscale = false) {
   int rc, chunk = 0;
   const int splits = gemm_tn_plan(M, N, K, &chunk);
   if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
   if ((rc = launch_gemm_tn(dY, X, e->wg_ws, M, N, K, chunk, e->dt, st))) return rc;
-  return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st);
+  return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st, unscale ? e->scaler : nullptr);
 }
 
 // loss-scale state -> device.  what: 0 = everything incl. the counters (create), 1 = a new scale (restarts the growth count),
@@ -233,6 +241,21 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   A(&e->part_rows, (size_t)(e->rows_max / Rr + 4) * 2 * D);
   A(&e->part_cols, (size_t)(colsum_chunks((int)e->rows_max) + 1) * std::max(Hm, 3 * D));
   {
+    const size_t pr = (size_t)(e->rows_max / Rr / 4 + 1) * 2 * D;   // one block of 4 runs -> 2 partial rows
+    A(&e->pg1, pr); A(&e->pl1, pr); A(&e->pg2, pr); A(&e->pl2, pr);
+    A(&e->pc_fc1, (size_t)(colsum_chunks((int)e->rows_max) + 1) * Hm);
+    A(&e->pc_qkv, (size_t)(colsum_chunks((int)e->rows_max) + 1) * 3 * D);
+    A(&e->dc_ws, (size_t)adaln_dc_splits(e->nmod) * Bm * D);
+    A(&e->pack_descs, (size_t)c.depth * 4);
+    const int shp[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
+    int t0 = 0;
+    for (int j = 0; j < 4; ++j) {
+      e->pack_plan.tile0[j] = t0;
+      t0 += ((shp[j][0] + 31) / 32) * ((shp[j][1] + 31) / 32);
+    }
+    e->pack_plan.tiles_per_block = t0;
+  }
+  {
     // split-K partial products: splits * N * K with splits <= ceil(1024 / tiles) (+1), tiles = ceil(N / 128) (K / 128)
     int64_t worst = 0;
     const int shapes[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
@@ -279,6 +302,20 @@ int latte_trainer_bind(latte_trainer_t* e, float* params, float* grads, float* e
   if (!e || !params || !grads || !exp_avg || !exp_avg_sq) return fail(LATTE_ERR_INVALID, "trainer_bind: null buffer");
   e->Pm = params; e->Gr = grads; e->M1 = exp_avg; e->V2 = exp_avg_sq; e->Ema = ema;
   e->weights_synced = false;
+  {   // pointer table of the one-launch weight pack (train_fin.hip): [block][qkv, proj, fc1, fc2]
+    const int D = e->D, Hm = e->Hm;
+    std::vector<PackDesc> h((size_t)e->cfg.depth * 4);
+    for (int i = 0; i < e->cfg.depth; ++i) {
+      const std::string p = "blocks." + std::to_string(i) + ".";
+      BlockBuf& b = e->blk[i];
+      h[i * 4 + 0] = PackDesc{P_(e, p + "attn.qkv.weight"), b.qkv_w, b.qkv_wt, 3 * D, D};
+      h[i * 4 + 1] = PackDesc{P_(e, p + "attn.proj.weight"), b.proj_w, b.proj_wt, D, D};
+      h[i * 4 + 2] = PackDesc{P_(e, p + "mlp.fc1.weight"), b.fc1_w, b.fc1_wt, Hm, D};
+      h[i * 4 + 3] = PackDesc{P_(e, p + "mlp.fc2.weight"), b.fc2_w, b.fc2_wt, D, Hm};
+    }
+    LATTE_HIP(hipDeviceSynchronize());
+    LATTE_HIP(hipMemcpy(e->pack_descs, h.data(), h.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+  }
   return LATTE_OK;
 }
 
@@ -296,6 +333,9 @@ int latte_trainer_sync_weights(latte_trainer_t* e, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int D = e->D, Hm = e->Hm;
   int rc;
+  if (e->fuse_small) {
+    if ((rc = launch_pack_weights(e->pack_descs, e->cfg.depth, e->pack_plan, e->dt, st))) return rc;
+  } else
   for (int i = 0; i < e->cfg.depth; ++i) {
     const std::string p = "blocks." + std::to_string(i) + ".";
     BlockBuf& b = e->blk[i];
@@ -451,7 +491,8 @@ int latte_trainer_stage_range(const latte_trainer_t* e, int stage, int64_t* offs
 static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream);
 int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream) {
   int rc = backward_stage_impl(e, stage, stream);
-  if (!rc && scaling_active(e)) {   // the slice this stage finalised leaves the loss-scaled domain
+  // (fuse_small: the block stages' slices were unscaled by the kernels that wrote them)
+  if (!rc && scaling_active(e) && !(e->fuse_small && stage >= 1 && stage <= e->cfg.depth)) {   // the slice this stage finalised leaves the loss-scaled domain
     int64_t off = 0, n = 0;
     if ((rc = latte_trainer_stage_range(e, stage, &off, &n))) return rc;
     rc = launch_scale_f32_dev(e->Gr + off, e->scaler, 1, (size_t)n, (hipStream_t)stream);
@@ -476,6 +517,11 @@ int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value)
     if (!(value >= 1.0) || value > 1e7) return fail(LATTE_ERR_INVALID, "loss_scale_growth_interval must be in [1, 1e7]");
     e->growth_interval = (float)value;
     return upload_scaler(e, 2);
+  }
+  if (std::string(name) == "fuse_small") {   // 0: the separate finalize / column-sum / adaLN launches of rounds 2 - 6, 1: train_fin.hip (default)
+    if (e->next_stage <= e->cfg.depth + 1) return fail(LATTE_ERR_STATE, "fuse_small: a step is in flight");
+    e->fuse_small = value != 0.0 ? 1 : 0;
+    return LATTE_OK;
   }
   if (std::string(name) == "fuse_gelu") {   // 0: separate GELU passes (rounds 2 - 5), 1: inside the GEMM epilogues (default)
     e->fuse_gelu = value != 0.0 ? 1 : 0;
@@ -509,6 +555,16 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
   if ((rc = launch_convert_f32_to_h16(e->f32b, e->dxnH, (int64_t)M * D, dt, st))) return rc;
   {
     float* dm = e->dmod + (size_t)c.depth * 6 * D;
+    if (e->fuse_small) {   // shift / scale gradients of the final modulation and its adaLN linear's bias / weight gradients in one launch
+      if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st))) return rc;
+      StageFinArgs a{};
+      a.mod_src[0] = a.mod_src[1] = e->pl1; a.mod_nsum[0] = a.mod_nsum[1] = 2; a.mod_which[0] = 0; a.mod_which[1] = 1;
+      a.n_mod = 2; a.rows_per_sample = rps / (4 * train_rows_per_run(rps)); a.B = B; a.D = D;
+      a.dmod = dm; a.dmod_stride = nmod; a.csilu = e->csilu;
+      a.dW = G_(e, "final_layer.adaLN_modulation.1.weight"); a.db = G_(e, "final_layer.adaLN_modulation.1.bias");
+      a.n_bias = 0; a.scaler = nullptr;   // this stage's slice is unscaled by the pass behind the stage
+      return launch_stage_finalize(a, st);
+    }
     if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->part_rows, dm, dm + D, nmod, M, D, rps, dt, st))) return rc;
   }
   return adaln_bwd(e, c.depth, st);
@@ -520,6 +576,51 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
     BlockBuf& b = e->blk[i];
     const float* mb = e->mod + (size_t)i * 6 * D;
     float* dm = e->dmod + (size_t)i * 6 * D;
+    if (e->fuse_small) {
+      const bool us = scaling_active(e);
+      // ---- MLP branch: x2 = x1 + g2 * (fc2(gelu(fc1(xn2))));  the gate / bias partial rows wait for the stage's finalize launch
+      if ((rc = launch_gate_bwd(e->dx, b.y2, mb + 5 * D, nmod, e->dyD, e->pg2, nullptr, nmod, M, D, rps, dt, st, 1))) return rc;
+      if ((rc = wgrad(e, e->dyD, b.h, M, D, Hm, G_(e, p + "mlp.fc2.weight"), st, us))) return rc;
+      if (gelu_fusable(e, M, Hm, D)) {
+        if ((rc = gemm_gelu(e, EPI_DGELU_H16, e->dyD, b.fc2_wt, e->zeros, e->dhH, b.u, M, Hm, D, st))) return rc;
+      } else {
+        if ((rc = gemm_half(e, e->dyD, b.fc2_wt, e->zeros, e->dhH, M, Hm, D, st))) return rc;
+        if ((rc = launch_gelu_bwd(b.u, e->dhH, e->dhH, (size_t)M * Hm, dt, st))) return rc;
+      }
+      if ((rc = launch_colsum_half(e->dhH, M, Hm, e->pc_fc1, nullptr, 0, dt, st))) return rc;
+      if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st, us))) return rc;
+      if ((rc = gemm_half(e, e->dhH, b.fc1_wt, e->zeros, e->dxnH, M, D, Hm, st))) return rc;
+      if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i + 1], mb + 4 * D, nmod, e->dx, e->dx, e->pl2, nullptr, nullptr, nmod, M, D, rps, dt, st)))
+        return rc;
+      // ---- attention branch: x1 = x0 + g1 * proj(attn(qkv(xn1)))
+      if ((rc = launch_gate_bwd(e->dx, b.y1, mb + 2 * D, nmod, e->dyD, e->pg1, nullptr, nmod, M, D, rps, dt, st, 1))) return rc;
+      if ((rc = wgrad(e, e->dyD, b.att, M, D, D, G_(e, p + "attn.proj.weight"), st, us))) return rc;
+      if ((rc = gemm_half(e, e->dyD, b.proj_wt, e->zeros, e->dxnH, M, D, D, st))) return rc;   // d(attention output)
+      if (spatial) rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * F, T, c.num_heads, e->hd, F, rps, T, 1, dt, st);
+      else         rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * T, F, c.num_heads, e->hd, T, rps, 1, T, dt, st);
+      if (rc) return rc;
+      if ((rc = launch_colsum_half(e->dqkvH, M, 3 * D, e->pc_qkv, nullptr, 0, dt, st))) return rc;
+      if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st, us))) return rc;
+      if ((rc = gemm_half(e, e->dqkvH, b.qkv_wt, e->zeros, e->dxnH, M, D, 3 * D, st))) return rc;
+      if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st))) return rc;
+      // ---- one launch: the six modulation gradients, the adaLN linear's bias / weight gradients, the four linears' bias gradients
+      StageFinArgs a{};
+      const float* msrc[6] = {e->pl1, e->pl1, e->pg1, e->pl2, e->pl2, e->pg2};
+      const int mwhich[6] = {0, 1, 0, 0, 1, 0};
+      for (int k = 0; k < 6; ++k) { a.mod_src[k] = msrc[k]; a.mod_nsum[k] = 2; a.mod_which[k] = mwhich[k]; }
+      const int rb = rps / (4 * train_rows_per_run(rps));   // partial rows (blocks of 4 runs) per sample
+      a.n_mod = 6; a.rows_per_sample = rb; a.B = B; a.D = D;
+      a.dmod = dm; a.dmod_stride = nmod; a.csilu = e->csilu;
+      a.dW = G_(e, p + "adaLN_modulation.1.weight"); a.db = G_(e, p + "adaLN_modulation.1.bias");
+      const int ch = colsum_chunks(M);
+      a.n_bias = 4;
+      a.bias_src[0] = e->pc_qkv;   a.bias_rows[0] = ch;     a.bias_stride[0] = 3 * D; a.bias_cols[0] = 3 * D; a.bias_out[0] = G_(e, p + "attn.qkv.bias");
+      a.bias_src[1] = e->pg1 + D;  a.bias_rows[1] = B * rb; a.bias_stride[1] = 2 * D; a.bias_cols[1] = D;     a.bias_out[1] = G_(e, p + "attn.proj.bias");
+      a.bias_src[2] = e->pc_fc1;   a.bias_rows[2] = ch;     a.bias_stride[2] = Hm;    a.bias_cols[2] = Hm;    a.bias_out[2] = G_(e, p + "mlp.fc1.bias");
+      a.bias_src[3] = e->pg2 + D;  a.bias_rows[3] = B * rb; a.bias_stride[3] = 2 * D; a.bias_cols[3] = D;     a.bias_out[3] = G_(e, p + "mlp.fc2.bias");
+      a.scaler = us ? e->scaler : nullptr;
+      return launch_stage_finalize(a, st);
+    }
     // ---- MLP branch: x2 = x1 + g2 * (fc2(gelu(fc1(xn2))))
     if ((rc = launch_gate_bwd(e->dx, b.y2, mb + 5 * D, nmod, e->dyD, e->part_rows, dm + 5 * D, nmod, M, D, rps, dt, st))) return rc;
     if ((rc = launch_colsum_half(e->dyD, M, D, e->part_cols, G_(e, p + "mlp.fc2.bias"), 0, dt, st))) return rc;
@@ -555,6 +656,13 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
   if ((rc = launch_naive_gemm(e->dx, 1, D, e->pix, e->KPE, 1, G_(e, "x_embedder.proj.weight"), e->KPE, 1, D, e->KPE, M, 1.0f, 0, st, 64,
                               e->ng_ws))) return rc;
   // ---- conditioning tail: d SiLU(c) (summed by the stages) -> c = temb (+ y_emb) -> t_embedder MLP
+  if (e->fuse_small) {   // d SiLU(c) = dmod W over every adaLN linear of the model at once (the stages left their dmod rows)
+    auto off = [&](const std::string& k) { return e->params[e->index.at(k)].offset; };
+    const int64_t o0 = off("blocks.0.adaLN_modulation.1.weight");
+    const int64_t stride = off("blocks.1.adaLN_modulation.1.weight") - o0;
+    if ((rc = launch_adaln_dc(e->dmod, nmod, B, e->Pm + o0, (long)stride, c.depth, 6 * D, P_(e, "final_layer.adaLN_modulation.1.weight"), D,
+                              e->dc_ws, e->dc, st))) return rc;
+  }
   if ((rc = launch_silu_bwd(e->dc, e->cvec, e->dtmp, (size_t)B * D, 0, st))) return rc;     // dtmp = dc (gradient of c = temb + y_emb)
   if (c.extras == 2) {
     // the scatter accumulates (a label may repeat inside the batch): clear the slice first, so that forward_backward ASSIGNS this
