@@ -269,6 +269,8 @@ int launch_pack_small_w(const float* w, float* out, int Cout, int Cin, int trans
 int train_rows_per_run(int rps);
 int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, int M, int D, int rps,
                      int dtype, hipStream_t st);
+int launch_gated_add_ln(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, half_t* xn, const float* shift,
+                        const float* scale, int mod_stride, int M, int D, int rps, const float* te, int T, int F, int dtype, hipStream_t st);
 // dgate == nullptr: no finalize launch (the stage's finalize kernel reads the partial rows);  bias_partial != 0: partial is
 // [M / (4 R)][2][D] and row 1 of a run holds sum_rows gate * dx (the bias gradient of the branch's output linear)
 int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
@@ -303,6 +305,10 @@ int launch_stage_finalize(const StageFinArgs& a, hipStream_t st);
 int adaln_dc_splits(int nmod);
 int launch_adaln_dc(const float* dmod, int nmod, int B, const float* w_blocks, long blk_stride, int depth, int rows6, const float* w_final,
                     int D, float* ws, float* dc, hipStream_t st);
+int narrow_blocks(int M);
+int launch_narrow_outer(const float* nar, int P, const void* wide, int wide_half, int D, int M, float* dW, long so_p, long so_k,
+                        float* nsum_out, float* wsum_out, float* ws, int dtype, const float* inv_scale_dev, hipStream_t st);
+int launch_narrow_dx(const float* nar, int P, const float* W, int D, int M, half_t* out, int dtype, hipStream_t st);
 struct PackDesc { const float* w; half_t* wn; half_t* wt; int N, K; };
 struct PackPlan { int tiles_per_block; int tile0[4]; };
 int launch_pack_weights(const PackDesc* descs_dev, int blocks, const PackPlan& pl, int dtype, hipStream_t st);

@@ -71,6 +71,78 @@ __global__ void __launch_bounds__(256) gated_add_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------- gated residual + the next LayerNorm
+// x' = x + gate * y (+ temp_embed row, latte.py:355-358) written once, and xn = LN(x') (1 + scale) + shift of the NEXT LayerNorm in
+// the same pass over the row (round 6b): the separate pair moved 16 bytes per element, this 12, in one launch.  One wave per row,
+// the arithmetic of gated_add_kernel followed by ln_modulate_kernel (pointwise.hip) expression for expression; equal to the pair up
+// to the compiler's FMA contraction choices inside the fp32 statistics (measured: model output within 9e-6 absolute,
+// tests/test_training_step.py::test_small_kernel_consolidation_matches_the_separate_launches).
+template <int DT, bool ADD_TE>
+__global__ void __launch_bounds__(256) gated_add_ln_kernel(const float* __restrict__ x_in, const half_t* __restrict__ y,
+                                                           const float* __restrict__ gate, int gate_stride, float* __restrict__ x_out,
+                                                           half_t* __restrict__ xn, const float* __restrict__ shift,
+                                                           const float* __restrict__ scale, int mod_stride, int M, int D, int rps,
+                                                           const float* __restrict__ te, int T, int F) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nt = D >> 2;
+  const int smp = row / rps;
+  const size_t ro = (size_t)row * nt;
+  const float4* g4 = (const float4*)(gate + (size_t)smp * gate_stride);
+  const float4* sh = (const float4*)(shift + (size_t)smp * mod_stride);
+  const float4* sc = (const float4*)(scale + (size_t)smp * mod_stride);
+  float4 v[NQ_MAX], sha[NQ_MAX], sca[NQ_MAX];
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    v[c] = sha[c] = sca[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < nt) {
+      const float4 xv = ((const float4*)x_in)[ro + ch];
+      const float4 g = g4[ch];
+      float a, b, cc, d;
+      unpack4<DT>(((const uint2*)y)[ro + ch], a, b, cc, d);
+      sha[c] = sh[ch];
+      sca[c] = sc[ch];
+      v[c] = make_float4(xv.x + g.x * a, xv.y + g.y * b, xv.z + g.z * cc, xv.w + g.w * d);
+      if constexpr (ADD_TE) {
+        const float4 e = ((const float4*)(te + (size_t)((row / T) % F) * D))[ch];
+        v[c].x += e.x; v[c].y += e.y; v[c].z += e.z; v[c].w += e.w;
+      }
+      ((float4*)x_out)[ro + ch] = v[c];
+    }
+  }
+  const float invD = 1.0f / (float)D;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);     // absent chunks hold zeros
+  const float mean = wave_sum_t(s) * invD;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    if (c * 64 + lane < nt) {
+      const float a = v[c].x - mean, b = v[c].y - mean, d = v[c].z - mean, e = v[c].w - mean;
+      q += (a * a + b * b) + (d * d + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum_t(q) * invD + 1e-6f);
+#pragma unroll
+  for (int c = 0; c < NQ_MAX; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nt) {
+      const float4 a = sha[c], b = sca[c];
+      const float o0 = (v[c].x - mean) * rstd * (1.0f + b.x) + a.x;
+      const float o1 = (v[c].y - mean) * rstd * (1.0f + b.y) + a.y;
+      const float o2 = (v[c].z - mean) * rstd * (1.0f + b.z) + a.z;
+      const float o3 = (v[c].w - mean) * rstd * (1.0f + b.w) + a.w;
+      uint2 o;
+      o.x = pack2t<DT>(o0, o1);
+      o.y = pack2t<DT>(o2, o3);
+      ((uint2*)xn)[ro + ch] = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- gated residual, backward
 // one wave per run of R consecutive rows of one sample: dy = gate * dx (half), partial[run][col] = sum_rows dx * y
 template <int DT, bool BIAS>
@@ -725,6 +797,21 @@ int launch_gated_add(const float* x_in, const half_t* y, const float* gate, int 
                      int dtype, hipStream_t st) {
   if (D % 4) return fail(LATTE_ERR_INVALID, "gated_add: D % 4 != 0");
 #define CALL(DT) hipLaunchKernelGGL(gated_add_kernel<DT>, dim3(blocks_for((size_t)M * D / 4)), dim3(256), 0, st, x_in, y, gate, gate_stride, x_out, M, D, rps)
+  LATTE_DT_SWITCH(dtype, CALL);
+#undef CALL
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+// x_out = x_in + gate * y (+ temp_embed when te != nullptr: added to x_out as ln_modulate's x_rw form does), xn = LN-modulate(x_out)
+int launch_gated_add_ln(const float* x_in, const half_t* y, const float* gate, int gate_stride, float* x_out, half_t* xn, const float* shift,
+                        const float* scale, int mod_stride, int M, int D, int rps, const float* te, int T, int F, int dtype, hipStream_t st) {
+  if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "gated_add_ln: need D % 4 == 0 and D <= 1280");
+#define CALL(DT)                                                                                                                     \
+  if (te) hipLaunchKernelGGL((gated_add_ln_kernel<DT, true>), dim3((M + 3) / 4), dim3(256), 0, st, x_in, y, gate, gate_stride, x_out, xn, \
+                             shift, scale, mod_stride, M, D, rps, te, T, F);                                                         \
+  else hipLaunchKernelGGL((gated_add_ln_kernel<DT, false>), dim3((M + 3) / 4), dim3(256), 0, st, x_in, y, gate, gate_stride, x_out, xn,  \
+                          shift, scale, mod_stride, M, D, rps, te, T, F)
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
   LATTE_HIP(hipGetLastError());

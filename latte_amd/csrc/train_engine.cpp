@@ -55,7 +55,7 @@ struct latte_trainer {
   // row-run / column partials of a stage stay in their own buffers until its end, the adaLN linear's input gradient is one batched
   // product at the last stage, the loss-scale pass of the block slices rides on the kernels that write them, one weight-pack launch
   int fuse_small = 1;
-  float *pg1 = nullptr, *pl1 = nullptr, *pg2 = nullptr, *pl2 = nullptr, *pc_fc1 = nullptr, *pc_qkv = nullptr, *dc_ws = nullptr;
+  float *pg1 = nullptr, *pl1 = nullptr, *pg2 = nullptr, *pl2 = nullptr, *pc_fc1 = nullptr, *pc_qkv = nullptr, *dc_ws = nullptr, *no_ws = nullptr;
   PackDesc* pack_descs = nullptr;
   PackPlan pack_plan{};
   float growth_interval = 2000.0f;
@@ -246,6 +246,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
     A(&e->pc_fc1, (size_t)(colsum_chunks((int)e->rows_max) + 1) * Hm);
     A(&e->pc_qkv, (size_t)(colsum_chunks((int)e->rows_max) + 1) * 3 * D);
     A(&e->dc_ws, (size_t)adaln_dc_splits(e->nmod) * Bm * D);
+    A(&e->no_ws, (size_t)narrow_blocks((int)e->rows_max) * ((size_t)32 * D + 32 + D));
     A(&e->pack_descs, (size_t)c.depth * 4);
     const int shp[4][2] = {{3 * D, D}, {D, D}, {Hm, D}, {D, Hm}};
     int t0 = 0;
@@ -409,7 +410,9 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
     float* x0 = e->xs[2 * i];
     float* x1 = e->xs[2 * i + 1];
     float* x2 = e->xs[2 * i + 2];
-    if ((rc = launch_ln_modulate(x0, x0, b.xn1, mb, mb + D, nmod, M, D, rps, i == 1 ? e->temp : nullptr, T, F, dt, st))) return rc;
+    // (fuse_small: blocks 1 .. depth-1 got xn1 -- and the temporal embedding -- from the previous block's closing gated add)
+    if ((!e->fuse_small || i == 0) &&
+        (rc = launch_ln_modulate(x0, x0, b.xn1, mb, mb + D, nmod, M, D, rps, i == 1 ? e->temp : nullptr, T, F, dt, st))) return rc;
     if ((rc = gemm_half(e, b.xn1, b.qkv_w, P_(e, p + "attn.qkv.bias"), b.qkv, M, 3 * D, D, st))) return rc;
     AttnArgs a{};
     a.qkv = b.qkv; a.out = b.att; a.heads = c.num_heads; a.hd = e->hd; a.D = D;
@@ -418,8 +421,13 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
     else         { a.num_seq = B * T; a.L = F; a.U = T; a.seq_stride = 1; a.row_stride = T; }
     if ((rc = launch_attention(a, dt, st))) return rc;
     if ((rc = gemm_half(e, b.att, b.proj_w, P_(e, p + "attn.proj.bias"), b.y1, M, D, D, st))) return rc;
-    if ((rc = launch_gated_add(x0, b.y1, mb + 2 * D, nmod, x1, M, D, rps, dt, st))) return rc;
-    if ((rc = launch_ln_modulate(x1, x1, b.xn2, mb + 3 * D, mb + 4 * D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    if (e->fuse_small) {   // x1 = x0 + g1 y1 and xn2 = LN-modulate(x1) in one pass over the rows
+      if ((rc = launch_gated_add_ln(x0, b.y1, mb + 2 * D, nmod, x1, b.xn2, mb + 3 * D, mb + 4 * D, nmod, M, D, rps, nullptr, T, F, dt, st)))
+        return rc;
+    } else {
+      if ((rc = launch_gated_add(x0, b.y1, mb + 2 * D, nmod, x1, M, D, rps, dt, st))) return rc;
+      if ((rc = launch_ln_modulate(x1, x1, b.xn2, mb + 3 * D, mb + 4 * D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    }
     if (gelu_fusable(e, M, Hm, D)) {   // u and h = gelu(u) out of one launch (bit-identical to the separate pass)
       if ((rc = gemm_gelu(e, EPI_BIAS_GELU_DUAL_H16, b.xn2, b.fc1_w, P_(e, p + "mlp.fc1.bias"), b.u, b.h, M, Hm, D, st))) return rc;
     } else {
@@ -427,7 +435,11 @@ int latte_trainer_begin(latte_trainer_t* e, const latte_schedule_t* s, int loss_
       if ((rc = launch_gelu_fwd(b.u, b.h, (size_t)M * Hm, dt, st))) return rc;
     }
     if ((rc = gemm_half(e, b.h, b.fc2_w, P_(e, p + "mlp.fc2.bias"), b.y2, M, D, Hm, st))) return rc;
-    if ((rc = launch_gated_add(x1, b.y2, mb + 5 * D, nmod, x2, M, D, rps, dt, st))) return rc;
+    if (e->fuse_small && i + 1 < c.depth) {   // x2 = x1 + g2 y2 (+ temp_embed in front of block 1) and the NEXT block's xn1
+      const float* nb = e->mod + (size_t)(i + 1) * 6 * D;
+      if ((rc = launch_gated_add_ln(x1, b.y2, mb + 5 * D, nmod, x2, e->blk[i + 1].xn1, nb, nb + D, nmod, M, D, rps,
+                                    i + 1 == 1 ? e->temp : nullptr, T, F, dt, st))) return rc;
+    } else if ((rc = launch_gated_add(x1, b.y2, mb + 5 * D, nmod, x2, M, D, rps, dt, st))) return rc;
   }
   float* xl = e->xs[2 * c.depth];
   const float* fm = e->mod + (size_t)c.depth * 6 * D;
@@ -545,6 +557,14 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
   const float* fm = e->mod + (size_t)c.depth * 6 * D;
   // final layer: out = unpatchify(Linear(LN-mod(x)))
   if ((rc = launch_unpatchify_bwd(e->dmodel_out, e->dtok, B * F, e->G, c.patch_size, e->Cout, st))) return rc;
+  if (e->fuse_small && e->P <= 32) {
+    // the linear's weight / bias gradients (exact fp32 products of dtok with the half LN output, as below) in one launch + its
+    // reductions, and its input gradient straight to half (train_fin.hip)
+    if ((rc = launch_ln_modulate(xl, xl, e->xnh, fm, fm + D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
+    if ((rc = launch_narrow_outer(e->dtok, e->P, e->xnh, 1, D, M, G_(e, "final_layer.linear.weight"), D, 1, G_(e, "final_layer.linear.bias"),
+                                  nullptr, e->no_ws, dt, nullptr, st))) return rc;
+    if ((rc = launch_narrow_dx(e->dtok, e->P, P_(e, "final_layer.linear.weight"), D, M, e->dxnH, dt, st))) return rc;
+  } else {
   if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dtok, e->P, 1, G_(e, "final_layer.linear.bias"), e->P, 1, 1, e->P, M, 1.0f, 0, st, 64, e->ng_ws)))
     return rc;
   if ((rc = launch_ln_modulate(xl, xl, e->xnh, fm, fm + D, nmod, M, D, rps, nullptr, T, F, dt, st))) return rc;
@@ -553,6 +573,7 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
     return rc;
   if ((rc = launch_naive_gemm(e->dtok, e->P, 1, P_(e, "final_layer.linear.weight"), D, 1, e->f32b, D, 1, M, D, e->P, 1.0f, 0, st))) return rc;
   if ((rc = launch_convert_f32_to_h16(e->f32b, e->dxnH, (int64_t)M * D, dt, st))) return rc;
+  }
   {
     float* dm = e->dmod + (size_t)c.depth * 6 * D;
     if (e->fuse_small) {   // shift / scale gradients of the final modulation and its adaLN linear's bias / weight gradients in one launch
@@ -651,10 +672,16 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
     return adaln_bwd(e, i, st);
   }
   // ---- patch embed (latte.py:233,330-331): tokens = pix W^T + b + pos
+  if (e->fuse_small && e->KPE <= 32) {   // dW[k][j] = sum_m dx[m][k] pix[m][j], db[k] = sum_m dx[m][k]: one launch + reductions
+    if ((rc = launch_im2col_patch(e->x_t, e->pix, B * F, e->G, c.patch_size, e->Cin, st))) return rc;
+    if ((rc = launch_narrow_outer(e->pix, e->KPE, e->dx, 0, D, M, G_(e, "x_embedder.proj.weight"), 1, e->KPE, nullptr,
+                                  G_(e, "x_embedder.proj.bias"), e->no_ws, dt, nullptr, st))) return rc;
+  } else {
   if ((rc = launch_naive_gemm(e->ones, 0, 1, e->dx, D, 1, G_(e, "x_embedder.proj.bias"), D, 1, 1, D, M, 1.0f, 0, st, 64, e->ng_ws))) return rc;
   if ((rc = launch_im2col_patch(e->x_t, e->pix, B * F, e->G, c.patch_size, e->Cin, st))) return rc;
   if ((rc = launch_naive_gemm(e->dx, 1, D, e->pix, e->KPE, 1, G_(e, "x_embedder.proj.weight"), e->KPE, 1, D, e->KPE, M, 1.0f, 0, st, 64,
                               e->ng_ws))) return rc;
+  }
   // ---- conditioning tail: d SiLU(c) (summed by the stages) -> c = temb (+ y_emb) -> t_embedder MLP
   if (e->fuse_small) {   // d SiLU(c) = dmod W over every adaLN linear of the model at once (the stages left their dmod rows)
     auto off = [&](const std::string& k) { return e->params[e->index.at(k)].offset; };

@@ -208,6 +208,122 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __res
     if (k0 + r < d.K && n0 + tx < d.N) d.wt[(size_t)(k0 + r) * d.N + n0 + tx] = f2h_t<DT>(tile[tx][r]);
 }
 
+// ---------------------------------------------------------------------------------------------- narrow-operand products, exact fp32
+// The final layer's linear (D -> P = p p C_out <= 32 columns, latte.py:196-207) and the patch embed (K = p p C_in <= 32, :233) have one
+// operand with a handful of columns: no MFMA shape fits, and the strided fp32 GEMM ran them at a few percent of anything.
+//   narrow_outer_kernel   partial[blk][p so_p + k so_k] = sum over the block's rows m of nar[m][p] wide[m][k]   (weight gradients;
+//                         + the column sums of either operand = the bias gradients), thread = one float4 of wide columns x all P
+//   narrow_dx_kernel      out[m][k] = half(sum_p nar[m][p] W[p][k])   (input gradient of the final linear), W column in registers
+constexpr int NO_ROWS = 16;     // rows per LDS stage
+constexpr int NO_PMAX = 32;
+template <typename WT, int DT>
+__global__ void __launch_bounds__(320) narrow_outer_kernel(const float* __restrict__ nar, int P, const WT* __restrict__ wide, int D, int M,
+                                                           int rows_per_block, float* __restrict__ partial, long so_p, long so_k,
+                                                           float* __restrict__ part_nsum, float* __restrict__ part_wsum) {
+  extern __shared__ __attribute__((aligned(16))) float no_sm[];   // wide [NO_ROWS][D] | narrow [NO_ROWS][NO_PMAX]
+  float* ws = no_sm;
+  float* ns = no_sm + (size_t)NO_ROWS * D;
+  const int tid = threadIdx.x, nq = D >> 2;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  const bool own = tid < nq;
+  float4 acc[NO_PMAX];
+#pragma unroll
+  for (int p = 0; p < NO_PMAX; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nsum = 0.f;
+  for (int r0 = m0; r0 < m1; r0 += NO_ROWS) {
+    const int nr = min(NO_ROWS, m1 - r0);
+    for (int i = tid; i < nr * nq; i += blockDim.x) {
+      const int r = i / nq, q = i - r * nq;
+      float4 v;
+      if constexpr (sizeof(WT) == 4) v = *(const float4*)((const float*)wide + (size_t)(r0 + r) * D + q * 4);
+      else {
+        const uint2 h = *(const uint2*)((const unsigned short*)wide + (size_t)(r0 + r) * D + q * 4);
+        if constexpr (DT == LATTE_DTYPE_BF16) {
+          v = make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                          __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+        } else {
+          v = make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(h.x & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(h.x >> 16)),
+                          (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(h.y >> 16)));
+        }
+      }
+      ((float4*)ws)[r * nq + q] = v;
+    }
+    for (int i = tid; i < nr * NO_PMAX; i += blockDim.x) {
+      const int r = i / NO_PMAX, p = i - r * NO_PMAX;
+      ns[i] = p < P ? nar[(size_t)(r0 + r) * P + p] : 0.f;
+    }
+    __syncthreads();
+    if (own) {
+      for (int r = 0; r < nr; ++r) {
+        const float4 w = ((const float4*)ws)[r * nq + tid];
+        wsum.x += w.x; wsum.y += w.y; wsum.z += w.z; wsum.w += w.w;
+#pragma unroll
+        for (int p4 = 0; p4 < NO_PMAX / 4; ++p4) {
+          const float4 n = ((const float4*)ns)[r * (NO_PMAX / 4) + p4];
+          acc[p4 * 4 + 0].x += n.x * w.x; acc[p4 * 4 + 0].y += n.x * w.y; acc[p4 * 4 + 0].z += n.x * w.z; acc[p4 * 4 + 0].w += n.x * w.w;
+          acc[p4 * 4 + 1].x += n.y * w.x; acc[p4 * 4 + 1].y += n.y * w.y; acc[p4 * 4 + 1].z += n.y * w.z; acc[p4 * 4 + 1].w += n.y * w.w;
+          acc[p4 * 4 + 2].x += n.z * w.x; acc[p4 * 4 + 2].y += n.z * w.y; acc[p4 * 4 + 2].z += n.z * w.z; acc[p4 * 4 + 2].w += n.z * w.w;
+          acc[p4 * 4 + 3].x += n.w * w.x; acc[p4 * 4 + 3].y += n.w * w.y; acc[p4 * 4 + 3].z += n.w * w.z; acc[p4 * 4 + 3].w += n.w * w.w;
+        }
+      }
+    }
+    if (tid < NO_PMAX)
+      for (int r = 0; r < nr; ++r) nsum += ns[r * NO_PMAX + tid];
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * P * D;
+  if (own) {
+#pragma unroll
+    for (int p = 0; p < NO_PMAX; ++p) {
+      if (p < P) {
+        float* o = out + p * so_p + (size_t)(tid * 4) * so_k;
+        o[0] = acc[p].x; o[so_k] = acc[p].y; o[2 * so_k] = acc[p].z; o[3 * so_k] = acc[p].w;
+      }
+    }
+    if (part_wsum) ((float4*)(part_wsum + (size_t)blockIdx.x * D))[tid] = wsum;
+  }
+  if (part_nsum && tid < P) part_nsum[(size_t)blockIdx.x * P + tid] = nsum;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(320) narrow_dx_kernel(const float* __restrict__ nar, int P, const float* __restrict__ W, int D, int M,
+                                                        int rows_per_block, half_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float ns[NO_ROWS * NO_PMAX];
+  const int tid = threadIdx.x, nq = D >> 2;
+  const bool own = tid < nq;
+  float4 w[NO_PMAX];
+#pragma unroll
+  for (int p = 0; p < NO_PMAX; ++p) w[p] = (own && p < P) ? ((const float4*)(W + (size_t)p * D))[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  for (int r0 = m0; r0 < m1; r0 += NO_ROWS) {
+    const int nr = min(NO_ROWS, m1 - r0);
+    for (int i = tid; i < nr * NO_PMAX; i += blockDim.x) {
+      const int r = i / NO_PMAX, p = i - r * NO_PMAX;
+      ns[i] = p < P ? nar[(size_t)(r0 + r) * P + p] : 0.f;
+    }
+    __syncthreads();
+    if (own) {
+      for (int r = 0; r < nr; ++r) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p4 = 0; p4 < NO_PMAX / 4; ++p4) {
+          const float4 n = ((const float4*)ns)[r * (NO_PMAX / 4) + p4];
+          a.x += n.x * w[p4 * 4].x; a.y += n.x * w[p4 * 4].y; a.z += n.x * w[p4 * 4].z; a.w += n.x * w[p4 * 4].w;
+          a.x += n.y * w[p4 * 4 + 1].x; a.y += n.y * w[p4 * 4 + 1].y; a.z += n.y * w[p4 * 4 + 1].z; a.w += n.y * w[p4 * 4 + 1].w;
+          a.x += n.z * w[p4 * 4 + 2].x; a.y += n.z * w[p4 * 4 + 2].y; a.z += n.z * w[p4 * 4 + 2].z; a.w += n.z * w[p4 * 4 + 2].w;
+          a.x += n.w * w[p4 * 4 + 3].x; a.y += n.w * w[p4 * 4 + 3].y; a.z += n.w * w[p4 * 4 + 3].z; a.w += n.w * w[p4 * 4 + 3].w;
+        }
+        uint2 o;
+        o.x = (unsigned int)f2h_t<DT>(a.x) | ((unsigned int)f2h_t<DT>(a.y) << 16);
+        o.y = (unsigned int)f2h_t<DT>(a.z) | ((unsigned int)f2h_t<DT>(a.w) << 16);
+        ((uint2*)(out + (size_t)(r0 + r) * D))[tid] = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 int launch_stage_finalize(const StageFinArgs& a, hipStream_t st) {
@@ -222,6 +338,51 @@ int launch_stage_finalize(const StageFinArgs& a, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
   if (int rc = ensure_dynamic_lds((const void*)stage_finalize_kernel, lds, done)) return rc;
   hipLaunchKernelGGL(stage_finalize_kernel, dim3(blocks), dim3(1024), lds, st, b);
+  LATTE_HIP(hipGetLastError());
+  return LATTE_OK;
+}
+
+constexpr int NO_ROWS_PER_BLOCK = 128;
+int narrow_blocks(int M) { return (M + NO_ROWS_PER_BLOCK - 1) / NO_ROWS_PER_BLOCK; }
+// dW[p so_p + k so_k] = sum_m nar[m][p] wide[m][k] (assigned), optional bias gradients nsum_out[p] = sum_m nar[m][p],
+// wsum_out[k] = sum_m wide[m][k];  wide: fp32 (wide_half == 0) or the engine's half type;  ws: float [narrow_blocks(M)][P D + P + D];
+// inv_scale_dev: optional device loss scale (results x 1 / scale)
+int launch_narrow_outer(const float* nar, int P, const void* wide, int wide_half, int D, int M, float* dW, long so_p, long so_k,
+                        float* nsum_out, float* wsum_out, float* ws, int dtype, const float* inv_scale_dev, hipStream_t st) {
+  if (P < 1 || P > NO_PMAX || D % 4 || D > FIN_DMAX) return fail(LATTE_ERR_INVALID, "narrow_outer: need 1 <= P <= 32, D % 4 == 0, D <= 1280");
+  const int nb = narrow_blocks(M), threads = (D / 4 + 63) / 64 * 64;
+  float* part = ws;
+  float* pn = ws + (size_t)nb * P * D;
+  float* pw = pn + (size_t)nb * P;
+  const int lds = (NO_ROWS * D + NO_ROWS * NO_PMAX) * (int)sizeof(float);
+#define NO_CASE(WT, DT)                                                                                                          \
+  {                                                                                                                              \
+    static std::atomic<uint64_t> done{0};                                                                                        \
+    if (int rc = ensure_dynamic_lds((const void*)narrow_outer_kernel<WT, DT>, lds, done)) return rc;                              \
+    hipLaunchKernelGGL((narrow_outer_kernel<WT, DT>), dim3(nb), dim3(threads), lds, st, nar, P, (const WT*)wide, D, M,            \
+                       NO_ROWS_PER_BLOCK, part, so_p, so_k, nsum_out ? pn : nullptr, wsum_out ? pw : nullptr);                   \
+  }
+  if (!wide_half) NO_CASE(float, LATTE_DTYPE_F16)
+  else if (dtype == LATTE_DTYPE_BF16) NO_CASE(half_t, LATTE_DTYPE_BF16)
+  else if (dtype == LATTE_DTYPE_F16) NO_CASE(half_t, LATTE_DTYPE_F16)
+  else return fail(LATTE_ERR_INVALID, "narrow_outer: unknown dtype");
+#undef NO_CASE
+  LATTE_HIP(hipGetLastError());
+  int rc;
+  if ((rc = launch_split_reduce(part, nb, (size_t)P * D, (size_t)P * D, dW, 0, st, inv_scale_dev))) return rc;
+  if (nsum_out && (rc = launch_split_reduce(pn, nb, (size_t)P, (size_t)P, nsum_out, 0, st, inv_scale_dev))) return rc;
+  if (wsum_out && (rc = launch_split_reduce(pw, nb, (size_t)D, (size_t)D, wsum_out, 0, st, inv_scale_dev))) return rc;
+  return LATTE_OK;
+}
+// out[m][k] = half(sum_p nar[m][p] W[p][k])
+int launch_narrow_dx(const float* nar, int P, const float* W, int D, int M, half_t* out, int dtype, hipStream_t st) {
+  if (P < 1 || P > NO_PMAX || D % 4 || D > FIN_DMAX) return fail(LATTE_ERR_INVALID, "narrow_dx: need 1 <= P <= 32, D % 4 == 0, D <= 1280");
+  const int threads = (D / 4 + 63) / 64 * 64;
+  if (dtype == LATTE_DTYPE_BF16)
+    hipLaunchKernelGGL(narrow_dx_kernel<LATTE_DTYPE_BF16>, dim3(narrow_blocks(M)), dim3(threads), 0, st, nar, P, W, D, M, NO_ROWS_PER_BLOCK, out);
+  else if (dtype == LATTE_DTYPE_F16)
+    hipLaunchKernelGGL(narrow_dx_kernel<LATTE_DTYPE_F16>, dim3(narrow_blocks(M)), dim3(threads), 0, st, nar, P, W, D, M, NO_ROWS_PER_BLOCK, out);
+  else return fail(LATTE_ERR_INVALID, "narrow_dx: unknown dtype");
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
