@@ -276,7 +276,9 @@ int launch_gated_add_ln(const float* x_in, const half_t* y, const float* gate, i
 int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gate_stride, half_t* dy, float* partial, float* dgate,
                     int out_stride, int M, int D, int rps, int dtype, hipStream_t st, int bias_partial = 0);
 int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_stride, const float* dx_in, float* dx_out, float* partial,
-                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st);
+                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st,
+                  const half_t* y2 = nullptr, const float* gate2 = nullptr, int gate2_stride = 0, half_t* dy2 = nullptr,
+                  float* gpartial = nullptr);   // y2: + the gated residual's backward of the branch below on the same pass
 int launch_gelu_fwd(const half_t* u, half_t* h, size_t n, int dtype, hipStream_t st);
 int launch_gelu_bwd(const half_t* u, const half_t* dh, half_t* du, size_t n, int dtype, hipStream_t st);
 int colsum_chunks(int M);

@@ -240,38 +240,70 @@ __global__ void __launch_bounds__(256) sample_colsum_finalize_kernel(const float
 // ---------------------------------------------------------------------------------------------- LN + modulate, backward
 // y = LN(x) (1 + scale) + shift.  Given dy (half):  dshift = sum dy, dscale = sum dy * xhat (per sample),
 // dxhat = dy (1 + scale),  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)),  dx_out = dx_in + dx.
-template <int DT>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ dy, const float* __restrict__ x,
+// GATE (round 6b): the gated residual's backward of the branch BELOW this LayerNorm rides on the same pass -- the fresh dx row is
+// still in registers when gate_bwd_kernel would read it back: dy2 = gate2 * dx (half), gpartial[block][0] = sum dx * y2,
+// gpartial[block][1] = sum gate2 * dx (the branch's output-linear bias gradient).  NQ: float4 chunk groups per lane (3: D <= 768).
+template <int DT, int NQ, bool GATE>
+__global__ void __launch_bounds__(256, NQ <= 3 ? 3 : 2) ln_bwd_kernel(const half_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ scale, int mod_stride, const float* dx_in,
-                                                     float* dx_out, float* __restrict__ partial, int M, int D, int rps, int R) {
+                                                     float* dx_out, float* __restrict__ partial, int M, int D, int rps, int R,
+                                                     const half_t* __restrict__ y2, const float* __restrict__ gate2, int gate2_stride,
+                                                     half_t* __restrict__ dy2, float* __restrict__ gpartial) {
   const int lane = threadIdx.x & 63;
   const int run = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row0 = run * R;          // (launcher: M / R is a multiple of 4)
   const int nt = D >> 2;
   const float invD = 1.0f / (float)D;
   const float4* sc4 = (const float4*)(scale + (size_t)(row0 / rps) * mod_stride);
-  float4 sc[NQ_MAX], a_sh[NQ_MAX], a_sc[NQ_MAX];
+  float4 sc[NQ], a_sh[NQ], a_sc[NQ];
+  float4 g2[GATE ? NQ : 1], a_g[GATE ? NQ : 1], a_b[GATE ? NQ : 1];
 #pragma unroll
-  for (int c = 0; c < NQ_MAX; ++c) {
+  for (int c = 0; c < NQ; ++c) {
     const int ch = c * 64 + lane;
     sc[c] = ch < nt ? sc4[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
     a_sh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     a_sc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (GATE) {
+      g2[c] = ch < nt ? ((const float4*)(gate2 + (size_t)(row0 / rps) * gate2_stride))[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+      a_g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a_b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // the next row's x and dy are requested before this row's three dependent wave reductions (round 6b: a block holds ~2.5 waves per
+  // SIMD at the training shapes, so the row chain's load latency was exposed: 55 -> see profiles/r6b_*)
+  float4 nx[NQ];
+  uint2 nd[NQ];
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) {
+    const int ch = c * 64 + lane;
+    nx[c] = ch < nt ? ((const float4*)x)[(size_t)row0 * nt + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    nd[c] = ch < nt ? ((const uint2*)dy)[(size_t)row0 * nt + ch] : make_uint2(0u, 0u);
   }
   for (int r = 0; r < R; ++r) {
     const size_t ro = (size_t)(row0 + r) * nt;
-    float4 v[NQ_MAX], g[NQ_MAX];
+    float4 v[NQ], g[NQ];
+    uint2 dyr[NQ];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < NQ_MAX; ++c) {
-      const int ch = c * 64 + lane;
-      v[c] = ch < nt ? ((const float4*)x)[ro + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < NQ; ++c) {
+      v[c] = nx[c];
+      dyr[c] = nd[c];
       s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    }
+    if (r + 1 < R) {
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nt) {
+          nx[c] = ((const float4*)x)[ro + nt + ch];
+          nd[c] = ((const uint2*)dy)[ro + nt + ch];
+        }
+      }
     }
     const float mean = wave_sum_t(s) * invD;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < NQ_MAX; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       if (c * 64 + lane < nt) {
         v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
         q += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
@@ -280,13 +312,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ 
     const float rstd = 1.0f / sqrtf(wave_sum_t(q) * invD + 1e-6f);
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < NQ_MAX; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = c * 64 + lane;
       g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ch < nt) {
         v[c].x *= rstd; v[c].y *= rstd; v[c].z *= rstd; v[c].w *= rstd;       // xhat
         float a, b, cc, e;
-        unpack4<DT>(((const uint2*)dy)[ro + ch], a, b, cc, e);
+        unpack4<DT>(dyr[c], a, b, cc, e);
         a_sh[c].x += a; a_sh[c].y += b; a_sh[c].z += cc; a_sh[c].w += e;
         a_sc[c].x += a * v[c].x; a_sc[c].y += b * v[c].y; a_sc[c].z += cc * v[c].z; a_sc[c].w += e * v[c].w;
         g[c] = make_float4(a * (1.0f + sc[c].x), b * (1.0f + sc[c].y), cc * (1.0f + sc[c].z), e * (1.0f + sc[c].w));   // dxhat
@@ -297,7 +329,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ 
     m1 = wave_sum_t(m1) * invD;
     m2 = wave_sum_t(m2) * invD;
 #pragma unroll
-    for (int c = 0; c < NQ_MAX; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nt) {
         float4 o = make_float4(rstd * (g[c].x - m1 - v[c].x * m2), rstd * (g[c].y - m1 - v[c].y * m2),
@@ -307,35 +339,63 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const half_t* __restrict__ 
           o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         ((float4*)dx_out)[ro + ch] = o;
+        if constexpr (GATE) {   // gate_bwd_kernel<DT, true>'s row body on the row just written
+          float a, b, cc, e;
+          unpack4<DT>(((const uint2*)y2)[ro + ch], a, b, cc, e);
+          a_g[c].x += o.x * a; a_g[c].y += o.y * b; a_g[c].z += o.z * cc; a_g[c].w += o.w * e;
+          const float4 gd = make_float4(g2[c].x * o.x, g2[c].y * o.y, g2[c].z * o.z, g2[c].w * o.w);
+          a_b[c].x += gd.x; a_b[c].y += gd.y; a_b[c].z += gd.z; a_b[c].w += gd.w;
+          uint2 w;
+          w.x = pack2t<DT>(gd.x, gd.y);
+          w.y = pack2t<DT>(gd.z, gd.w);
+          ((uint2*)dy2)[ro + ch] = w;
+        }
       }
     }
   }
-  extern __shared__ __attribute__((aligned(16))) float red_t[];   // [3 waves][2][D]
+  extern __shared__ __attribute__((aligned(16))) float red_t[];   // [3 waves][2 or 4][D]
+  constexpr int NS = GATE ? 4 : 2;
   const int wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int c = 0; c < NQ_MAX; ++c) {
+  for (int c = 0; c < NQ; ++c) {
     const int ch = c * 64 + lane;
     if (ch < nt && wv > 0) {
-      ((float4*)(red_t + ((size_t)(wv - 1) * 2 + 0) * D))[ch] = a_sh[c];
-      ((float4*)(red_t + ((size_t)(wv - 1) * 2 + 1) * D))[ch] = a_sc[c];
+      ((float4*)(red_t + ((size_t)(wv - 1) * NS + 0) * D))[ch] = a_sh[c];
+      ((float4*)(red_t + ((size_t)(wv - 1) * NS + 1) * D))[ch] = a_sc[c];
+      if constexpr (GATE) {
+        ((float4*)(red_t + ((size_t)(wv - 1) * NS + 2) * D))[ch] = a_g[c];
+        ((float4*)(red_t + ((size_t)(wv - 1) * NS + 3) * D))[ch] = a_b[c];
+      }
     }
   }
   __syncthreads();
   if (wv == 0) {
 #pragma unroll
-    for (int c = 0; c < NQ_MAX; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nt) {
         float4 a = a_sh[c], b = a_sc[c];
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
-          const float4 o = ((const float4*)(red_t + ((size_t)w * 2 + 0) * D))[ch];
-          const float4 q = ((const float4*)(red_t + ((size_t)w * 2 + 1) * D))[ch];
+          const float4 o = ((const float4*)(red_t + ((size_t)w * NS + 0) * D))[ch];
+          const float4 q = ((const float4*)(red_t + ((size_t)w * NS + 1) * D))[ch];
           a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
           b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
         }
         ((float4*)(partial + ((size_t)blockIdx.x * 2 + 0) * D))[ch] = a;
         ((float4*)(partial + ((size_t)blockIdx.x * 2 + 1) * D))[ch] = b;
+        if constexpr (GATE) {
+          float4 e = a_g[c], f = a_b[c];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            const float4 o = ((const float4*)(red_t + ((size_t)w * NS + 2) * D))[ch];
+            const float4 q = ((const float4*)(red_t + ((size_t)w * NS + 3) * D))[ch];
+            e.x += o.x; e.y += o.y; e.z += o.z; e.w += o.w;
+            f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+          }
+          ((float4*)(gpartial + ((size_t)blockIdx.x * 2 + 0) * D))[ch] = e;
+          ((float4*)(gpartial + ((size_t)blockIdx.x * 2 + 1) * D))[ch] = f;
+        }
       }
     }
   }
@@ -386,6 +446,7 @@ __global__ void __launch_bounds__(256) colsum_half_kernel(const half_t* __restri
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col0 < C) {
     const int rend = min(r0 + CS_ROWS, M);
+#pragma unroll 8
     for (int r = r0 + ty; r < rend; r += 16) {
       const uint4 p = *(const uint4*)(in + (size_t)r * C + col0);
       float v[8];
@@ -839,15 +900,28 @@ int launch_gate_bwd(const float* dx, const half_t* y, const float* gate, int gat
   return LATTE_OK;
 }
 
-// partial: float [M / R][2][D];  dshift / dscale: [B][out_stride] (assigned)
+// partial: float [M / (4 R)][2][D];  dshift / dscale: [B][out_stride] (assigned) or nullptr (no finalize launches).
+// y2 != nullptr: the gated residual's backward of the branch below rides on the pass (dy2 = gate2 * dx_out in half,
+// gpartial [M / (4 R)][2][D] = {sum dx * y2, sum gate2 * dx} per block of 4 runs) -- gate_bwd_kernel<DT, true> without re-reading dx
 int launch_ln_bwd(const half_t* dy, const float* x, const float* scale, int mod_stride, const float* dx_in, float* dx_out, float* partial,
-                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st) {
+                  float* dshift, float* dscale, int out_stride, int M, int D, int rps, int dtype, hipStream_t st, const half_t* y2,
+                  const float* gate2, int gate2_stride, half_t* dy2, float* gpartial) {
   if (D % 4 || D > NQ_MAX * 256) return fail(LATTE_ERR_INVALID, "ln_bwd: need D % 4 == 0 and D <= 1280");
   const int R = train_rows_per_run(rps), runs = M / R;
   if (rps % (4 * R)) return fail(LATTE_ERR_INVALID, "ln_bwd: rows per sample must be a multiple of 4 runs");
-#define CALL(DT) hipLaunchKernelGGL(ln_bwd_kernel<DT>, dim3(runs / 4), dim3(256), 6 * D * sizeof(float), st, dy, x, scale, mod_stride, dx_in, dx_out, partial, M, D, rps, R)
+  if (y2 && (!gate2 || !dy2 || !gpartial)) return fail(LATTE_ERR_INVALID, "ln_bwd: the gated form needs gate2, dy2 and gpartial");
+  const int ns = y2 ? 4 : 2;
+#define CALLQ(DT, NQ)                                                                                                                  \
+  if (y2) hipLaunchKernelGGL((ln_bwd_kernel<DT, NQ, true>), dim3(runs / 4), dim3(256), 3 * ns * D * sizeof(float), st, dy, x, scale,   \
+                             mod_stride, dx_in, dx_out, partial, M, D, rps, R, y2, gate2, gate2_stride, dy2, gpartial);                \
+  else hipLaunchKernelGGL((ln_bwd_kernel<DT, NQ, false>), dim3(runs / 4), dim3(256), 3 * ns * D * sizeof(float), st, dy, x, scale,     \
+                          mod_stride, dx_in, dx_out, partial, M, D, rps, R, y2, gate2, gate2_stride, dy2, gpartial)
+#define CALL(DT)                       \
+  if (D <= 768) { CALLQ(DT, 3); }      \
+  else { CALLQ(DT, NQ_MAX); }
   LATTE_DT_SWITCH(dtype, CALL);
 #undef CALL
+#undef CALLQ
   if (dshift) {   // nullptr: the stage's finalize kernel reads the partial rows
     hipLaunchKernelGGL(sample_colsum_finalize_kernel, dim3((D + 63) / 64, M / rps), dim3(256), 0, st, partial, rps / (4 * R), 2, 0, D, dshift,
                        out_stride);

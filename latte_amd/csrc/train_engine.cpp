@@ -55,7 +55,7 @@ struct latte_trainer {
   // row-run / column partials of a stage stay in their own buffers until its end, the adaLN linear's input gradient is one batched
   // product at the last stage, the loss-scale pass of the block slices rides on the kernels that write them, one weight-pack launch
   int fuse_small = 1;
-  float *pg1 = nullptr, *pl1 = nullptr, *pg2 = nullptr, *pl2 = nullptr, *pc_fc1 = nullptr, *pc_qkv = nullptr, *dc_ws = nullptr, *no_ws = nullptr;
+  float *pg1 = nullptr, *pl1 = nullptr, *pg2 = nullptr, *pg2b = nullptr, *pl2 = nullptr, *pc_fc1 = nullptr, *pc_qkv = nullptr, *dc_ws = nullptr, *no_ws = nullptr;
   PackDesc* pack_descs = nullptr;
   PackPlan pack_plan{};
   float growth_interval = 2000.0f;
@@ -242,7 +242,7 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   A(&e->part_cols, (size_t)(colsum_chunks((int)e->rows_max) + 1) * std::max(Hm, 3 * D));
   {
     const size_t pr = (size_t)(e->rows_max / Rr / 4 + 1) * 2 * D;   // one block of 4 runs -> 2 partial rows
-    A(&e->pg1, pr); A(&e->pl1, pr); A(&e->pg2, pr); A(&e->pl2, pr);
+    A(&e->pg1, pr); A(&e->pl1, pr); A(&e->pg2, pr); A(&e->pg2b, pr); A(&e->pl2, pr);
     A(&e->pc_fc1, (size_t)(colsum_chunks((int)e->rows_max) + 1) * Hm);
     A(&e->pc_qkv, (size_t)(colsum_chunks((int)e->rows_max) + 1) * 3 * D);
     A(&e->dc_ws, (size_t)adaln_dc_splits(e->nmod) * Bm * D);
@@ -577,7 +577,11 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
   {
     float* dm = e->dmod + (size_t)c.depth * 6 * D;
     if (e->fuse_small) {   // shift / scale gradients of the final modulation and its adaLN linear's bias / weight gradients in one launch
-      if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st))) return rc;
+      {   // ... and the gated residual's backward of the last block's MLP branch on the same pass over dx (its stage starts at the wgrad)
+        const int il = c.depth - 1;
+        if ((rc = launch_ln_bwd(e->dxnH, xl, fm + D, nmod, nullptr, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st, e->blk[il].y2,
+                                e->mod + (size_t)il * 6 * D + 5 * D, nmod, e->dyD, (il & 1) ? e->pg2b : e->pg2))) return rc;
+      }
       StageFinArgs a{};
       a.mod_src[0] = a.mod_src[1] = e->pl1; a.mod_nsum[0] = a.mod_nsum[1] = 2; a.mod_which[0] = 0; a.mod_which[1] = 1;
       a.n_mod = 2; a.rows_per_sample = rps / (4 * train_rows_per_run(rps)); a.B = B; a.D = D;
@@ -599,8 +603,9 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
     float* dm = e->dmod + (size_t)i * 6 * D;
     if (e->fuse_small) {
       const bool us = scaling_active(e);
-      // ---- MLP branch: x2 = x1 + g2 * (fc2(gelu(fc1(xn2))));  the gate / bias partial rows wait for the stage's finalize launch
-      if ((rc = launch_gate_bwd(e->dx, b.y2, mb + 5 * D, nmod, e->dyD, e->pg2, nullptr, nmod, M, D, rps, dt, st, 1))) return rc;
+      // ---- MLP branch: x2 = x1 + g2 * (fc2(gelu(fc1(xn2)))).  dy = g2 dx and the gate / bias partial rows were left by the LayerNorm
+      // backward that produced dx (the previous stage's last pass); the partial rows wait for this stage's finalize launch
+      float* pg2 = (i & 1) ? e->pg2b : e->pg2;
       if ((rc = wgrad(e, e->dyD, b.h, M, D, Hm, G_(e, p + "mlp.fc2.weight"), st, us))) return rc;
       if (gelu_fusable(e, M, Hm, D)) {
         if ((rc = gemm_gelu(e, EPI_DGELU_H16, e->dyD, b.fc2_wt, e->zeros, e->dhH, b.u, M, Hm, D, st))) return rc;
@@ -611,10 +616,9 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       if ((rc = launch_colsum_half(e->dhH, M, Hm, e->pc_fc1, nullptr, 0, dt, st))) return rc;
       if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st, us))) return rc;
       if ((rc = gemm_half(e, e->dhH, b.fc1_wt, e->zeros, e->dxnH, M, D, Hm, st))) return rc;
-      if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i + 1], mb + 4 * D, nmod, e->dx, e->dx, e->pl2, nullptr, nullptr, nmod, M, D, rps, dt, st)))
-        return rc;
-      // ---- attention branch: x1 = x0 + g1 * proj(attn(qkv(xn1)))
-      if ((rc = launch_gate_bwd(e->dx, b.y1, mb + 2 * D, nmod, e->dyD, e->pg1, nullptr, nmod, M, D, rps, dt, st, 1))) return rc;
+      // ---- attention branch: x1 = x0 + g1 * proj(attn(qkv(xn1))): its gate backward rides on LN2's backward
+      if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i + 1], mb + 4 * D, nmod, e->dx, e->dx, e->pl2, nullptr, nullptr, nmod, M, D, rps, dt, st,
+                              b.y1, mb + 2 * D, nmod, e->dyD, e->pg1))) return rc;
       if ((rc = wgrad(e, e->dyD, b.att, M, D, D, G_(e, p + "attn.proj.weight"), st, us))) return rc;
       if ((rc = gemm_half(e, e->dyD, b.proj_wt, e->zeros, e->dxnH, M, D, D, st))) return rc;   // d(attention output)
       if (spatial) rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * F, T, c.num_heads, e->hd, F, rps, T, 1, dt, st);
@@ -623,10 +627,15 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       if ((rc = launch_colsum_half(e->dqkvH, M, 3 * D, e->pc_qkv, nullptr, 0, dt, st))) return rc;
       if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st, us))) return rc;
       if ((rc = gemm_half(e, e->dqkvH, b.qkv_wt, e->zeros, e->dxnH, M, D, 3 * D, st))) return rc;
-      if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st))) return rc;
+      if (i > 0) {   // LN1's backward + the gate backward of block i - 1's MLP branch (the next stage's first step)
+        if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st,
+                                e->blk[i - 1].y2, e->mod + (size_t)(i - 1) * 6 * D + 5 * D, nmod, e->dyD, ((i - 1) & 1) ? e->pg2b : e->pg2)))
+          return rc;
+      } else if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st)))
+        return rc;
       // ---- one launch: the six modulation gradients, the adaLN linear's bias / weight gradients, the four linears' bias gradients
       StageFinArgs a{};
-      const float* msrc[6] = {e->pl1, e->pl1, e->pg1, e->pl2, e->pl2, e->pg2};
+      const float* msrc[6] = {e->pl1, e->pl1, e->pg1, e->pl2, e->pl2, pg2};
       const int mwhich[6] = {0, 1, 0, 0, 1, 0};
       for (int k = 0; k < 6; ++k) { a.mod_src[k] = msrc[k]; a.mod_nsum[k] = 2; a.mod_which[k] = mwhich[k]; }
       const int rb = rps / (4 * train_rows_per_run(rps));   // partial rows (blocks of 4 runs) per sample
@@ -638,7 +647,7 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       a.bias_src[0] = e->pc_qkv;   a.bias_rows[0] = ch;     a.bias_stride[0] = 3 * D; a.bias_cols[0] = 3 * D; a.bias_out[0] = G_(e, p + "attn.qkv.bias");
       a.bias_src[1] = e->pg1 + D;  a.bias_rows[1] = B * rb; a.bias_stride[1] = 2 * D; a.bias_cols[1] = D;     a.bias_out[1] = G_(e, p + "attn.proj.bias");
       a.bias_src[2] = e->pc_fc1;   a.bias_rows[2] = ch;     a.bias_stride[2] = Hm;    a.bias_cols[2] = Hm;    a.bias_out[2] = G_(e, p + "mlp.fc1.bias");
-      a.bias_src[3] = e->pg2 + D;  a.bias_rows[3] = B * rb; a.bias_stride[3] = 2 * D; a.bias_cols[3] = D;     a.bias_out[3] = G_(e, p + "mlp.fc2.bias");
+      a.bias_src[3] = pg2 + D;      a.bias_rows[3] = B * rb; a.bias_stride[3] = 2 * D; a.bias_cols[3] = D;     a.bias_out[3] = G_(e, p + "mlp.fc2.bias");
       a.scaler = us ? e->scaler : nullptr;
       return launch_stage_finalize(a, st);
     }
