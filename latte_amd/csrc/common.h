@@ -334,7 +334,9 @@ int launch_adamw_ema(float* p, float* g, float* m, float* v, float* ema, size_t 
 // dW[N, K] = dY[M, N]^T X[M, K] without transposed copies (gemm_tn.hip); partial: float [ceil(M / m_chunk)][N][K]
 int gemm_tn_tile_n();   // rows of dW per workgroup tile (for the caller's split heuristic)
 int gemm_tn_plan(int M, int N, int K, int* chunk);   // -> splits of the contraction, *chunk = rows per split
-int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st);
+int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st,
+                   float* colsum_partial = nullptr);   // colsum_partial: [splits][N] column sums of dY per split (8-wave kernel only)
+bool gemm_tn8_ok(int M, int N, int K);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout, half_t* dqkv, float* stats, int num_seq, int L, int heads,
                          int hd, int U, int64_t sample_stride, int64_t seq_stride, int64_t row_stride, int dtype, hipStream_t st);
 

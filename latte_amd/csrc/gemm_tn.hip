@@ -32,6 +32,7 @@ struct TnArgs {
   const half_t* X;    // [M, K]
   float* out;         // [splits][N][K] partial products
   int M, N, K, m_chunk;
+  float* colsum;      // gemm_tn8_kernel<DT, true>: [splits][N] column sums of dY over the split's rows (the bias gradient's partials)
 };
 
 template <int DT, int WN>   // WN = 2 | 4 wave rows: output tile 64 WN (n) x 128 (k), 2 WN waves
@@ -160,7 +161,23 @@ __device__ __forceinline__ void dma16tn(__amdgpu_buffer_rsrc_t rs, char* lds_wav
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_tn*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// COLSUM (round 6b): the bias gradient db[n] = sum_m dY[m, n] rides on the launch -- the dY fragments of a K step are in registers
+// anyway (lane (fl, gq) holds column 16 i + fl, rows 32 ks + 4 gq + {0..3, 16..19}), so wave 0 of each group in the k-tile-0
+// workgroups adds its 8 halves per fragment with four v_dot2c_f32_f16 against (1, 1) (fp32 accumulate) between the MFMAs; 8 extra
+// registers, no extra memory traffic.  The separate column-sum kernel read dY a second time: 0.69 ms per Latte-B/2 step.
 template <int DT>
+__device__ __forceinline__ float dot2_ones(unsigned int w, float acc) {
+  if constexpr (DT == LATTE_DTYPE_BF16) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2t;
+    const b2t one = {(__bf16)1.0f, (__bf16)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2t, w), one, acc, false);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2t;
+    const h2t one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2t, w), one, acc, false);
+  }
+}
+template <int DT, bool COLSUM>
 __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
   constexpr int HALF = 64 * 256;             // one half-image: 64 rows x 256 B
   constexpr int STG = 4 * HALF;              // dY half 0 | dY half 1 | X half 0 | X half 1
@@ -229,6 +246,13 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  float cs[COLSUM ? 8 : 1];
+  const bool do_cs = COLSUM && wk == 0 && tk == 0 && y_ok;   // wave-uniform
+  if constexpr (COLSUM) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[i] = 0.f;
+  }
+
   dma_y(0, 0);
   if (grp == 0) dma_x(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,6 +290,19 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(kf[ks][j], nf[ks][i], acc[i][j]);   // D[k = 4 gq + r][n = fl]
+    if constexpr (COLSUM) {
+      if (do_cs) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float a = cs[i];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a = dot2_ones<DT>(nf[ks][i][w], a);
+            cs[i] = a;
+          }
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -275,6 +312,17 @@ __global__ void __launch_bounds__(512) gemm_tn8_kernel(TnArgs g) {
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's extra barrier
+  if constexpr (COLSUM) {
+    if (do_cs) {   // the four row quarters (gq) of a column, fixed order
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v = cs[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (gq == 0) g.colsum[(size_t)split * g.N + n0 + grp * 128 + i * 16 + fl] = v;
+      }
+    }
+  }
   // lane holds dW[n = n0 + 128 grp + 16 i + fl][k = k0 + 64 wk + 16 j + 4 gq + {0..3}]
   if (y_ok && k_ok) {
 #pragma unroll
@@ -317,21 +365,24 @@ int gemm_tn_plan(int M, int N, int K, int* chunk) {
 int gemm_tn_tile_n() {
   return debug_choice(DBG_TN_WN) == 4 ? 256 : 128;     // latte_debug_set_choice("tn_wn", 4): the 8-wave 256 x 128 tile (A/B)
 }
-int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st) {
+// colsum_partial (optional, only where gemm_tn8_ok(M, N, K)): float [splits][N] receives the column sums of dY per split
+int launch_gemm_tn(const half_t* dY, const half_t* X, float* partial, int M, int N, int K, int m_chunk, int dtype, hipStream_t st,
+                   float* colsum_partial) {
   if (K % 128 || N % 8 || m_chunk % 64 || m_chunk <= 0) return fail(LATTE_ERR_INVALID, "gemm_tn: need K % 128 == 0, N % 8 == 0, m_chunk % 64 == 0");
-  TnArgs a{dY, X, partial, M, N, K, m_chunk};
+  TnArgs a{dY, X, partial, M, N, K, m_chunk, colsum_partial};
   const int splits = (M + m_chunk - 1) / m_chunk;
+  if (colsum_partial && !gemm_tn8_ok(M, N, K)) return fail(LATTE_ERR_INVALID, "gemm_tn: column sums ride on the 8-wave kernel only");
   if (gemm_tn8_ok(M, N, K)) {
     constexpr int LDS8 = 2 * 4 * 64 * 256;
     dim3 grid8(((N + 255) / 256) * ((K + 255) / 256) * splits), block8(512);   // 1-D: the kernel maps workgroups to (split, tile)
-#define LATTE_TN8_CASE(DT)                                                                          \
+#define LATTE_TN8_CASE(DT, CS)                                                                      \
   {                                                                                                 \
     static std::atomic<uint64_t> done{0};                                                           \
-    if (int rc = ensure_dynamic_lds((const void*)gemm_tn8_kernel<DT>, LDS8, done)) return rc;       \
-    hipLaunchKernelGGL((gemm_tn8_kernel<DT>), grid8, block8, LDS8, st, a);                          \
+    if (int rc = ensure_dynamic_lds((const void*)gemm_tn8_kernel<DT, CS>, LDS8, done)) return rc;   \
+    hipLaunchKernelGGL((gemm_tn8_kernel<DT, CS>), grid8, block8, LDS8, st, a);                      \
   }
-    if (dtype == LATTE_DTYPE_BF16) LATTE_TN8_CASE(LATTE_DTYPE_BF16)
-    else if (dtype == LATTE_DTYPE_F16) LATTE_TN8_CASE(LATTE_DTYPE_F16)
+    if (dtype == LATTE_DTYPE_BF16) { if (colsum_partial) LATTE_TN8_CASE(LATTE_DTYPE_BF16, true) else LATTE_TN8_CASE(LATTE_DTYPE_BF16, false) }
+    else if (dtype == LATTE_DTYPE_F16) { if (colsum_partial) LATTE_TN8_CASE(LATTE_DTYPE_F16, true) else LATTE_TN8_CASE(LATTE_DTYPE_F16, false) }
     else return fail(LATTE_ERR_INVALID, "gemm_tn: unknown dtype");
 #undef LATTE_TN8_CASE
     LATTE_HIP(hipGetLastError());

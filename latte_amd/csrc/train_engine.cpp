@@ -132,11 +132,14 @@ int gemm_gelu(latte_trainer* e, int epi, const half_t* A, const half_t* W, const
 // dW[N, K] = dY[M, N]^T X[M, K] on the transposed-operand GEMM (gemm_tn.hip: no transposed copies), the contraction split so
 // that about four workgroups per CU are in flight; the partial products are reduced in a fixed order; result ASSIGNED to dW
 // (unscale: the reduction also takes the result out of the loss-scaled domain, x 1 / scaler[0])
-int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st, bool unscale = false) {
+// cs_partial / cs_rows: the column sums of dY per split ([*cs_rows][N]: the bias gradient's partial rows) ride on the launch
+int wgrad(latte_trainer* e, const half_t* dY, const half_t* X, int M, int N, int K, float* dW, hipStream_t st, bool unscale = false,
+          float* cs_partial = nullptr, int* cs_rows = nullptr) {
   int rc, chunk = 0;
   const int splits = gemm_tn_plan(M, N, K, &chunk);
   if ((int64_t)splits * N * K > e->wg_ws_floats) return fail(LATTE_ERR_STATE, "wgrad: workspace too small");
-  if ((rc = launch_gemm_tn(dY, X, e->wg_ws, M, N, K, chunk, e->dt, st))) return rc;
+  if (cs_rows) *cs_rows = splits;
+  if ((rc = launch_gemm_tn(dY, X, e->wg_ws, M, N, K, chunk, e->dt, st, cs_partial))) return rc;
   return launch_split_reduce(e->wg_ws, splits, (size_t)N * K, (size_t)N * K, dW, 0, st, unscale ? e->scaler : nullptr);
 }
 
@@ -243,8 +246,9 @@ int latte_trainer_create(const latte_model_config_t* cfg, int max_batch, latte_t
   {
     const size_t pr = (size_t)(e->rows_max / Rr / 4 + 1) * 2 * D;   // one block of 4 runs -> 2 partial rows
     A(&e->pg1, pr); A(&e->pl1, pr); A(&e->pg2, pr); A(&e->pg2b, pr); A(&e->pl2, pr);
-    A(&e->pc_fc1, (size_t)(colsum_chunks((int)e->rows_max) + 1) * Hm);
-    A(&e->pc_qkv, (size_t)(colsum_chunks((int)e->rows_max) + 1) * 3 * D);
+    const size_t pcr = (size_t)std::max(colsum_chunks((int)e->rows_max) + 1, 260);   // column-sum chunks or weight-gradient splits (<= 256)
+    A(&e->pc_fc1, pcr * Hm);
+    A(&e->pc_qkv, pcr * 3 * D);
     A(&e->dc_ws, (size_t)adaln_dc_splits(e->nmod) * Bm * D);
     A(&e->no_ws, (size_t)narrow_blocks((int)e->rows_max) * ((size_t)32 * D + 32 + D));
     A(&e->pack_descs, (size_t)c.depth * 4);
@@ -613,8 +617,12 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
         if ((rc = gemm_half(e, e->dyD, b.fc2_wt, e->zeros, e->dhH, M, Hm, D, st))) return rc;
         if ((rc = launch_gelu_bwd(b.u, e->dhH, e->dhH, (size_t)M * Hm, dt, st))) return rc;
       }
-      if ((rc = launch_colsum_half(e->dhH, M, Hm, e->pc_fc1, nullptr, 0, dt, st))) return rc;
-      if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st, us))) return rc;
+      // bias gradients of fc1 / qkv: column sums of dY on the weight-gradient launch where the 8-wave kernel takes the shape
+      int fc1_rows = colsum_chunks(M), qkv_rows = colsum_chunks(M);
+      const bool cs_fc1 = gemm_tn8_ok(M, Hm, D), cs_qkv = gemm_tn8_ok(M, 3 * D, D);
+      if (!cs_fc1 && (rc = launch_colsum_half(e->dhH, M, Hm, e->pc_fc1, nullptr, 0, dt, st))) return rc;
+      if ((rc = wgrad(e, e->dhH, b.xn2, M, Hm, D, G_(e, p + "mlp.fc1.weight"), st, us, cs_fc1 ? e->pc_fc1 : nullptr, cs_fc1 ? &fc1_rows : nullptr)))
+        return rc;
       if ((rc = gemm_half(e, e->dhH, b.fc1_wt, e->zeros, e->dxnH, M, D, Hm, st))) return rc;
       // ---- attention branch: x1 = x0 + g1 * proj(attn(qkv(xn1))): its gate backward rides on LN2's backward
       if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i + 1], mb + 4 * D, nmod, e->dx, e->dx, e->pl2, nullptr, nullptr, nmod, M, D, rps, dt, st,
@@ -624,8 +632,9 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       if (spatial) rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * F, T, c.num_heads, e->hd, F, rps, T, 1, dt, st);
       else         rc = launch_attention_bwd(b.qkv, b.att, e->dxnH, e->dqkvH, e->attn_stats, B * T, F, c.num_heads, e->hd, T, rps, 1, T, dt, st);
       if (rc) return rc;
-      if ((rc = launch_colsum_half(e->dqkvH, M, 3 * D, e->pc_qkv, nullptr, 0, dt, st))) return rc;
-      if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st, us))) return rc;
+      if (!cs_qkv && (rc = launch_colsum_half(e->dqkvH, M, 3 * D, e->pc_qkv, nullptr, 0, dt, st))) return rc;
+      if ((rc = wgrad(e, e->dqkvH, b.xn1, M, 3 * D, D, G_(e, p + "attn.qkv.weight"), st, us, cs_qkv ? e->pc_qkv : nullptr,
+                      cs_qkv ? &qkv_rows : nullptr))) return rc;
       if ((rc = gemm_half(e, e->dqkvH, b.qkv_wt, e->zeros, e->dxnH, M, D, 3 * D, st))) return rc;
       if (i > 0) {   // LN1's backward + the gate backward of block i - 1's MLP branch (the next stage's first step)
         if ((rc = launch_ln_bwd(e->dxnH, e->xs[2 * i], mb + D, nmod, e->dx, e->dx, e->pl1, nullptr, nullptr, nmod, M, D, rps, dt, st,
@@ -642,11 +651,10 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       a.n_mod = 6; a.rows_per_sample = rb; a.B = B; a.D = D;
       a.dmod = dm; a.dmod_stride = nmod; a.csilu = e->csilu;
       a.dW = G_(e, p + "adaLN_modulation.1.weight"); a.db = G_(e, p + "adaLN_modulation.1.bias");
-      const int ch = colsum_chunks(M);
       a.n_bias = 4;
-      a.bias_src[0] = e->pc_qkv;   a.bias_rows[0] = ch;     a.bias_stride[0] = 3 * D; a.bias_cols[0] = 3 * D; a.bias_out[0] = G_(e, p + "attn.qkv.bias");
+      a.bias_src[0] = e->pc_qkv;   a.bias_rows[0] = qkv_rows;   a.bias_stride[0] = 3 * D; a.bias_cols[0] = 3 * D; a.bias_out[0] = G_(e, p + "attn.qkv.bias");
       a.bias_src[1] = e->pg1 + D;  a.bias_rows[1] = B * rb; a.bias_stride[1] = 2 * D; a.bias_cols[1] = D;     a.bias_out[1] = G_(e, p + "attn.proj.bias");
-      a.bias_src[2] = e->pc_fc1;   a.bias_rows[2] = ch;     a.bias_stride[2] = Hm;    a.bias_cols[2] = Hm;    a.bias_out[2] = G_(e, p + "mlp.fc1.bias");
+      a.bias_src[2] = e->pc_fc1;   a.bias_rows[2] = fc1_rows;   a.bias_stride[2] = Hm;    a.bias_cols[2] = Hm;    a.bias_out[2] = G_(e, p + "mlp.fc1.bias");
       a.bias_src[3] = pg2 + D;      a.bias_rows[3] = B * rb; a.bias_stride[3] = 2 * D; a.bias_cols[3] = D;     a.bias_out[3] = G_(e, p + "mlp.fc2.bias");
       a.scaler = us ? e->scaler : nullptr;
       return launch_stage_finalize(a, st);
