@@ -792,6 +792,17 @@ def main():
         torch.cuda.synchronize()
         side["config5"] = {"ms_per_step": (time.perf_counter() - t5) / n5 * 1e3, "steps": n5,
                            "loss_finite": bool(torch.isfinite(o5["loss"]).all())}
+        # the same step with the small-kernel consolidation of round 6b off (trainer option fuse_small = 0: the separate finalize /
+        # column-sum / adaLN / gate-backward launches of rounds 2 - 6), interleaved on this box
+        trn.set_option("fuse_small", 0)
+        for _ in range(2):
+            trn.train_step(x5)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(n5):
+            trn.train_step(x5)
+        torch.cuda.synchronize()
+        side["config5"]["ms_per_step_separate_launches"] = (time.perf_counter() - t5) / n5 * 1e3
         del trn, m5
         torch.cuda.empty_cache()
         if dist is not None:   # max over ranks of every side timing
@@ -860,7 +871,10 @@ def main():
                                   "value": round(world * tb / (v["ms_per_step"] * 1e-3), 3), "unit": "training samples/s",
                                   "ms_per_step": round(v["ms_per_step"], 3), "steps": v["steps"], "global_batch": tb * world,
                                   "algorithmic_tflops_per_gpu": round(3 * fwd5 / (v["ms_per_step"] * 1e-3) / 1e12, 1),
-                                  "loss_finite": v.get("loss_finite")}
+                                  "loss_finite": v.get("loss_finite"),
+                                  "fuse_small_0": {"ms_per_step": round(v.get("ms_per_step_separate_launches", 0.0), 3),
+                                                   "note": "trainer option fuse_small = 0 (the separate finalize / column-sum / adaLN / gate-backward "
+                                                           "launches of rounds 2 - 6) on the same box; the default folds them (latte_amd/csrc/train_fin.hip)"}}
             else:
                 res[k] = {"value": round(world * v.get("batch", B) / (v["ms_per_step"] * 1e-3), 3), "unit": "sample-steps/s",
                           "ms_per_step": round(v["ms_per_step"], 4), "steps": v["steps"]}

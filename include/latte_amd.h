@@ -276,7 +276,12 @@ int latte_trainer_backward_stage(latte_trainer_t* e, int stage, void* stream);
  * with (train.py:12-14 allow_tf32), bf16 has 7; the reference itself needs no scaling because it keeps fp32 ranges.
  * "dynamic_loss_scale" (0 / 1; default 1 with f16, 0 with bf16): a skipped update halves the scale (floor 1), and
  * "loss_scale_growth_interval" (default 2000) applied updates in a row double it (cap max(initial scale, 2^16)) -- all on the
- * device, no host round trip.  Setting "loss_scale" restarts from that value. */
+ * device, no host round trip.  Setting "loss_scale" restarts from that value.
+ * "fuse_gelu" (default 1): the MLP's GELU passes inside the fc1 forward / fc2 input-gradient GEMM epilogues.
+ * "fuse_small" (default 1, round 6b): the step's tiny launches folded (csrc/train_fin.hip) -- one finalize launch per block
+ * stage, the gated residual's backward on the LayerNorm backward's pass, gated add + next LayerNorm in one forward pass, fc1 / qkv
+ * bias gradients on the weight-gradient launch, one weight-pack launch; 0 = the separate launches (A/B tests); refused while a
+ * step is in flight (between latte_trainer_begin and the last backward stage).  Gradients agree with the separate path to 2e-4. */
 int latte_trainer_set_option(latte_trainer_t* e, const char* name, double value);
 /* out8 (host) = {loss scale, applied updates since it changed, applied updates in total, skipped updates, last call skipped (0/1),
  * dynamic (0/1), growth interval, largest scale}.  Synchronises the device: for logging and tests, not for the step path. */

@@ -128,7 +128,9 @@ class LatteTrainer:
 
     def set_option(self, name, value):
         """Engine options of the trainer (latte_trainer_set_option): "loss_scale", "dynamic_loss_scale", "loss_scale_growth_interval",
-        "fuse_gelu" (0: separate GELU passes, 1: inside the fc1 / fc2-gradient GEMMs -- the default)."""
+        "fuse_gelu" (0: separate GELU passes, 1: inside the fc1 / fc2-gradient GEMMs -- the default), "fuse_small" (0: the
+        separate finalize / column-sum / adaLN / gate-backward launches of rounds 2 - 6, 1: folded -- the default, csrc/train_fin.hip;
+        not while a step is in flight)."""
         check(load_library().latte_trainer_set_option(self._h, name.encode(), float(value)))
 
     def __del__(self):
