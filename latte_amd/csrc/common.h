@@ -291,7 +291,6 @@ int launch_pack_weight(const float* w, half_t* wn, half_t* wt, int N, int K, int
 struct StageFinArgs {
   const float* mod_src[6];   // per modulation chunk: row-run partials [B rows_per_sample][nsum][D]
   int mod_nsum[6], mod_which[6];
-  float* mod_bias_out[6];    // gate chunks (nsum 2, which 0): out[col] = sum over every partial row of row 1 (the branch's output-linear bias gradient), or nullptr
   int n_mod, rows_per_sample, B, D;
   float* dmod;               // [B][dmod_stride], this linear's first column (assigned, loss-scaled domain)
   int dmod_stride;

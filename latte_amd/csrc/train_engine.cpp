@@ -651,12 +651,11 @@ static int backward_stage_impl(latte_trainer_t* e, int stage, void* stream) {
       a.n_mod = 6; a.rows_per_sample = rb; a.B = B; a.D = D;
       a.dmod = dm; a.dmod_stride = nmod; a.csilu = e->csilu;
       a.dW = G_(e, p + "adaLN_modulation.1.weight"); a.db = G_(e, p + "adaLN_modulation.1.bias");
-      // proj / fc2 bias gradients: the second partial row of the gate backwards, summed by the gate chunks' own blocks
-      a.mod_bias_out[2] = G_(e, p + "attn.proj.bias");
-      a.mod_bias_out[5] = G_(e, p + "mlp.fc2.bias");
-      a.n_bias = 2;
+      a.n_bias = 4;
       a.bias_src[0] = e->pc_qkv;   a.bias_rows[0] = qkv_rows;   a.bias_stride[0] = 3 * D; a.bias_cols[0] = 3 * D; a.bias_out[0] = G_(e, p + "attn.qkv.bias");
-      a.bias_src[1] = e->pc_fc1;   a.bias_rows[1] = fc1_rows;   a.bias_stride[1] = Hm;    a.bias_cols[1] = Hm;    a.bias_out[1] = G_(e, p + "mlp.fc1.bias");
+      a.bias_src[1] = e->pg1 + D;  a.bias_rows[1] = B * rb; a.bias_stride[1] = 2 * D; a.bias_cols[1] = D;     a.bias_out[1] = G_(e, p + "attn.proj.bias");
+      a.bias_src[2] = e->pc_fc1;   a.bias_rows[2] = fc1_rows;   a.bias_stride[2] = Hm;    a.bias_cols[2] = Hm;    a.bias_out[2] = G_(e, p + "mlp.fc1.bias");
+      a.bias_src[3] = pg2 + D;      a.bias_rows[3] = B * rb; a.bias_stride[3] = 2 * D; a.bias_cols[3] = D;     a.bias_out[3] = G_(e, p + "mlp.fc2.bias");
       a.scaler = us ? e->scaler : nullptr;
       return launch_stage_finalize(a, st);
     }

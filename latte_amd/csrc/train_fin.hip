@@ -52,42 +52,17 @@ __global__ void __launch_bounds__(1024) stage_finalize_kernel(StageFinArgs a) {
     const int nsum = a.mod_nsum[chunk], which = a.mod_which[chunk], rows = a.rows_per_sample;
     for (int bs = 0; bs < a.B; bs += FIN_SB) {
       const int nb = min(FIN_SB, a.B - bs);
-      float acc[FIN_SB], accb[FIN_SB];
+      float acc[FIN_SB];
 #pragma unroll
-      for (int b = 0; b < FIN_SB; ++b) acc[b] = accb[b] = 0.f;
-      float* bias_out = a.mod_bias_out[chunk];   // gate chunks: the partial rows' second sum = the branch's output-linear bias gradient
-      {   // the samples' partial rows side by side: FIN_SB (x 2) independent loads per step, four steps in flight
+      for (int b = 0; b < FIN_SB; ++b) acc[b] = 0.f;
+      {   // the samples' partial rows side by side: FIN_SB independent loads per step
         const float* p = src + (((size_t)bs * rows + ty) * nsum + which) * D + col;
         const size_t step = (size_t)16 * nsum * D, sample = (size_t)rows * nsum * D;
-        if (bias_out) {
-#pragma unroll 4
-          for (int r = ty; r < rows; r += 16, p += step) {
+        for (int r = ty; r < rows; r += 16, p += step) {
 #pragma unroll
-            for (int b = 0; b < FIN_SB; ++b)
-              if (b < nb) { acc[b] += p[b * sample]; accb[b] += p[b * sample + D]; }
-          }
-        } else {
-#pragma unroll 4
-          for (int r = ty; r < rows; r += 16, p += step) {
-#pragma unroll
-            for (int b = 0; b < FIN_SB; ++b)
-              if (b < nb) acc[b] += p[b * sample];
-          }
+          for (int b = 0; b < FIN_SB; ++b)
+            if (b < nb) acc[b] += p[b * sample];
         }
-      }
-      if (bias_out) {   // (which == 0 and nsum == 2 for these chunks) all samples and thread rows of a column, fixed order
-        float t = 0.f;
-#pragma unroll
-        for (int b = 0; b < FIN_SB; ++b) t += accb[b];
-        red[0][ty][tx] = t;
-        __syncthreads();
-        if (ty == 0) {
-          float u = 0.f;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) u += red[0][k][tx];
-          bias_out[col] = bs ? bias_out[col] + u * inv : u * inv;
-        }
-        __syncthreads();
       }
 #pragma unroll
       for (int b = 0; b < FIN_SB; ++b) red[b][ty][tx] = acc[b];
