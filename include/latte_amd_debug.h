@@ -94,6 +94,11 @@ int latte_debug_attention_bwd(const void* qkv, const void* o, const void* dout, 
  * workspace: >= splits * N * K floats (256 * 256 * ceil(N/256) * ceil(K/256) * 256 is always enough). */
 int latte_debug_gemm_tn(const void* dY, const void* X, float* dW, float* workspace, int64_t workspace_floats, int M, int N, int K,
                         int dtype, void* stream);
+/* The same product with colsum[n] = sum_m dY[m, n] (the linear's bias gradient, autograd of nn.Linear) formed on the launch from the
+ * dY fragments the 8-wave kernel holds in registers (round 6b); M % 64 == 0, N % 128 == 0, K % 128 == 0, else LATTE_ERR_INVALID.
+ * workspace: >= splits * (N * K + N) floats. */
+int latte_debug_gemm_tn_colsum(const void* dY, const void* X, float* dW, float* colsum, float* workspace, int64_t workspace_floats,
+                               int M, int N, int K, int dtype, void* stream);
 /* half y = LN(x) * (1 + scale[sample]) + shift[sample]; optional x += temp_embed[frame] first
  * (latte.py:28-29,166,179; :357-358). */
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,

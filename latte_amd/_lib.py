@@ -136,6 +136,7 @@ PROTOTYPES = {
     "latte_debug_attention_bwd": (c_int, [c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64,
                                           c_int, c_void]),
     "latte_debug_gemm_tn": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_int, c_void]),
+    "latte_debug_gemm_tn_colsum": (c_int, [c_void, c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_int, c_void]),
     "latte_debug_ln_modulate": (c_int, [c_void, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_int,
                                         c_int, c_int, c_void]),
     "latte_debug_convert": (c_int, [c_void, c_void, c_i64, c_int, c_void]),

@@ -275,6 +275,20 @@ int latte_debug_gemm_tn(const void* dY, const void* X, float* dW, float* workspa
   return launch_split_reduce(workspace, splits, (size_t)N * K, (size_t)N * K, dW, 0, (hipStream_t)stream);
 }
 
+// the same product with the column sums of dY riding on the launch (gemm_tn8_kernel<DT, true>: the bias gradient of the linear);
+// workspace: >= splits * (N * K + N) floats.  Shapes the 8-wave kernel does not take are refused.
+int latte_debug_gemm_tn_colsum(const void* dY, const void* X, float* dW, float* colsum, float* workspace, int64_t workspace_floats, int M,
+                               int N, int K, int dtype, void* stream) {
+  int chunk = 0;
+  const int splits = gemm_tn_plan(M, N, K, &chunk);
+  if (!gemm_tn8_ok(M, N, K)) return fail(LATTE_ERR_INVALID, "gemm_tn_colsum: the column sums ride on the 8-wave kernel only (M % 64, N % 128, K % 128)");
+  if ((int64_t)splits * ((int64_t)N * K + N) > workspace_floats) return fail(LATTE_ERR_INVALID, "gemm_tn_colsum: workspace too small");
+  float* cs = workspace + (size_t)splits * N * K;
+  if (int rc = launch_gemm_tn((const half_t*)dY, (const half_t*)X, workspace, M, N, K, chunk, dtype, (hipStream_t)stream, cs)) return rc;
+  if (int rc = launch_split_reduce(workspace, splits, (size_t)N * K, (size_t)N * K, dW, 0, (hipStream_t)stream)) return rc;
+  return launch_split_reduce(cs, splits, (size_t)N, (size_t)N, colsum, 0, (hipStream_t)stream);
+}
+
 int latte_debug_ln_modulate(float* x, void* y, const float* shift, const float* scale, int mod_stride, int M, int D,
                             int rows_per_sample, const float* temp_embed, int T, int F, int dtype, void* stream) {
   return launch_ln_modulate(x, x, (half_t*)y, shift, scale, mod_stride, M, D, rows_per_sample, temp_embed, T, F, dtype,

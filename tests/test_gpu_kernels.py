@@ -430,6 +430,30 @@ def test_weight_gradient_gemm_tn(lib, dev, dt, shape, kernel_choice):
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(1024, 768, 768), (2048, 2304, 768), (1536, 3072, 768), (640, 3456, 1152), (1280, 1152, 1152), (256, 128, 128)])
+def test_weight_gradient_gemm_tn_with_bias_column_sums(lib, dev, dt, shape):
+    """Round 6b: the linear's bias gradient (column sums of dY) on the weight-gradient launch -- wave 0 of each group of the k-tile-0
+    workgroups adds the dY fragments it holds with v_dot2c against (1, 1).  The column sums against fp32 torch on the same half
+    operand; the weight gradient BIT-IDENTICAL to the launch without them (same MFMA stream); shapes with half-tile edges in n
+    (1152 = 4.5 tiles, 3456 = 13.5) and a single-tile case.  A shape the 8-wave kernel does not take is refused."""
+    M, N, K = shape
+    g = torch.Generator("cpu").manual_seed(M + N + K + 1)
+    dY = torch.randn(M, N, generator=g).to(dev).to(TD[dt])
+    X = torch.randn(M, K, generator=g).to(dev).to(TD[dt])
+    ws = torch.empty(64 * 1024 * 1024, device=dev)
+    dW0 = torch.full((N, K), float("nan"), device=dev)
+    check(lib.latte_debug_gemm_tn(ptr(dY), ptr(X), ptr(dW0), ptr(ws), ws.numel(), M, N, K, dt, stream_ptr()))
+    dW1 = torch.full((N, K), float("nan"), device=dev)
+    cs = torch.full((N,), float("nan"), device=dev)
+    check(lib.latte_debug_gemm_tn_colsum(ptr(dY), ptr(X), ptr(dW1), ptr(cs), ptr(ws), ws.numel(), M, N, K, dt, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dW0, dW1)
+    want = dY.double().sum(0)
+    assert float((cs.double() - want).norm() / want.norm()) < 2e-6
+    assert lib.latte_debug_gemm_tn_colsum(ptr(dY), ptr(X), ptr(dW1), ptr(cs), ptr(ws), ws.numel(), 1000, N, K, dt, stream_ptr()) != 0
+
+
 # (B, F, T, heads, hd): temporal sequences of 16 / 8 / 5 frames (the one-wave-per-problem kernel, ragged L), spatial 64 and 256 tokens
 ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 2, 64, 2, 72), (1, 2, 256, 2, 64)]
 
