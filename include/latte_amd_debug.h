@@ -148,7 +148,8 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
  *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too
  *   "xattn_flash"     1 = the generic flash kernel for text cross-attention instead of the whole-panel kernel
  *   "tn_kernel"       4 = the 4-wave weight-gradient GEMM;   "tn_wn" 4 = its 256 x 128 tile
- *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too
+ *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too, 2 = also for 64 < L <= 256 (instead of the
+ *                     resident-image kernels of round 6b)
  *   "conv_kernel"     1 = the plain 128 x 128 implicit-GEMM convolution everywhere, 2 | 3 = the ping-pong 256-pixel kernel everywhere,
  *                     4 = its persistent form (round 6: bit-identical, measured 6 - 13 % slower, not a default anywhere)
  *   "vae_split"       1024 + m: which stages of the temporal decoder run split-operand convolutions -- bits 0..4 of m = the spatial resnets of

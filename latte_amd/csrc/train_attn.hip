@@ -70,7 +70,7 @@ struct AttnBwdArgs {
   int num_seq, L, heads, hd, D, U;
   int64_t sample_stride, seq_stride, row_stride;
   float scale;
-  int force_tiles;     // test / measurement hook: 1 = the two tile kernels also for L <= 16
+  int force_tiles;     // test / measurement hook: 1 = the two tile kernels also for L <= 16, 2 = also for 64 < L <= 256 (no resident images)
 };
 
 __device__ __forceinline__ int64_t seq_base(const AttnBwdArgs& a, int seq) {
@@ -78,15 +78,47 @@ __device__ __forceinline__ int64_t seq_base(const AttnBwdArgs& a, int seq) {
 }
 
 // stage 64 rows (tile `tile` of a sequence) of a [rows, ld] matrix, columns [col0, col0 + HD), into a row-major LDS image
-template <int HD>
+template <int HD, int NT = 256>
 __device__ __forceinline__ void stage_tile(char* img, const half_t* src, size_t ld, int col0, int64_t base, int64_t row_stride, int tile,
                                            int L, int tid) {
   constexpr int NCH = HD / 8;
-  for (int id = tid; id < 64 * NCH; id += 256) {
+  for (int id = tid; id < 64 * NCH; id += NT) {
     const int r = id / NCH, ch = id % NCH;
     const int rl = min(tile * 64 + r, L - 1);
     *(u32x4b*)(img + r * RPB + ch * 16) = *(const u32x4b*)(src + (size_t)(base + (int64_t)rl * row_stride) * ld + col0 + ch * 8);
   }
+}
+
+// all (<= 4) tiles of TWO images at once: every global load of the workgroup is issued before the first LDS store (a tile-by-tile
+// walk waits for one load latency per tile and image -- 8 in a row with nothing else resident on the CU)
+template <int HD, int NT>
+__device__ __forceinline__ void stage_pair_all(char* img_a, const half_t* src_a, size_t ld_a, int col_a, char* img_b, const half_t* src_b,
+                                               size_t ld_b, int col_b, int64_t base, int64_t row_stride, int tiles, int L, int tid) {
+  constexpr int NCH = HD / 8, IT = (64 * NCH + NT - 1) / NT, TIMG = 64 * RPB;
+  u32x4b ra[4][IT], rb[4][IT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int id = tid + it * NT;
+      if (t < tiles && id < 64 * NCH) {
+        const int r = id / NCH, ch = id % NCH;
+        const int64_t row = base + (int64_t)min(t * 64 + r, L - 1) * row_stride;
+        ra[t][it] = *(const u32x4b*)(src_a + (size_t)row * ld_a + col_a + ch * 8);
+        rb[t][it] = *(const u32x4b*)(src_b + (size_t)row * ld_b + col_b + ch * 8);
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int id = tid + it * NT;
+      if (t < tiles && id < 64 * NCH) {
+        const int r = id / NCH, ch = id % NCH;
+        *(u32x4b*)(img_a + t * TIMG + r * RPB + ch * 16) = ra[t][it];
+        *(u32x4b*)(img_b + t * TIMG + r * RPB + ch * 16) = rb[t][it];
+      }
+    }
 }
 
 // T^T[tile row 16 j + 4 g + r][own row fl] for the 64 tile rows: st[j][r]
@@ -314,6 +346,171 @@ __global__ void __launch_bounds__(256) attn_bwd_kv_kernel(AttnBwdArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ 64 < L <= 256: resident images
+// Round 6b.  The two tile passes above stage one 64-row tile, synchronise, multiply, synchronise -- per tile and sweep, through
+// registers, nothing in flight under the MFMAs: at the spatial attention of the training step (L = 256, 960 (sequence, head)
+// problems) they ran at 0.11 of the MFMA peak, 230 us per block.  A (sequence, head) of L <= 256 rows is 4 tiles: here ALL tiles of
+// both images (K | V in pass A, Q | dO in pass B: 80 KB at pitch 160) are staged ONCE per workgroup, the workgroup is 8 waves = 128
+// own rows (the images serve twice as many rows), and the sweeps run over the resident tiles without a barrier.  Same products,
+// same order per own row: bit-identical to the tile passes (tests/test_gpu_kernels.py::test_attention_backward compares both).
+template <int HD, int DT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) attn_bwd_q_res_kernel(AttnBwdArgs a) {
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8, NT = WAVES * 64, QB = WAVES * 16, TIMG = 64 * RPB;
+  extern __shared__ __attribute__((aligned(16))) char lds_res[];   // K tiles | V tiles | 16 slack rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fl = lane & 15, g = lane >> 4;
+  const int tiles = (a.L + 63) >> 6;
+  const int qblocks = (a.L + QB - 1) / QB;
+  char* const k_img = lds_res;
+  char* const v_img = lds_res + tiles * TIMG;
+  const int qb = blockIdx.x % qblocks;
+  const int head = (blockIdx.x / qblocks) % a.heads;
+  const int seq = blockIdx.x / (qblocks * a.heads);
+  const int64_t base = seq_base(a, seq);
+  const size_t ld3 = (size_t)3 * a.D;
+  stage_pair_all<HD, NT>(k_img, a.qkv, ld3, a.D + head * HD, v_img, a.qkv, ld3, 2 * a.D + head * HD, base, a.row_stride, tiles, a.L, tid);
+  const int q_idx = qb * QB + wave * 16 + fl;
+  const int q_ld = min(q_idx, a.L - 1);
+  const int64_t q_row = base + (int64_t)q_ld * a.row_stride;
+  u32x4b qf[KS], dof[KS];
+  load_own<HD>(qf, a.qkv + (size_t)q_row * ld3 + head * HD, g);
+  load_own<HD>(dof, a.dout + (size_t)q_row * a.D + head * HD, g);
+  float dq_dot = 0.f;
+  {
+    const half_t* orow = a.o + (size_t)q_row * a.D + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = g + 4 * ks;
+      if (ch < NCH) {
+        const u32x4b ov = *(const u32x4b*)(orow + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dq_dot += hf<DT>((unsigned short)(ov[e] & 0xffffu)) * hf<DT>((unsigned short)(dof[ks][e] & 0xffffu));
+          dq_dot += hf<DT>((unsigned short)(ov[e] >> 16)) * hf<DT>((unsigned short)(dof[ks][e] >> 16));
+        }
+      }
+    }
+    dq_dot += __shfl_xor(dq_dot, 16, 64);
+    dq_dot += __shfl_xor(dq_dot, 32, 64);
+  }
+  __syncthreads();
+  if (qb * QB + wave * 16 >= a.L) return;   // (wave-uniform; no barrier below)
+  const float c = a.scale * 1.4426950408889634f;
+  float m_run = NEG_BIG_B, l_run = 0.f;
+  for (int kt = 0; kt < tiles; ++kt) {
+    f32x4b st[4];
+    score_product<HD, DT>(k_img + kt * TIMG, qf, st, fl, g);
+    float mx = NEG_BIG_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 64 + 16 * j + 4 * g + r;
+        const float z = key < a.L ? st[j][r] * c : NEG_BIG_B;
+        st[j][r] = z;
+        mx = fmaxf(mx, z);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(st[j][r] - m_new);
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ls;
+    m_run = m_new;
+  }
+  const float inv_l = 1.0f / l_run;
+  if (q_idx < a.L && g == 0) {
+    float* sp = a.stats + ((size_t)(seq * a.heads + head) * a.L + q_idx) * 3;
+    sp[0] = m_run; sp[1] = inv_l; sp[2] = dq_dot;
+  }
+  f32x4b acc[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) acc[d] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < tiles; ++kt) {
+    f32x4b st[4], dp[4];
+    score_product<HD, DT>(k_img + kt * TIMG, qf, st, fl, g);
+    score_product<HD, DT>(v_img + kt * TIMG, dof, dp, fl, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 64 + 16 * j + 4 * g + r;
+        const float p = key < a.L ? __builtin_amdgcn_exp2f(st[j][r] * c - m_run) * inv_l : 0.f;
+        st[j][r] = p * (dp[j][r] - dq_dot) * a.scale;           // dS
+      }
+    value_product<HD, DT>(k_img + kt * TIMG, st, acc, fl, g);    // dQ^T += K^T dS^T
+  }
+  if (q_idx < a.L) store_own<HD, DT>(a.dqkv + (size_t)(base + (int64_t)q_idx * a.row_stride) * ld3 + head * HD, acc, 1.0f, g);
+}
+
+template <int HD, int DT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) attn_bwd_kv_res_kernel(AttnBwdArgs a) {
+  constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NT = WAVES * 64, QB = WAVES * 16, TIMG = 64 * RPB;
+  extern __shared__ __attribute__((aligned(16))) char lds_res[];   // Q tiles | dO tiles | 16 slack rows | per-query statistics [64 tiles][3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fl = lane & 15, g = lane >> 4;
+  const int tiles = (a.L + 63) >> 6;
+  const int kblocks = (a.L + QB - 1) / QB;
+  char* const q_img = lds_res;
+  char* const do_img = lds_res + tiles * TIMG;
+  float (*qstat)[3] = (float (*)[3])(lds_res + 2 * tiles * TIMG + 16 * RPB);
+  const int kb = blockIdx.x % kblocks;
+  const int head = (blockIdx.x / kblocks) % a.heads;
+  const int seq = blockIdx.x / (kblocks * a.heads);
+  const int64_t base = seq_base(a, seq);
+  const size_t ld3 = (size_t)3 * a.D;
+  const float* sbase = a.stats + (size_t)(seq * a.heads + head) * a.L * 3;
+  stage_pair_all<HD, NT>(q_img, a.qkv, ld3, head * HD, do_img, a.dout, (size_t)a.D, head * HD, base, a.row_stride, tiles, a.L, tid);
+  for (int q = tid; q < tiles * 64; q += NT) {
+    const bool ok = q < a.L;
+    qstat[q][0] = ok ? sbase[(size_t)q * 3 + 0] : 0.f;
+    qstat[q][1] = ok ? sbase[(size_t)q * 3 + 1] : 0.f;     // 1 / l = 0 masks the query
+    qstat[q][2] = ok ? sbase[(size_t)q * 3 + 2] : 0.f;
+  }
+  const int k_idx = kb * QB + wave * 16 + fl;
+  const int k_ld = min(k_idx, a.L - 1);
+  const int64_t k_row = base + (int64_t)k_ld * a.row_stride;
+  u32x4b kf[KS], vf[KS];
+  load_own<HD>(kf, a.qkv + (size_t)k_row * ld3 + a.D + head * HD, g);
+  load_own<HD>(vf, a.qkv + (size_t)k_row * ld3 + 2 * a.D + head * HD, g);
+  __syncthreads();
+  if (kb * QB + wave * 16 >= a.L) return;   // (wave-uniform; no barrier below)
+  const float c = a.scale * 1.4426950408889634f;
+  f32x4b dv[DF], dk[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    dv[d] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+    dk[d] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int qt = 0; qt < tiles; ++qt) {
+    f32x4b st[4], dp[4];
+    score_product<HD, DT>(q_img + qt * TIMG, kf, st, fl, g);      // S[q][k]: tile row = query, own row = key
+    score_product<HD, DT>(do_img + qt * TIMG, vf, dp, fl, g);     // dP[q][k] = dO[q] . V[k]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qt * 64 + 16 * j + 4 * g + r;
+        const float il = qstat[ql][1];
+        const float p = il != 0.f ? __builtin_amdgcn_exp2f(st[j][r] * c - qstat[ql][0]) * il : 0.f;
+        st[j][r] = p;
+        dp[j][r] = p * (dp[j][r] - qstat[ql][2]) * a.scale;     // dS
+      }
+    value_product<HD, DT>(do_img + qt * TIMG, st, dv, fl, g);     // dV^T += dO^T P
+    value_product<HD, DT>(q_img + qt * TIMG, dp, dk, fl, g);      // dK^T += Q^T dS
+  }
+  if (k_idx < a.L) {
+    half_t* rowp = a.dqkv + (size_t)(base + (int64_t)k_idx * a.row_stride) * ld3 + head * HD;
+    store_own<HD, DT>(rowp + a.D, dk, 1.0f, g);
+    store_own<HD, DT>(rowp + 2 * a.D, dv, 1.0f, g);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ L <= 16: one wave per (sequence, head)
 // The temporal attention of the training step (16 frames per token; latte.py:355-368) gave the two tile kernels above one
 // quarter-filled 64-row tile per workgroup -- 110 us per pass for 0.4 GFLOP.  Here a wave owns a whole (sequence, head) problem:
@@ -462,12 +659,25 @@ __global__ void __launch_bounds__(256) attn_bwd_small_kernel(AttnBwdArgs a) {
 
 template <int HD, int DT>
 int launch_hd_dt(const AttnBwdArgs& a, hipStream_t st) {
-  if (a.L <= 16 && !a.force_tiles) {
+  if (a.L <= 16 && a.force_tiles != 1) {
     hipLaunchKernelGGL((attn_bwd_small_kernel<HD, DT>), dim3((a.num_seq * a.heads + 3) / 4), dim3(256), 0, st, a);
     LATTE_HIP(hipGetLastError());
     return LATTE_OK;
   }
   const int tiles = (a.L + 63) / 64;
+  if (a.L > 64 && a.L <= 256 && a.force_tiles != 2) {   // resident images, 8 waves = 128 own rows per workgroup (round 6b)
+    constexpr int W = 16;
+    const int blocks = (a.L + 16 * W - 1) / (16 * W);
+    const int lds = 2 * tiles * 64 * RPB + 16 * RPB + tiles * 64 * 3 * (int)sizeof(float);
+    static std::atomic<uint64_t> done_q{0}, done_kv{0};
+    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_q_res_kernel<HD, DT, W>, lds, done_q)) return rc;
+    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_kv_res_kernel<HD, DT, W>, lds, done_kv)) return rc;
+    dim3 gridr(a.num_seq * a.heads * blocks), blockr(W * 64);
+    hipLaunchKernelGGL((attn_bwd_q_res_kernel<HD, DT, W>), gridr, blockr, lds, st, a);
+    hipLaunchKernelGGL((attn_bwd_kv_res_kernel<HD, DT, W>), gridr, blockr, lds, st, a);
+    LATTE_HIP(hipGetLastError());
+    return LATTE_OK;
+  }
   dim3 grid(a.num_seq * a.heads * tiles), block(256);
   hipLaunchKernelGGL((attn_bwd_q_kernel<HD, DT>), grid, block, 0, st, a);
   hipLaunchKernelGGL((attn_bwd_kv_kernel<HD, DT>), grid, block, 0, st, a);
@@ -485,7 +695,8 @@ int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* dout,
   a.num_seq = num_seq; a.L = L; a.heads = heads; a.hd = hd; a.D = heads * hd; a.U = U;
   a.sample_stride = sample_stride; a.seq_stride = seq_stride; a.row_stride = row_stride;
   a.scale = 1.0f / sqrtf((float)hd);
-  a.force_tiles = debug_choice(DBG_ATTN_BWD_TILES) == 1;   // latte_debug_set_choice("attn_bwd_tiles", 1): the tiled kernels for L = 16 too (A/B tests)
+  // latte_debug_set_choice("attn_bwd_tiles", v) (A/B tests): 1 = the tile passes also for L <= 16, 2 = also for 64 < L <= 256
+  a.force_tiles = debug_choice(DBG_ATTN_BWD_TILES);
   if (dtype != LATTE_DTYPE_BF16 && dtype != LATTE_DTYPE_F16) return fail(LATTE_ERR_INVALID, "attention_bwd: unknown dtype");
 #define CASE(HD)                                                                                         \
   case HD:                                                                                               \

@@ -455,7 +455,8 @@ def test_weight_gradient_gemm_tn_with_bias_column_sums(lib, dev, dt, shape):
 
 
 # (B, F, T, heads, hd): temporal sequences of 16 / 8 / 5 frames (the one-wave-per-problem kernel, ragged L), spatial 64 and 256 tokens
-ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 2, 64, 2, 72), (1, 2, 256, 2, 64)]
+ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 2, 64, 2, 72), (1, 2, 256, 2, 64), (1, 2, 200, 2, 72),
+                  (1, 3, 128, 2, 64), (2, 2, 256, 3, 72)]
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -463,7 +464,8 @@ ATTN_BWD_CASES = [(2, 16, 32, 4, 64), (1, 8, 24, 2, 72), (3, 5, 16, 3, 64), (1, 
 @pytest.mark.parametrize("mode", ["spatial", "temporal"])
 def test_attention_backward(lib, dev, dt, case, mode, kernel_choice):
     """dq, dk, dv of the attention core (csrc/train_attn.hip) against torch autograd on the same half q / k / v / dout, for the
-    strided sequence layouts of both block kinds; where L <= 16 the one-wave kernel AND the tile passes (forced) are checked."""
+    strided sequence layouts of both block kinds; where L <= 16 the one-wave kernel AND the tile passes (forced) are checked, where 64 < L <= 256 the resident-image
+    kernels AND the tile passes."""
     B, F, T, H, hd = case
     D, rows = H * hd, B * F * T
     g = torch.Generator("cpu").manual_seed(rows + hd)
@@ -482,11 +484,17 @@ def test_attention_backward(lib, dev, dt, case, mode, kernel_choice):
     want = q5.grad.reshape(rows, 3 * D)
     oh = o.detach().to(TD[dt])
     stats = torch.zeros(args[0] * H * L * 3 + 16, device=dev)
-    for force in ([False, True] if L <= 16 else [False]):
+    # L <= 16: the one-wave kernel and the tile passes (forced, 1); 64 < L <= 256: the resident-image kernels (round 6b) and the
+    # tile passes (forced, 2) -- the same products in the same order per own row: bit-identical
+    outs = []
+    for force in ([0, 1] if L <= 16 else [0, 2] if 64 < L <= 256 else [0]):
         if force:
-            kernel_choice("attn_bwd_tiles", 1)
+            kernel_choice("attn_bwd_tiles", force)
         got = torch.full((rows, 3 * D), float("nan"), dtype=TD[dt], device=dev)
         check(lib.latte_debug_attention_bwd(ptr(qkv), ptr(oh), ptr(dout), ptr(got), ptr(stats), *args, dt, stream_ptr()))
         torch.cuda.synchronize()
         rel = float((got.float() - want).norm() / want.norm())
         assert rel < (1.2e-2 if dt == 0 else 2e-3), (force, rel)
+        outs.append(got)
+    if 64 < L <= 256:
+        assert torch.equal(outs[0], outs[1])
