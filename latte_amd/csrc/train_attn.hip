@@ -670,8 +670,9 @@ int launch_hd_dt(const AttnBwdArgs& a, hipStream_t st) {
     const int blocks = (a.L + 16 * W - 1) / (16 * W);
     const int lds = 2 * tiles * 64 * RPB + 16 * RPB + tiles * 64 * 3 * (int)sizeof(float);
     static std::atomic<uint64_t> done_q{0}, done_kv{0};
-    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_q_res_kernel<HD, DT, W>, lds, done_q)) return rc;
-    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_kv_res_kernel<HD, DT, W>, lds, done_kv)) return rc;
+    constexpr int lds_max = 2 * 4 * 64 * RPB + 16 * RPB + 4 * 64 * 3 * (int)sizeof(float);   // 4 tiles: the per-device opt-in covers every L
+    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_q_res_kernel<HD, DT, W>, lds_max, done_q)) return rc;
+    if (int rc = ensure_dynamic_lds((const void*)attn_bwd_kv_res_kernel<HD, DT, W>, lds_max, done_kv)) return rc;
     dim3 gridr(a.num_seq * a.heads * blocks), blockr(W * 64);
     hipLaunchKernelGGL((attn_bwd_q_res_kernel<HD, DT, W>), gridr, blockr, lds, st, a);
     hipLaunchKernelGGL((attn_bwd_kv_res_kernel<HD, DT, W>), gridr, blockr, lds, st, a);

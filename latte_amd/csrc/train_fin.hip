@@ -336,7 +336,9 @@ int launch_stage_finalize(const StageFinArgs& a, hipStream_t st) {
   if (blocks <= 0) return LATTE_OK;
   const int lds = (FIN_SB * 16 * 64 + FIN_SB * 64 + FIN_SB * a.D) * (int)sizeof(float);
   static std::atomic<uint64_t> done{0};
-  if (int rc = ensure_dynamic_lds((const void*)stage_finalize_kernel, lds, done)) return rc;
+  // (the opt-in is remembered per device: ask for the largest image the kernel can need, not this launch's)
+  constexpr int LDS_MAX = (FIN_SB * 16 * 64 + FIN_SB * 64 + FIN_SB * FIN_DMAX) * (int)sizeof(float);
+  if (int rc = ensure_dynamic_lds((const void*)stage_finalize_kernel, LDS_MAX, done)) return rc;
   hipLaunchKernelGGL(stage_finalize_kernel, dim3(blocks), dim3(1024), lds, st, b);
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
@@ -355,10 +357,11 @@ int launch_narrow_outer(const float* nar, int P, const void* wide, int wide_half
   float* pn = ws + (size_t)nb * P * D;
   float* pw = pn + (size_t)nb * P;
   const int lds = (NO_ROWS * D + NO_ROWS * NO_PMAX) * (int)sizeof(float);
+  constexpr int lds_max = (NO_ROWS * FIN_DMAX + NO_ROWS * NO_PMAX) * (int)sizeof(float);   // the per-device opt-in covers every D
 #define NO_CASE(WT, DT)                                                                                                          \
   {                                                                                                                              \
     static std::atomic<uint64_t> done{0};                                                                                        \
-    if (int rc = ensure_dynamic_lds((const void*)narrow_outer_kernel<WT, DT>, lds, done)) return rc;                              \
+    if (int rc = ensure_dynamic_lds((const void*)narrow_outer_kernel<WT, DT>, lds_max, done)) return rc;                          \
     hipLaunchKernelGGL((narrow_outer_kernel<WT, DT>), dim3(nb), dim3(threads), lds, st, nar, P, (const WT*)wide, D, M,            \
                        NO_ROWS_PER_BLOCK, part, so_p, so_k, nsum_out ? pn : nullptr, wsum_out ? pw : nullptr);                   \
   }
