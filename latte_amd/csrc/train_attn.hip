@@ -351,8 +351,10 @@ __global__ void __launch_bounds__(256) attn_bwd_kv_kernel(AttnBwdArgs a) {
 // registers, nothing in flight under the MFMAs: at the spatial attention of the training step (L = 256, 960 (sequence, head)
 // problems) they ran at 0.11 of the MFMA peak, 230 us per block.  A (sequence, head) of L <= 256 rows is 4 tiles: here ALL tiles of
 // both images (K | V in pass A, Q | dO in pass B: 80 KB at pitch 160) are staged ONCE per workgroup, the workgroup is 8 waves = 128
-// own rows (the images serve twice as many rows), and the sweeps run over the resident tiles without a barrier.  Same products,
-// same order per own row: bit-identical to the tile passes (tests/test_gpu_kernels.py::test_attention_backward compares both).
+// own rows (the launcher uses 16 waves: the whole sequence, 4 waves per SIMD), and the sweeps run over the resident tiles without a
+// barrier.  Same MFMA products in the same order per own row; the elementwise chain between them is a shorter form of the same
+// arithmetic (comment in pass A): equal to the tile passes to rounding (tests/test_gpu_kernels.py::test_attention_backward checks
+// both against torch autograd and against each other).
 template <int HD, int DT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_bwd_q_res_kernel(AttnBwdArgs a) {
   constexpr int KS = (HD + 31) / 32, DF = (HD + 15) / 16, NCH = HD / 8, NT = WAVES * 64, QB = WAVES * 16, TIMG = 64 * RPB;
@@ -395,39 +397,47 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_q_res_kernel(AttnBwdArgs 
   }
   __syncthreads();
   if (qb * QB + wave * 16 >= a.L) return;   // (wave-uniform; no barrier below)
+  // The passes are VALU-bound (16 own rows per wave: 16 scores per lane and tile against 8 - 24 MFMAs), so the elementwise chain is
+  // kept short: the running maximum is taken on the RAW scores (the scale is positive), exp2 takes one FMA as its argument, the
+  // normaliser and the softmax scale enter as log2 terms of that argument, key masks only exist on a ragged last tile.
   const float c = a.scale * 1.4426950408889634f;
-  float m_run = NEG_BIG_B, l_run = 0.f;
+  float m_raw = NEG_BIG_B, l_run = 0.f;   // running maximum of the raw scores; row sum in the exp2 domain relative to it
   for (int kt = 0; kt < tiles; ++kt) {
     f32x4b st[4];
     score_product<HD, DT>(k_img + kt * TIMG, qf, st, fl, g);
+    if (kt * 64 + 64 > a.L) {   // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 64 + 16 * j + 4 * g + r >= a.L) st[j][r] = NEG_BIG_B;
+    }
     float mx = NEG_BIG_B;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 64 + 16 * j + 4 * g + r;
-        const float z = key < a.L ? st[j][r] * c : NEG_BIG_B;
-        st[j][r] = z;
-        mx = fmaxf(mx, z);
-      }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[j][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_raw, mx);
+    const float nm = -m_new * c;
     float ls = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(st[j][r] - m_new);
+      for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][r], c, nm));   // masked keys: exp2(-huge) = 0
     ls += __shfl_xor(ls, 16, 64);
     ls += __shfl_xor(ls, 32, 64);
-    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ls;
-    m_run = m_new;
+    l_run = l_run * __builtin_amdgcn_exp2f((m_raw - m_new) * c) + ls;
+    m_raw = m_new;
   }
+  const float m_run = m_raw * c;            // the statistics pass B reads: exp2-domain maximum, 1 / l, D
   const float inv_l = 1.0f / l_run;
   if (q_idx < a.L && g == 0) {
     float* sp = a.stats + ((size_t)(seq * a.heads + head) * a.L + q_idx) * 3;
     sp[0] = m_run; sp[1] = inv_l; sp[2] = dq_dot;
   }
+  const float nm2 = __builtin_amdgcn_logf(inv_l * a.scale) - m_run;   // (v_log_f32 = log2) dS = exp2(S c + nm2) (dP - D)
   f32x4b acc[DF];
 #pragma unroll
   for (int d = 0; d < DF; ++d) acc[d] = (f32x4b){0.f, 0.f, 0.f, 0.f};
@@ -438,11 +448,14 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_q_res_kernel(AttnBwdArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 64 + 16 * j + 4 * g + r;
-        const float p = key < a.L ? __builtin_amdgcn_exp2f(st[j][r] * c - m_run) * inv_l : 0.f;
-        st[j][r] = p * (dp[j][r] - dq_dot) * a.scale;           // dS
-      }
+      for (int r = 0; r < 4; ++r) st[j][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][r], c, nm2)) * (dp[j][r] - dq_dot);   // dS
+    if (kt * 64 + 64 > a.L) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 64 + 16 * j + 4 * g + r >= a.L) st[j][r] = 0.f;
+    }
     value_product<HD, DT>(k_img + kt * TIMG, st, acc, fl, g);    // dQ^T += K^T dS^T
   }
   if (q_idx < a.L) store_own<HD, DT>(a.dqkv + (size_t)(base + (int64_t)q_idx * a.row_stride) * ld3 + head * HD, acc, 1.0f, g);
@@ -458,7 +471,10 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kv_res_kernel(AttnBwdArgs
   const int kblocks = (a.L + QB - 1) / QB;
   char* const q_img = lds_res;
   char* const do_img = lds_res + tiles * TIMG;
-  float (*qstat)[3] = (float (*)[3])(lds_res + 2 * tiles * TIMG + 16 * RPB);
+  // per-query terms, one array each so that a lane's four consecutive queries are one 16-byte read:
+  //   qnm[q] = log2(1 / l_q) - m_q  (-inf for an absent query: P = exp2(-inf) = 0),   qds[q] = D_q * scale
+  float* const qnm = (float*)(lds_res + 2 * tiles * TIMG + 16 * RPB);
+  float* const qds = qnm + tiles * 64;
   const int kb = blockIdx.x % kblocks;
   const int head = (blockIdx.x / kblocks) % a.heads;
   const int seq = blockIdx.x / (kblocks * a.heads);
@@ -468,9 +484,9 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kv_res_kernel(AttnBwdArgs
   stage_pair_all<HD, NT>(q_img, a.qkv, ld3, head * HD, do_img, a.dout, (size_t)a.D, head * HD, base, a.row_stride, tiles, a.L, tid);
   for (int q = tid; q < tiles * 64; q += NT) {
     const bool ok = q < a.L;
-    qstat[q][0] = ok ? sbase[(size_t)q * 3 + 0] : 0.f;
-    qstat[q][1] = ok ? sbase[(size_t)q * 3 + 1] : 0.f;     // 1 / l = 0 masks the query
-    qstat[q][2] = ok ? sbase[(size_t)q * 3 + 2] : 0.f;
+    const float il = ok ? sbase[(size_t)q * 3 + 1] : 0.f;   // 1 / l = 0 masks the query
+    qnm[q] = __builtin_amdgcn_logf(il) - (ok ? sbase[(size_t)q * 3 + 0] : 0.f);
+    qds[q] = ok ? sbase[(size_t)q * 3 + 2] * a.scale : 0.f;
   }
   const int k_idx = kb * QB + wave * 16 + fl;
   const int k_ld = min(k_idx, a.L - 1);
@@ -492,15 +508,17 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kv_res_kernel(AttnBwdArgs
     score_product<HD, DT>(q_img + qt * TIMG, kf, st, fl, g);      // S[q][k]: tile row = query, own row = key
     score_product<HD, DT>(do_img + qt * TIMG, vf, dp, fl, g);     // dP[q][k] = dO[q] . V[k]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const float4 nm4 = *(const float4*)(qnm + qt * 64 + 16 * j + 4 * g);
+      const float4 ds4 = *(const float4*)(qds + qt * 64 + 16 * j + 4 * g);
+      const float nmr[4] = {nm4.x, nm4.y, nm4.z, nm4.w}, dsr[4] = {ds4.x, ds4.y, ds4.z, ds4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = qt * 64 + 16 * j + 4 * g + r;
-        const float il = qstat[ql][1];
-        const float p = il != 0.f ? __builtin_amdgcn_exp2f(st[j][r] * c - qstat[ql][0]) * il : 0.f;
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[j][r], c, nmr[r]));   // P (0 for an absent query)
         st[j][r] = p;
-        dp[j][r] = p * (dp[j][r] - qstat[ql][2]) * a.scale;     // dS
+        dp[j][r] = p * __builtin_fmaf(dp[j][r], a.scale, -dsr[r]);                      // dS = P (dP - D) scale
       }
+    }
     value_product<HD, DT>(do_img + qt * TIMG, st, dv, fl, g);     // dV^T += dO^T P
     value_product<HD, DT>(q_img + qt * TIMG, dp, dk, fl, g);      // dK^T += Q^T dS
   }
