@@ -7,7 +7,7 @@
 //                           (latte.py:178-180: shift / scale / gate of both branches), the adaLN linear's bias and weight
 //                           gradients from them (dW[n, k] = sum_b dmod[b, n] silu(c)[b, k]: K = batch, an outer product -- written
 //                           once at HBM speed), and the four bias gradients of the block's linears from the column partials
-//                           their producers left (gate_bwd for proj / fc2, colsum_half for qkv / fc1).  Gradients leave the
+//                           their producers left (the gate backward for proj / fc2; for qkv / fc1 the weight-gradient launch, gemm_tn.hip, or colsum_half).  Gradients leave the
 //                           loss-scaled domain here (x 1 / scale, a power of two: exact).
 //   adaln_dc_kernel         d silu(c)[b, k] = sum over ALL adaLN linears of dmod[b, n] W[n, k], once per step (the stages only
 //                           need it at the very end, train_engine.cpp) instead of one split GEMM + reduce + add per block
