@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--sync", action="store_true", help="synchronize after every warm-up launch (fault localisation)")
+    ap.add_argument("--check", action="store_true", help="relative L2 error of every variant against fp32 torch on the same half operands")
     a = ap.parse_args()
     lib = _lib.load_library()
     D = a.heads * a.hd
@@ -39,6 +40,15 @@ def main():
         assert rc == 0, rc
 
     vs = [int(v) for v in a.variants.split(",")]
+    if a.check:
+        q, k, v = [qkv.float().view(a.seqs, a.L, 3, a.heads, a.hd)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+        want = torch.cat([(torch.softmax((q[i:i + 4] @ k[i:i + 4].transpose(-1, -2)) * a.hd ** -0.5, dim=-1) @ v[i:i + 4])
+                          for i in range(0, a.seqs, 4)]).permute(0, 2, 1, 3).reshape(a.seqs * a.L, D)
+        for v_ in vs:
+            out.zero_()
+            run(v_)
+            torch.cuda.synchronize()
+            print(f"variant {v_}: rel L2 error {float((out.float() - want).norm() / want.norm()):.3e}, max abs {float((out.float() - want).abs().max()):.3e}", flush=True)
     best = {v: 1e9 for v in vs}
     for v in vs:
         run(v)
