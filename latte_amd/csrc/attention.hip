@@ -18,6 +18,7 @@
 //  attn_small : L <= 16 (temporal attention over frames); one wave per (sequence, head), Q/K
 //               fragments straight from global memory, V through a wave-private LDS patch.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -1022,6 +1023,337 @@ __global__ void __launch_bounds__(512) attn_stream32_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_stream64 (round 6c): L > 256, head dim 72, on ONE wave per SIMD.  A workgroup is 4 waves = 256 queries of a (sequence, head);
+// a wave owns 64 queries (two 32-query column groups) and the whole 512-register file, so every K fragment and every V^T fragment
+// read from LDS feeds TWO MFMAs (the 8-wave kernels above read one fragment per MFMA-pair of half the size: their LDS pipe is as
+// busy as their matrix pipe), and the softmax is software-pipelined against the matrix work inside the wave:
+//   iteration i:  phase 1   S(i+1) = K(i+1) Q^T, both groups            (40 MFMAs, 20 ds_read_b128)
+//                 phase 2   O += V(i)^T P(i)^T, both groups             (48 MFMAs, 48 transpose reads)
+//                           with the softmax of block i+1 -- S(i+1) -> P(i+1) -- in the same instruction stream: the exponentials of
+//                           key tile t are written over P(i)'s tile t after the MFMAs that read it have been issued.
+// K and V have their own rings of three blocks (K(i+1) and V(i) are read in the same iteration); one barrier per iteration.
+// Fragment shapes, the key order of P and the K image are attn_stream32's; the V image has a pitch of 160 bytes (the tenth chunk is
+// padding) with the keys of every 8-key group stored as key 8 b + 4 h + i -> row 8 b + 2 i + h.
+constexpr int S64_KP = 144, S64_VP = 160, S64_KB = 64, S64_NS = 4, S64_KIMG = S64_KB * S64_KP, S64_VIMG = S64_KB * S64_VP;
+constexpr int STREAM64_LDS = S64_NS * (S64_KIMG + S64_VIMG) + 256;
+
+template <int HD, int DT, bool LO8 = false, int ABL = 0>
+__global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
+  constexpr int KS = (HD + 15) / 16, DTL = (HD + 31) / 32, NCH = HD / 8;
+  constexpr int KP = S64_KP, VP = S64_VP, KB = S64_KB, NT = KB / 32, KIMG = S64_KIMG, VIMG = S64_VIMG, NS = S64_NS;
+  static_assert(HD == 72, "written for 9-chunk rows");
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  char* const kring = smem_attn;
+  char* const vring = smem_attn + NS * KIMG;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int qblocks = (a.L + 255) >> 8;
+  int seq, head, qb;
+  {
+    int b = blockIdx.x;
+    const int per_seq = a.heads * qblocks;
+    if ((a.num_seq & 7) == 0) {   // the heads and query blocks of one sequence on ONE XCD
+      const int xcd = b & 7, slot = b >> 3;
+      seq = (slot / per_seq) * 8 + xcd;
+      b = slot % per_seq;
+    } else {
+      seq = b / per_seq;
+      b = b % per_seq;
+    }
+    head = b / qblocks;
+    qb = b % qblocks;
+  }
+  const int64_t base = seq_base_row(a, seq);
+  const size_t ld = (size_t)3 * a.D;
+  const half_t* qkv_h = a.qkv + (size_t)head * HD;
+  const int q0 = qb * 256 + wave * 64;
+  const int nkb = (a.L + KB - 1) / KB;
+
+  u32x4 qf[2][KS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int q_ld = min(q0 + 32 * g + ql, a.L - 1);
+    const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ch = 2 * ks + hi;
+      qf[g][ks] = (u32x4){0u, 0u, 0u, 0u};
+      if (ch < NCH) qf[g][ks] = *(const u32x4*)(qrow + ch * 8);
+    }
+  }
+  // (the loads complete here; "+a": the Q fragments live in the accumulator half of the register file for the whole kernel -- MFMA
+  // reads its B operand from there directly -- which leaves the architectural half to the scores and the softmax)
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(qf[g][ks]));
+
+  // DMA.  K image of a 64-key block: 9 instructions (9 chunks x 64 rows); V image: 10 (10 chunks x 64 rows, LDS row r holds key
+  // (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)).  EVERY wave issues three pieces per image and block -- piece j of wave w is
+  // instruction min(w + 4 j, last): a few pieces are written twice with the same bytes -- and a block past the end re-reads the last
+  // block into the (free) slot it would have taken: no branch around a DMA piece, one vmcnt value for every wave and iteration.
+  auto k_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
+    const int idx = min(wave + 4 * j, 8) * 64 + lane;
+    const int row = idx / 9, ch = idx - row * 9;
+    const int key_ld = min(row, a.L - 1 - kb * KB);
+    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch * 8 + a.D) * 2);
+  };
+  auto v_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
+    const int idx = min(wave + 4 * j, 9) * 64 + lane;
+    const int row = idx / 10, ch = idx - row * 10;
+    const int key = (row & ~7) | ((row & 1) << 2) | ((row >> 1) & 3);
+    const int key_ld = min(key, a.L - 1 - kb * KB), ch_ld = min(ch, NCH - 1);
+    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch_ld * 8 + 2 * a.D) * 2);
+  };
+  unsigned koff[3], voff[3], koff_l[3], voff_l[3];   // whole blocks / the last block (rows >= L re-read row L - 1: they meet P = 0)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    koff[j] = k_offset(j, 0); voff[j] = v_offset(j, 0);
+    koff_l[j] = k_offset(j, nkb - 1); voff_l[j] = v_offset(j, nkb - 1);
+  }
+  auto stage_k_piece = [&](int kb, int j) __attribute__((always_inline)) {
+    const int kb_ld = min(kb, nkb - 1);
+    char* dst = kring + (kb % NS) * KIMG;
+    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb_ld * KB * a.row_stride) * ld);
+    const unsigned off = kb_ld == nkb - 1 ? koff_l[j] : koff[j];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
+                                     (__attribute__((address_space(3))) void*)(dst + min(wave + 4 * j, 8) * 1024), 16, 0, 0);
+  };
+  auto stage_v_piece = [&](int kb, int j) __attribute__((always_inline)) {
+    const int kb_ld = min(kb, nkb - 1);
+    char* dst = vring + (kb % NS) * VIMG;
+    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb_ld * KB * a.row_stride) * ld);
+    const unsigned off = kb_ld == nkb - 1 ? voff_l[j] : voff[j];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
+                                     (__attribute__((address_space(3))) void*)(dst + min(wave + 4 * j, 9) * 1024), 16, 0, 0);
+  };
+  auto stage_k = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) stage_k_piece(kb, j);
+  };
+  auto stage_v = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) stage_v_piece(kb, j);
+  };
+  // issue groups: [K(0)], then G(j) = [K(j + 1), V(j)]; G(0..2) here, G(i + 3) in iteration i
+  stage_k(0);
+  stage_k(1); stage_v(0);
+  stage_k(2); stage_v(1);
+  stage_k(3); stage_v(2);
+
+  const float c = a.scale * 1.4426950408889634f;
+  f32x16 o[2][DTL];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int d = 0; d < DTL; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[g][d][r] = 0.f;
+  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f}, ls[2] = {0.f, 0.f};
+  bool raised = false;
+  const bool wave_active = q0 < a.L;
+  f32x16 st[2][NT];
+  unsigned pk[2][NT][8];
+
+  const int kread = ql * KP + hi * 16;
+  const int vread = (2 * ((lane & 15) >> 2) + hi) * VP + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // phase 1: S(kb), both groups, every K fragment read once.  The MFMAs are inline assembly with architectural destination registers:
+  // hipcc puts every MFMA result of a kernel this size into the accumulator half and the softmax then pays one v_accvgpr_read per score
+  // and pass (128 per block, measured in the listing).  What the compiler does for its own MFMAs is done by hand here: the chain of a
+  // (group, tile) accumulates in place (back-to-back srcC = vDst needs no wait state), and its last MFMA carries the 20 wait states
+  // a VALU read of a 16-pass result needs -- hidden, the matrix pipe is busy for 32 cycles anyway.
+  auto scores = [&](int kb, int dma_kb) __attribute__((always_inline)) {
+    const char* kbase = kring + (kb % NS) * KIMG + kread;
+    u32x4 kf[2][KS];
+    auto load_k = [&](int t, u32x4 (&dst)[KS]) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + t * 32 * KP + ks * 32);
+    };
+    load_k(0, kf[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) load_k(t + 1, kf[(t + 1) & 1]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (ABL != 7 && dma_kb >= 0) {   // (the prologue call passes -1: compile-time after inlining)
+            if (g == 0 && ks == 2 && t == 0) stage_k_piece(dma_kb, 0);   // behind 4 / 14 / 18 MFMAs of the phase
+            if (g == 0 && ks == 2 && t == 1) stage_k_piece(dma_kb, 1);
+            if (g == 0 && ks == 4 && t == 1) stage_k_piece(dma_kb, 2);
+          }
+          if constexpr (DT == LATTE_DTYPE_BF16) {
+            if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+            else if (ks + 1 < KS) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+          } else {
+            if (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+            else if (ks + 1 < KS) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
+          }
+        }
+    }
+  };
+  // softmax of block kb, part 1: masks (MASKED: the block may be ragged), row maxima, the rescale factor of the accumulators
+  auto softmax_max = [&](int kb, auto masked) __attribute__((always_inline)) {
+    raised = false;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if constexpr (decltype(masked)::value) {
+        const int kleft = a.L - kb * KB;
+        if (kleft < KB) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi >= kleft) st[g][t][r] = NEG_BIG;
+        }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[g][t][r]);
+      mx = half_swap_max(mx);
+      // Lazy reference maximum: the running value is only raised when some query of the group found a score more than LAZY (in
+      // exp2 units) above it -- on every block it is raised for all lanes that exceed theirs at all, the block's P then is <= 1; in
+      // between P <= 2^LAZY, which half holds with the same relative rounding, and the sums are fp32.  With 64 queries per wave a
+      // raise by ANY amount happens in nearly every block (the accumulators sit in the accumulator registers: 5 instructions per
+      // pair to rescale them, 240 per block); a raise by 2^8 only in the first block or two of a sequence.
+      constexpr float LAZY = 8.0f;
+      const bool up = __builtin_amdgcn_ballot_w64((mx - m_run[g]) * c > LAZY) != 0;
+      const float m_new = up ? fmaxf(m_run[g], mx) : m_run[g];
+      alpha[g] = up ? __builtin_amdgcn_exp2f((m_run[g] - m_new) * c) : 1.0f;
+      nm[g] = -m_new * c;
+      raised = raised || up;
+      m_run[g] = m_new;
+      ls[g] = 0.f;
+    }
+  };
+  // part 2, one key tile: exponentials -> packed P (in place), row-sum chain
+  auto softmax_exp = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fma1(st[g][t][r], c, nm[g]));
+        const float p1 = __builtin_amdgcn_exp2f(fma1(st[g][t][r + 1], c, nm[g]));
+        pk[g][t][r >> 1] = pack2<DT>(p0, p1);
+        ls[g] += p0;
+        ls[g] += p1;
+      }
+  };
+  auto softmax_end = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) l_run[g] = l_run[g] * alpha[g] + ls[g];
+  };
+
+  // V^T fragments of k-step `step` of the block at vbase (two transpose reads per d tile); completion is counted by hand
+  auto load_v = [&](const char* vbase, int step, u32x2 (&lo)[DTL], u32x2 (&hi2)[DTL]) __attribute__((always_inline)) {
+    const char* pv = vbase + 16 * step * VP;
+    lo[0] = lds_tr16_asm<0>(pv); hi2[0] = lds_tr16_asm<8 * VP>(pv);
+    lo[1] = lds_tr16_asm<64>(pv); hi2[1] = lds_tr16_asm<8 * VP + 64>(pv);
+    lo[2] = lds_tr16_asm<128>(pv); hi2[2] = lds_tr16_asm<8 * VP + 128>(pv);
+  };
+
+  // prologue: K(0) landed (G(0..2) may stay in flight: 3 x (nk + nv) instructions of this wave) -> S(0), softmax(0) with nothing beside it
+  asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // K(0): everything but G(0..2), 6 pieces each
+  __builtin_amdgcn_s_barrier();
+  typedef std::integral_constant<bool, true> yes_t;
+  typedef std::integral_constant<bool, false> no_t;
+  if (wave_active) {
+    scores(0, -1);
+    softmax_max(0, yes_t{});
+#pragma unroll
+    for (int t = 0; t < NT; ++t) softmax_exp(t);
+    softmax_end();
+  }
+  // one iteration: G(i) landed; [rescale]; S(i+1); max(i+1); P(i) with exp(i+1) in the same stream.  MORE = block i+1 exists,
+  // MASKED = block i+1 may be ragged: the steady-state instance (MORE, not MASKED) has no branch between its MFMAs.
+  auto iteration = [&](int i, auto more, auto masked) __attribute__((always_inline)) {
+    constexpr bool MORE = decltype(more)::value;
+    if constexpr (ABL != 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // G(i) landed; G(i+1), G(i+2) may stay in flight
+    if constexpr (ABL != 9) __builtin_amdgcn_s_barrier();
+    if (!wave_active) {
+      if constexpr (ABL != 7) { stage_k(i + 4); stage_v(i + 3); }
+      return;
+    }
+    // V^T fragments of P(i)'s first two k-steps are requested before anything else (V(i) has landed): three buffers, two steps ahead
+    const char* vbase = vring + (i % NS) * VIMG + vread;
+    u32x2 vlo[3][DTL], vhi[3][DTL];
+    load_v(vbase, 0, vlo[0], vhi[0]);
+    load_v(vbase, 1, vlo[1], vhi[1]);
+    if (raised) {   // the accumulators meet P(i): rescale by the factor softmax(i) found
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < DTL; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha[g];
+    }
+    if constexpr (MORE) {
+      scores(i + 1, i + 4);
+      if constexpr (ABL != 8) softmax_max(i + 1, masked);
+    } else {
+      if constexpr (ABL != 7) stage_k(i + 4);
+    }
+#pragma unroll
+    for (int step = 0; step < 2 * NT; ++step) {
+      const int cur = step % 3;
+      if (step + 2 < 2 * NT) {
+        load_v(vbase, step + 2, vlo[(step + 2) % 3], vhi[(step + 2) % 3]);
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vhi[cur][0]), "+v"(vhi[cur][1]), "+v"(vhi[cur][2]) :: "memory");
+      } else if (step + 1 < 2 * NT) {
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vhi[cur][0]), "+v"(vhi[cur][1]), "+v"(vhi[cur][2]) :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vhi[cur][0]), "+v"(vhi[cur][1]), "+v"(vhi[cur][2]) :: "memory");
+      }
+      if constexpr (ABL != 7) {
+        if (step < 3) stage_v_piece(i + 3, step);
+      }
+      const int t = step >> 1, s2 = step & 1;
+#pragma unroll
+      for (int d = 0; d < DTL; ++d) {
+        const u32x4 vfrag = {vlo[cur][d][0], vlo[cur][d][1], vhi[cur][d][0], vhi[cur][d][1]};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const u32x4 pb = {pk[g][t][4 * s2], pk[g][t][4 * s2 + 1], pk[g][t][4 * s2 + 2], pk[g][t][4 * s2 + 3]};
+          o[g][d] = mfma32<DT>(vfrag, pb, o[g][d]);
+        }
+      }
+      if constexpr (MORE && ABL != 8) {
+        if (s2 == 1) softmax_exp(t);   // P(i)'s tile t has been read: P(i+1)'s tile t takes its registers
+      }
+    }
+    if constexpr (MORE) softmax_end();
+  };
+  for (int i = 0; i + 2 < nkb; ++i) iteration(i, yes_t{}, no_t{});
+  if (nkb >= 2) iteration(nkb - 2, yes_t{}, yes_t{});
+  iteration(nkb - 1, no_t{}, no_t{});
+  if (!wave_active) return;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int q_idx = q0 + 32 * g + ql;
+    const float inv = 1.0f / half_swap_sum(l_run[g]);
+    if (q_idx < a.L) {
+      half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
+#pragma unroll
+      for (int d = 0; d < DTL; ++d)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int dd = 32 * d + 8 * r4 + 4 * hi;
+          if (dd < HD)
+            store_out4<DT, LO8>(a, orow + dd, o[g][d][4 * r4] * inv, o[g][d][4 * r4 + 1] * inv, o[g][d][4 * r4 + 2] * inv,
+                                o[g][d][4 * r4 + 3] * inv);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // attn_cross (round 3): the text cross-attention of LatteT2V (attn2, latte_t2v.py:740-760) for Lk <= 128 keys (Latte-1: 120 T5
 // tokens).  The generic flash kernel gave every 64 queries their own workgroup, each staging the sample's K / V through registers
 // in two 64-key tiles with an online softmax between them: 102 us per launch at the Latte-1 shape for 18 GFLOP and 150 MB.
@@ -1318,8 +1650,19 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
         void* args_[] = {(void*)&a};                                                                          \
         LATTE_HIP(hipLaunchKernel(fn_, grid, block, args_, STREAM_LDS, st));                                  \
       } else
+#define ATTN_STREAM64_ABLATIONS(DT)                                                                           \
+      if (a.variant >= 17 && a.variant <= 19 && DT == LATTE_DTYPE_F16) {                                      \
+        static std::atomic<uint64_t> attr_done_b[3];                                                          \
+        const void* fn_ = a.variant == 17 ? (const void*)attn_stream64_kernel<72, LATTE_DTYPE_F16, false, 7>  \
+                          : a.variant == 18 ? (const void*)attn_stream64_kernel<72, LATTE_DTYPE_F16, false, 8>\
+                                            : (const void*)attn_stream64_kernel<72, LATTE_DTYPE_F16, false, 9>;\
+        if (int rc_ = ensure_dynamic_lds(fn_, STREAM64_LDS, attr_done_b[a.variant - 17])) return rc_;         \
+        void* args_[] = {(void*)&a};                                                                          \
+        LATTE_HIP(hipLaunchKernel(fn_, grid, dim3(256), args_, STREAM64_LDS, st));                            \
+      } else
 #else
 #define ATTN_STREAM_ABLATIONS(HD, DT)
+#define ATTN_STREAM64_ABLATIONS(DT)
 #endif
 #define ATTN_LAUNCH(HD, DT)                                                                                   \
   do {                                                                                                        \
@@ -1329,7 +1672,12 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
       static std::atomic<uint64_t> attr_done_s{0};                                                            \
       if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
       ATTN_STREAM_ABLATIONS(HD, DT)                                                                           \
-      if (HD == 72 && a.variant == 11) {                                                                      \
+      ATTN_STREAM64_ABLATIONS(DT)                                                                             \
+      if (HD == 72 && a.variant == 12) {                                                                      \
+        static std::atomic<uint64_t> attr_done_s64{0};                                                        \
+        if (int rc_ = ensure_dynamic_lds((const void*)attn_stream64_kernel<72, DT>, STREAM64_LDS, attr_done_s64)) return rc_; \
+        hipLaunchKernelGGL((attn_stream64_kernel<72, DT>), grid, dim3(256), STREAM64_LDS, st, a);             \
+      } else if (HD == 72 && a.variant == 11) {                                                               \
         static std::atomic<uint64_t> attr_done_s32{0};                                                        \
         if (int rc_ = ensure_dynamic_lds((const void*)attn_stream32_kernel<72, DT>, STREAM32_LDS, attr_done_s32)) return rc_; \
         hipLaunchKernelGGL((attn_stream32_kernel<72, DT>), grid, block, STREAM32_LDS, st, a);                 \
@@ -1373,6 +1721,7 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
   }
 #undef ATTN_LAUNCH
 #undef ATTN_STREAM_ABLATIONS
+#undef ATTN_STREAM64_ABLATIONS
   LATTE_HIP(hipGetLastError());
   return LATTE_OK;
 }
