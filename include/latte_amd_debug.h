@@ -145,7 +145,9 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
 
 /* Kernel-choice overrides for the A/B tests (process-global; value 0 restores the library's own choice).  Every offered value
  * selects another implementation of the SAME function (results equal up to rounding):
- *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too
+ *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too, 11 | 12 = the
+ *                     round-6c forms of the streaming kernel on 32 x 32 x 16 MFMA tiles for head dim 72, L > 256 (8 waves x 32 queries | 4
+ *                     waves x 64 queries on one wave per SIMD; measured 4 % / 14 % slower than the default)
  *   "xattn_flash"     1 = the generic flash kernel for text cross-attention instead of the whole-panel kernel
  *   "tn_kernel"       4 = the 4-wave weight-gradient GEMM;   "tn_wn" 4 = its 256 x 128 tile
  *   "attn_bwd_tiles"  1 = the tiled attention-backward kernels for 16-token sequences too, 2 = also for 64 < L <= 256 (instead of the
@@ -156,7 +158,7 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
  *                     {mid block, up block 0..3} add the pass on the activation's f16 rounding residual, bits 5..9 = the temporal resnets of the
  *                     same stages run three passes (hi*hi + lo*hi + hi*lo) instead of one (csrc/vae_engine.cpp: vae_split_mask)
  * Anything else is refused (LATTE_ERR_INVALID).  Replaces the LATTE_* environment variables round 3 read at every launch; the
- * measurement ablations whose results are garbage (attention variants 7-9) exist only in a LATTE_DEBUG_BUILD=1 library. */
+ * measurement ablations whose results are garbage (attention variants 7-9, 17-19) exist only in a LATTE_DEBUG_BUILD=1 library. */
 int latte_debug_set_choice(const char* name, int value);
 
 #ifdef __cplusplus
