@@ -158,7 +158,7 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
  *                     {mid block, up block 0..3} add the pass on the activation's f16 rounding residual, bits 5..9 = the temporal resnets of the
  *                     same stages run three passes (hi*hi + lo*hi + hi*lo) instead of one (csrc/vae_engine.cpp: vae_split_mask)
  * Anything else is refused (LATTE_ERR_INVALID).  Replaces the LATTE_* environment variables round 3 read at every launch; the
- * measurement ablations whose results are garbage (attention variants 7-9, 17-19) exist only in a LATTE_DEBUG_BUILD=1 library. */
+ * measurement ablations whose results are garbage (attention variants 7-10, 16-19) exist only in a LATTE_DEBUG_BUILD=1 library. */
 int latte_debug_set_choice(const char* name, int value);
 
 #ifdef __cplusplus

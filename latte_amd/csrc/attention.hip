@@ -569,6 +569,15 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
                                          (__attribute__((address_space(3))) void*)(dst + (wave * 5 + j) * 1024), 16, 0, 0);
     }
   };
+  // (ABL 11, measurement build: the five pieces of block kb + 2 spread over the MFMA phases of block kb instead of issued together behind the
+  // barrier -- both waves of a SIMD are then not held at their DMA issues at the same time)
+  auto stage_piece = [&](int kb, int slot, int j) __attribute__((always_inline)) {
+    char* dst = smem_attn + slot * BLK;
+    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb * KB * a.row_stride) * ld);
+    const unsigned off = (ragged && kb == nkb - 1) ? lane_offset(j, kb) : voff[j];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
+                                     (__attribute__((address_space(3))) void*)(dst + (wave * 5 + j) * 1024), 16, 0, 0);
+  };
   stage(0, 0);
   if (nkb > 1) stage(1, 1);
 
@@ -595,6 +604,9 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt + 2 < NKT) load_k(kt + 2, kf[(kt + 2) & 3]);
+      if constexpr (ABL == 11) {
+        if ((kt & 1) == 1 && kb + 2 < nkb) stage_piece(kb + 2, (kb + 2) % 3, kt >> 1);   // pieces 0..3 behind key tiles 1, 3, 5, 7
+      }
       __builtin_amdgcn_sched_barrier(0);
       st[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       st[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -701,6 +713,9 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      if constexpr (ABL == 11) {
+        if (ks2 == 1 && kb + 2 < nkb) stage_piece(kb + 2, (kb + 2) % 3, 4);
+      }
       __builtin_amdgcn_sched_barrier(0);
       u32x4 pb[2];
 #pragma unroll
@@ -727,8 +742,11 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if constexpr (ABL != 7) {
+    if constexpr (ABL != 7 && ABL != 11) {
       if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
+    }
+    if constexpr (ABL == 11) {   // (a wave without queries still has to bring its pieces)
+      if (!wave_active && kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
     }
     if (wave_active) {
       scores(kb);
@@ -1640,13 +1658,14 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
                             : (stream ? dim3(a.num_seq * a.heads * ((a.L + 255) / 256)) : dim3(a.num_seq * a.heads * ((a.L + 63) / 64))));
 #ifdef LATTE_GEMM_ABLATE
 #define ATTN_STREAM_ABLATIONS(HD, DT)                                                                         \
-      if (a.variant >= 7 && a.variant <= 10 && HD == 72 && DT == LATTE_DTYPE_F16) {                            \
-        static std::atomic<uint64_t> attr_done_a[4];                                                          \
+      if (((a.variant >= 7 && a.variant <= 10) || a.variant == 16) && HD == 72 && DT == LATTE_DTYPE_F16) {                            \
+        static std::atomic<uint64_t> attr_done_a[5];                                                          \
         const void* fn_ = a.variant == 7 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 7>            \
                           : a.variant == 8 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 8>          \
                           : a.variant == 9 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 9>          \
-                                           : (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 10>;        \
-        if (int rc_ = ensure_dynamic_lds(fn_, STREAM_LDS, attr_done_a[a.variant - 7])) return rc_;            \
+                          : a.variant == 10 ? (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 10>        \
+                                           : (const void*)attn_stream_kernel<72, LATTE_DTYPE_F16, 11>;        \
+        if (int rc_ = ensure_dynamic_lds(fn_, STREAM_LDS, attr_done_a[a.variant == 16 ? 4 : a.variant - 7])) return rc_;            \
         void* args_[] = {(void*)&a};                                                                          \
         LATTE_HIP(hipLaunchKernel(fn_, grid, block, args_, STREAM_LDS, st));                                  \
       } else

@@ -30,11 +30,6 @@ def report(name, qkv):
         r = int(rows[0])
         print("   row", r, "got", o[r, :12].tolist(), "\n          want", w[r, :12].tolist())
 g = torch.Generator("cpu").manual_seed(1)
-if len(sys.argv) > 3:
-    a = torch.zeros(L, 3 * hd); a[:, 2 * hd:] = 1.0
-    o = run(a.cuda().half())
-    for r in (0, 1, 4, 5, 8, 12, 33, 36, 300): print("row", r, o[r, :8].tolist(), o[r, 60:72].tolist())
-    sys.exit(0)
 z = torch.zeros(L, 3 * hd)
 a = z.clone(); a[:, 2 * hd:] = 1.0
 report("q=0 k=0 v=1", a.cuda().half())
