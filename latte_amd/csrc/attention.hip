@@ -1055,8 +1055,12 @@ __global__ void __launch_bounds__(512) attn_stream32_kernel(AttnArgs a) {
 constexpr int S64_KP = 144, S64_VP = 160, S64_KB = 64, S64_NS = 4, S64_KIMG = S64_KB * S64_KP, S64_VIMG = S64_KB * S64_VP;
 constexpr int STREAM64_LDS = S64_NS * (S64_KIMG + S64_VIMG) + 256;
 
-template <int HD, int DT, bool LO8 = false, int ABL = 0>
-__global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
+// NG = 32-query groups per wave: 2 = the one-wave-per-SIMD form described above (4 waves); 1 = the SAME pipeline on 8 waves x 32 queries, two
+// waves per SIMD (everything fits the architectural registers: the S MFMAs are the compiler's) -- `attn_variant` 13.
+template <int HD, int DT, bool LO8 = false, int ABL = 0, int NG = 2>
+__global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
+  constexpr int NWV = 8 / NG;                    // waves
+  constexpr int NPC = 19, NPW = (NPC + NWV - 1) / NWV;   // DMA pieces per issue group (9 K + 10 V), per wave
   constexpr int KS = (HD + 15) / 16, DTL = (HD + 31) / 32, NCH = HD / 8;
   constexpr int KP = S64_KP, VP = S64_VP, KB = S64_KB, NT = KB / 32, KIMG = S64_KIMG, VIMG = S64_VIMG, NS = S64_NS;
   static_assert(HD == 72, "written for 9-chunk rows");
@@ -1086,12 +1090,12 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   const int64_t base = seq_base_row(a, seq);
   const size_t ld = (size_t)3 * a.D;
   const half_t* qkv_h = a.qkv + (size_t)head * HD;
-  const int q0 = qb * 256 + wave * 64;
+  const int q0 = qb * 256 + wave * 32 * NG;
   const int nkb = (a.L + KB - 1) / KB;
 
-  u32x4 qf[2][KS];
+  u32x4 qf[NG][KS];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int q_ld = min(q0 + 32 * g + ql, a.L - 1);
     const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
 #pragma unroll
@@ -1104,76 +1108,70 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   // (the loads complete here; "+a": the Q fragments live in the accumulator half of the register file for the whole kernel -- MFMA
   // reads its B operand from there directly -- which leaves the architectural half to the scores and the softmax)
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(qf[g][ks]));
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (NG == 2) asm volatile("" : "+a"(qf[g][ks]));
+      else asm volatile("" : "+v"(qf[g][ks]));
+    }
 
   // DMA.  K image of a 64-key block: 9 instructions (9 chunks x 64 rows); V image: 10 (10 chunks x 64 rows, LDS row r holds key
-  // (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)).  EVERY wave issues three pieces per image and block -- piece j of wave w is
-  // instruction min(w + 4 j, last): a few pieces are written twice with the same bytes -- and a block past the end re-reads the last
-  // block into the (free) slot it would have taken: no branch around a DMA piece, one vmcnt value for every wave and iteration.
-  auto k_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
-    const int idx = min(wave + 4 * j, 8) * 64 + lane;
-    const int row = idx / 9, ch = idx - row * 9;
-    const int key_ld = min(row, a.L - 1 - kb * KB);
-    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch * 8 + a.D) * 2);
-  };
-  auto v_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
-    const int idx = min(wave + 4 * j, 9) * 64 + lane;
-    const int row = idx / 10, ch = idx - row * 10;
-    const int key = (row & ~7) | ((row & 1) << 2) | ((row >> 1) & 3);
+  // (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3)).  An issue group G(j) = [K(j + 1), V(j)] is 19 pieces; EVERY wave issues NPW of them --
+  // piece j of wave w is min(w + NWV j, 18): the last V piece is written more than once with the same bytes -- and a block past the end
+  // re-reads the last block into the (free) slot it would have taken: no branch around a DMA piece, one vmcnt value for every wave
+  // and iteration.
+  auto piece_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
+    const int pc = min(wave + NWV * j, NPC - 1);
+    const bool isv = pc >= 9;
+    const int idx = (isv ? pc - 9 : pc) * 64 + lane;
+    const int row = isv ? idx / 10 : idx / 9, ch = idx - row * (isv ? 10 : 9);
+    const int key = isv ? ((row & ~7) | ((row & 1) << 2) | ((row >> 1) & 3)) : row;
     const int key_ld = min(key, a.L - 1 - kb * KB), ch_ld = min(ch, NCH - 1);
-    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch_ld * 8 + 2 * a.D) * 2);
+    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch_ld * 8 + (isv ? 2 : 1) * a.D) * 2);
   };
-  unsigned koff[3], voff[3], koff_l[3], voff_l[3];   // whole blocks / the last block (rows >= L re-read row L - 1: they meet P = 0)
+  unsigned poff[NPW], poff_l[NPW];   // whole blocks / the last block (rows >= L re-read row L - 1: they meet P = 0)
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    koff[j] = k_offset(j, 0); voff[j] = v_offset(j, 0);
-    koff_l[j] = k_offset(j, nkb - 1); voff_l[j] = v_offset(j, nkb - 1);
+  for (int j = 0; j < NPW; ++j) {
+    poff[j] = piece_offset(j, 0);
+    poff_l[j] = piece_offset(j, nkb - 1);
   }
-  auto stage_k_piece = [&](int kb, int j) __attribute__((always_inline)) {
-    const int kb_ld = min(kb, nkb - 1);
-    char* dst = kring + (kb % NS) * KIMG;
+  auto stage_piece = [&](int kbk, int kbv, int j) __attribute__((always_inline)) {
+    const int pc = min(wave + NWV * j, NPC - 1);
+    const bool isv = pc >= 9;
+    const int kb = isv ? kbv : kbk, kb_ld = min(kb, nkb - 1);
+    char* dst = isv ? vring + (kb % NS) * VIMG + (pc - 9) * 1024 : kring + (kb % NS) * KIMG + pc * 1024;
     const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb_ld * KB * a.row_stride) * ld);
-    const unsigned off = kb_ld == nkb - 1 ? koff_l[j] : koff[j];
+    const unsigned off = kb_ld == nkb - 1 ? poff_l[j] : poff[j];
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
-                                     (__attribute__((address_space(3))) void*)(dst + min(wave + 4 * j, 8) * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  auto stage_v_piece = [&](int kb, int j) __attribute__((always_inline)) {
-    const int kb_ld = min(kb, nkb - 1);
-    char* dst = vring + (kb % NS) * VIMG;
-    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb_ld * KB * a.row_stride) * ld);
-    const unsigned off = kb_ld == nkb - 1 ? voff_l[j] : voff[j];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
-                                     (__attribute__((address_space(3))) void*)(dst + min(wave + 4 * j, 9) * 1024), 16, 0, 0);
-  };
-  auto stage_k = [&](int kb) __attribute__((always_inline)) {
+  auto stage_group = [&](int kbk, int kbv) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) stage_k_piece(kb, j);
+    for (int j = 0; j < NPW; ++j) stage_piece(kbk, kbv, j);
   };
-  auto stage_v = [&](int kb) __attribute__((always_inline)) {
+  // [K(0)] (its pieces only), then G(0..2) here, G(i + 3) in iteration i
 #pragma unroll
-    for (int j = 0; j < 3; ++j) stage_v_piece(kb, j);
-  };
-  // issue groups: [K(0)], then G(j) = [K(j + 1), V(j)]; G(0..2) here, G(i + 3) in iteration i
-  stage_k(0);
-  stage_k(1); stage_v(0);
-  stage_k(2); stage_v(1);
-  stage_k(3); stage_v(2);
+  for (int j = 0; j < NPW; ++j)
+    if (wave + NWV * j < 9) stage_piece(0, 0, j);
+  stage_group(1, 0);
+  stage_group(2, 1);
+  stage_group(3, 2);
 
   const float c = a.scale * 1.4426950408889634f;
-  f32x16 o[2][DTL];
+  f32x16 o[NG][DTL];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int d = 0; d < DTL; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[g][d][r] = 0.f;
-  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f}, ls[2] = {0.f, 0.f};
+  float m_run[NG], l_run[NG], alpha[NG], nm[NG], ls[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { m_run[g] = NEG_BIG; l_run[g] = 0.f; alpha[g] = 1.f; nm[g] = 0.f; ls[g] = 0.f; }
   bool raised = false;
   const bool wave_active = q0 < a.L;
-  f32x16 st[2][NT];
-  unsigned pk[2][NT][8];
+  f32x16 st[NG][NT];
+  unsigned pk[NG][NT][8];
 
   const int kread = ql * KP + hi * 16;
   const int vread = (2 * ((lane & 15) >> 2) + hi) * VP + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
@@ -1190,19 +1188,31 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + t * 32 * KP + ks * 32);
     };
+    static_assert(NT == 2, "both key tiles' fragments are held at once");
     load_k(0, kf[0]);
+    load_k(1, kf[1]);
+    // k-step outermost: the NT NG accumulator chains advance in turn (a chain's next MFMA waits for its previous result: 16 passes)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t + 1 < NT) load_k(t + 1, kf[(t + 1) & 1]);
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (ABL != 7 && dma_kb >= 0) {   // (the prologue call passes -1: compile-time after inlining)
-            if (g == 0 && ks == 2 && t == 0) stage_k_piece(dma_kb, 0);   // behind 4 / 14 / 18 MFMAs of the phase
-            if (g == 0 && ks == 2 && t == 1) stage_k_piece(dma_kb, 1);
-            if (g == 0 && ks == 4 && t == 1) stage_k_piece(dma_kb, 2);
+        for (int g = 0; g < NG; ++g) {
+          if (ABL != 7 && dma_kb >= 0 && g == 0) {   // (the prologue call passes -1: compile-time after inlining)
+            if constexpr (NG == 2) {
+              if (ks == 1 && t == 0) stage_piece(dma_kb + 1, dma_kb, 0);   // pieces 0, 1 of G(dma_kb) behind 4 / 12 MFMAs of the phase
+              if (ks == 3 && t == 0) stage_piece(dma_kb + 1, dma_kb, 1);
+            } else {
+              if (ks == 2 && t == 0) stage_piece(dma_kb + 1, dma_kb, 0);
+            }
           }
+          if constexpr (NG == 1) {
+            if (ks == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) st[g][t][r] = 0.f;
+            }
+            st[g][t] = mfma32<DT>(kf[t & 1][ks], qf[g][ks], st[g][t]);
+          } else
           if constexpr (DT == LATTE_DTYPE_BF16) {
             if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
             else if (ks + 1 < KS) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(st[g][t]) : "v"(kf[t & 1][ks]), "a"(qf[g][ks]));
@@ -1219,7 +1229,7 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   auto softmax_max = [&](int kb, auto masked) __attribute__((always_inline)) {
     raised = false;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
       if constexpr (decltype(masked)::value) {
         const int kleft = a.L - kb * KB;
         if (kleft < KB) {
@@ -1254,7 +1264,7 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   // part 2, one key tile: exponentials -> packed P (in place), row-sum chain
   auto softmax_exp = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(fma1(st[g][t][r], c, nm[g]));
@@ -1266,7 +1276,7 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   };
   auto softmax_end = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) l_run[g] = l_run[g] * alpha[g] + ls[g];
+    for (int g = 0; g < NG; ++g) l_run[g] = l_run[g] * alpha[g] + ls[g];
   };
 
   // V^T fragments of k-step `step` of the block at vbase (two transpose reads per d tile); completion is counted by hand
@@ -1278,7 +1288,8 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   };
 
   // prologue: K(0) landed (G(0..2) may stay in flight: 3 x (nk + nv) instructions of this wave) -> S(0), softmax(0) with nothing beside it
-  asm volatile("s_waitcnt vmcnt(18)" ::: "memory");   // K(0): everything but G(0..2), 6 pieces each
+  if constexpr (NG == 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // K(0): everything but G(0..2), NPW pieces each
+  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
@@ -1293,10 +1304,13 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   // MASKED = block i+1 may be ragged: the steady-state instance (MORE, not MASKED) has no branch between its MFMAs.
   auto iteration = [&](int i, auto more, auto masked) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more)::value;
-    if constexpr (ABL != 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // G(i) landed; G(i+1), G(i+2) may stay in flight
+    if constexpr (ABL != 9) {   // G(i) landed; G(i+1), G(i+2) may stay in flight
+      if constexpr (NG == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     if constexpr (ABL != 9) __builtin_amdgcn_s_barrier();
     if (!wave_active) {
-      if constexpr (ABL != 7) { stage_k(i + 4); stage_v(i + 3); }
+      if constexpr (ABL != 7) stage_group(i + 4, i + 3);
       return;
     }
     // V^T fragments of P(i)'s first two k-steps are requested before anything else (V(i) has landed): three buffers, two steps ahead
@@ -1306,17 +1320,20 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
     load_v(vbase, 1, vlo[1], vhi[1]);
     if (raised) {   // the accumulators meet P(i): rescale by the factor softmax(i) found
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int d = 0; d < DTL; ++d)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha[g];
     }
     if constexpr (MORE) {
-      scores(i + 1, i + 4);
+      scores(i + 1, i + 3);
       if constexpr (ABL != 8) softmax_max(i + 1, masked);
     } else {
-      if constexpr (ABL != 7) stage_k(i + 4);
+      if constexpr (ABL != 7) {
+        stage_piece(i + 4, i + 3, 0);
+        if constexpr (NG == 2) stage_piece(i + 4, i + 3, 1);
+      }
     }
 #pragma unroll
     for (int step = 0; step < 2 * NT; ++step) {
@@ -1329,15 +1346,19 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vhi[cur][0]), "+v"(vhi[cur][1]), "+v"(vhi[cur][2]) :: "memory");
       }
-      if constexpr (ABL != 7) {
-        if (step < 3) stage_v_piece(i + 3, step);
+      if constexpr (ABL != 7) {   // the group's remaining pieces between the k-steps
+        if constexpr (NG == 2) {
+          if (step < 3) stage_piece(i + 4, i + 3, 2 + step);
+        } else {
+          if (step == 0 || step == 2) stage_piece(i + 4, i + 3, 1 + step / 2);
+        }
       }
       const int t = step >> 1, s2 = step & 1;
 #pragma unroll
       for (int d = 0; d < DTL; ++d) {
         const u32x4 vfrag = {vlo[cur][d][0], vlo[cur][d][1], vhi[cur][d][0], vhi[cur][d][1]};
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < NG; ++g) {
           const u32x4 pb = {pk[g][t][4 * s2], pk[g][t][4 * s2 + 1], pk[g][t][4 * s2 + 2], pk[g][t][4 * s2 + 3]};
           o[g][d] = mfma32<DT>(vfrag, pb, o[g][d]);
         }
@@ -1353,7 +1374,7 @@ __global__ void __launch_bounds__(256) attn_stream64_kernel(AttnArgs a) {
   iteration(nkb - 1, no_t{}, no_t{});
   if (!wave_active) return;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int q_idx = q0 + 32 * g + ql;
     const float inv = 1.0f / half_swap_sum(l_run[g]);
     if (q_idx < a.L) {
@@ -1692,7 +1713,11 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
       if (int rc_ = ensure_dynamic_lds((const void*)attn_stream_kernel<HD, DT>, STREAM_LDS, attr_done_s)) return rc_; \
       ATTN_STREAM_ABLATIONS(HD, DT)                                                                           \
       ATTN_STREAM64_ABLATIONS(DT)                                                                             \
-      if (HD == 72 && a.variant == 12) {                                                                      \
+      if (HD == 72 && a.variant == 13) {                                                                      \
+        static std::atomic<uint64_t> attr_done_s64b{0};                                                       \
+        if (int rc_ = ensure_dynamic_lds((const void*)attn_stream64_kernel<72, DT, false, 0, 1>, STREAM64_LDS, attr_done_s64b)) return rc_; \
+        hipLaunchKernelGGL((attn_stream64_kernel<72, DT, false, 0, 1>), grid, dim3(512), STREAM64_LDS, st, a); \
+      } else if (HD == 72 && a.variant == 12) {                                                               \
         static std::atomic<uint64_t> attr_done_s64{0};                                                        \
         if (int rc_ = ensure_dynamic_lds((const void*)attn_stream64_kernel<72, DT>, STREAM64_LDS, attr_done_s64)) return rc_; \
         hipLaunchKernelGGL((attn_stream64_kernel<72, DT>), grid, dim3(256), STREAM64_LDS, st, a);             \

@@ -31,7 +31,8 @@ int set_debug_choice(const char* name, int value) {
     if (name && std::string(name) == names[i]) {
       bool ok = value == 0;
       for (int k = 0; k < 4; ++k) ok = ok || (allowed[i][k] != 0 && value == allowed[i][k]);
-      ok = ok || (i == DBG_VAE_SPLIT && (value >> 24) == 1);   // (1 << 24) | pass mask (vae_engine.cpp: vae_split_mask)
+      ok = ok || (i == DBG_VAE_SPLIT && (value >> 24) == 1);
+      ok = ok || (i == DBG_ATTN_VARIANT && value == 13);   // (the table above has four slots)   // (1 << 24) | pass mask (vae_engine.cpp: vae_split_mask)
 #ifdef LATTE_GEMM_ABLATE
       ok = ok || (i == DBG_ATTN_VARIANT && value >= 7 && value <= 19);   // measurement build: attn_stream ablations (results garbage)
 #endif
