@@ -145,9 +145,9 @@ int latte_debug_dma_probe(const void* src, long long* out, int mode, int waves, 
 
 /* Kernel-choice overrides for the A/B tests (process-global; value 0 restores the library's own choice).  Every offered value
  * selects another implementation of the SAME function (results equal up to rounding):
- *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too, 11 | 12 | 13 = the
- *                     round-6c forms of the streaming kernel on 32 x 32 x 16 MFMA tiles for head dim 72, L > 256 (8 waves x 32 queries | 4
- *                     waves x 64 queries on one wave per SIMD | that pipeline on 8 waves; measured +4 % / +14 % / -1 % against the default,
+ *   "attn_variant"    1 = the generic flash kernel for every L > 16, 5 = the streaming kernel for 128 < L <= 256 too, 12 | 13 = the
+ *                     round-6c forms of the streaming kernel on 32 x 32 x 16 MFMA tiles for head dim 72, L > 256 (4 waves x 64 queries on
+ *                     one wave per SIMD with the softmax inside the P V stream | that pipeline on 8 waves; measured +14 % / -1 % against the default,
  *                     DESIGN.md section 4.2)
  *   "xattn_flash"     1 = the generic flash kernel for text cross-attention instead of the whole-panel kernel
  *   "tn_kernel"       4 = the 4-wave weight-gradient GEMM;   "tn_wn" 4 = its 256 x 128 tile

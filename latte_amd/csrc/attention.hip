@@ -773,19 +773,14 @@ __global__ void __launch_bounds__(512) attn_stream_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// attn_stream32 (round 6c): the L > 256 kernel on the 32 x 32 x 16 MFMA shape.  Same workgroup (8 waves, 256 queries of a (sequence,
-// head), 32 per wave), same ring of three 128-key blocks written by LDS DMA, same online softmax -- what changes is the fragment shape:
+// Round 6c: the L > 256 attention on the 32 x 32 x 16 MFMA shape (attn_stream64_kernel below; the first form, attn_stream32_kernel -- the
+// 8-wave kernel above with these tiles and nothing else changed: 251.8 against 243.2 us -- is `git show 9a6a033:latte_amd/csrc/attention.hip`).
 //   S^T = K Q^T as 32-key x 32-query tiles: a lane holds, for ITS query (lane & 31), 16 keys of every tile (key = (r & 3) + 8 (r >> 2) +
 //   4 (lane >> 5)), so the row maximum and the row sum are in-lane chains with one half-wave exchange (v_permlane32_swap) per block for the
 //   maximum and one per launch for the sum -- no ds_bpermute in the loop;
 //   O^T = V^T P^T: registers 8 s .. 8 s + 7 of a tile ARE the B operand of k-step s (k-slot 8 hi + j <-> key 16 s + 4 hi + (j & 3) +
-//   8 (j >> 2)) -- P is packed to half where it is produced and never moves; the V^T operand comes from two transpose reads per d tile;
-//   44 MFMAs of 32 cycles per block and wave instead of 88 of 16: half the matrix issue slots, gaps of 8 slots for the softmax of the
-//   partner wave, whose arithmetic is kept on single-issue fp32 forms (a packed fp32 instruction beside MFMAs costs 20+ cycles,
-//   MI355X_MICROARCH "price of one filler").
-// LDS image of a block: K rows at a pitch of 144 bytes (9 chunks: conflict-free ds_read_b128 for 32-row fragments), V rows at the same
-// pitch with the keys of every 16-key group stored 4 x 4 transposed (key 16 b + 4 q + i -> row 16 b + 4 i + q): the four key rows a
-// 32-lane group of a transpose read touches are then 16 banks apart.
+//   8 (j >> 2)) -- P is packed to half where it is produced and never moves; the V^T operand comes from two transpose reads per d tile.
+// K rows sit at a pitch of 144 bytes (9 chunks: conflict-free ds_read_b128 for 32-row fragments).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <int DT>
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
@@ -818,240 +813,19 @@ __device__ __forceinline__ float half_swap_sum(float x) {
   return r0 + r1;
 }
 
-constexpr int S32_RP = 144, S32_KB = 128, S32_IMG = S32_KB * S32_RP, S32_BLK = 2 * S32_IMG;   // 36 KB per block
-constexpr int STREAM32_LDS = 3 * S32_BLK + 256;   // (the d tile past the head dim reads up to 48 bytes beyond its row)
-
-template <int HD, int DT, bool LO8 = false, int ABL = 0>
-__global__ void __launch_bounds__(512) attn_stream32_kernel(AttnArgs a) {
-  constexpr int KS = (HD + 15) / 16, DTL = (HD + 31) / 32, NCH = HD / 8;   // QK^T k-steps, 32-wide d tiles, 16-byte chunks per row
-  constexpr int RP = S32_RP, KB = S32_KB, NT = KB / 32, IMG = S32_IMG, BLK = S32_BLK;
-  constexpr int NINST = 2 * IMG / 1024;                // 36 DMA instructions per block: waves 0-3 issue 5, waves 4-7 issue 4
-  static_assert(NCH <= 9 && NINST == 36, "the DMA split below is written for 9-chunk rows");
-  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ql = lane & 31, hi = lane >> 5;
-  const int qblocks = (a.L + 255) >> 8;
-  int seq, head, qb;
-  {
-    int b = blockIdx.x;
-    const int per_seq = a.heads * qblocks;
-    if ((a.num_seq & 7) == 0) {   // the heads and query blocks of one sequence on ONE XCD (shared K / V panels, shared output lines)
-      const int xcd = b & 7, slot = b >> 3;
-      seq = (slot / per_seq) * 8 + xcd;
-      b = slot % per_seq;
-    } else {
-      seq = b / per_seq;
-      b = b % per_seq;
-    }
-    head = b / qblocks;
-    qb = b % qblocks;
-  }
-  const int64_t base = seq_base_row(a, seq);
-  const size_t ld = (size_t)3 * a.D;
-  const half_t* qkv_h = a.qkv + (size_t)head * HD;
-  const int q0 = qb * 256 + wave * 32;
-  const int nkb = (a.L + KB - 1) / KB;
-
-  // Q fragments (B operand: n = query, k-slot 8 hi + j <-> d = 16 ks + 8 hi + j), complete before any DMA is issued
-  u32x4 qf[KS];
-  {
-    const int q_ld = min(q0 + ql, a.L - 1);
-    const half_t* qrow = qkv_h + (size_t)(base + (int64_t)q_ld * a.row_stride) * ld;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int ch = 2 * ks + hi;
-      qf[ks] = (u32x4){0u, 0u, 0u, 0u};
-      if (ch < NCH) qf[ks] = *(const u32x4*)(qrow + ch * 8);
-    }
-  }
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-
-  // DMA: instruction i of a block (0..17 K image, 18..35 V image) writes LDS bytes [1024 i, 1024 i + 1024) of the block; its lane
-  // l carries chunk idx = 64 (i mod 18) + l of the image = (LDS row idx / 9, chunk idx % 9).  K: row = key.  V: row 16 b + 4 i + q holds
-  // key 16 b + 4 q + i.  Per-lane source offsets are block-independent (32-bit); a ragged last block re-forms them (rows >= L re-read
-  // row L - 1: they meet P = 0 and finite data).
-  const int ninst = wave < 4 ? 5 : 4;
-  unsigned voff[5];
-  auto lane_offset = [&](int j, int kb) __attribute__((always_inline)) -> unsigned {
-    const int inst = wave + 8 * j;
-    const bool isv = inst >= 18;
-    const int idx = (isv ? inst - 18 : inst) * 64 + lane;
-    const int row = idx / 9, ch = idx - row * 9;
-    const int key = isv ? ((row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3)) : row;
-    const int key_ld = min(key, a.L - 1 - kb * KB), ch_ld = min(ch, NCH - 1);
-    return (unsigned)(((int64_t)key_ld * a.row_stride * (int64_t)ld + ch_ld * 8 + (isv ? 2 : 1) * a.D) * 2);
-  };
-#pragma unroll
-  for (int j = 0; j < 5; ++j) voff[j] = lane_offset(j, 0);
-  const bool ragged = (a.L % KB) != 0;
-  auto stage = [&](int kb, int slot) __attribute__((always_inline)) {
-    char* dst = smem_attn + slot * BLK;
-    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb * KB * a.row_stride) * ld);   // wave-uniform
-    const bool rag = ragged && kb == nkb - 1;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (j < 4 || wave < 4) {
-        const unsigned off = rag ? lane_offset(j, kb) : voff[j];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
-                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * j) * 1024), 16, 0, 0);
-      }
-    }
-  };
-  stage(0, 0);
-  if (nkb > 1) stage(1, 1);
-
-  const float c = a.scale * 1.4426950408889634f;
-  f32x16 o[DTL];
-#pragma unroll
-  for (int d = 0; d < DTL; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;   // l_run: this lane's half of the keys
-  const bool wave_active = q0 < a.L;
-  f32x16 st[NT];            // S^T of the block
-  unsigned pk[NT][8];       // P packed to half: word w of tile t = registers 2 w, 2 w + 1
-
-  const int kread = ql * RP + hi * 16;                                              // K fragment: row = key, 16 bytes at 32 ks + 16 hi
-  const int vread = (4 * ((lane & 15) >> 2) + hi) * RP + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;   // V^T fragment, see above
-
-  auto scores = [&](int kb) __attribute__((always_inline)) {
-    const char* kbase = smem_attn + (kb % 3) * BLK + kread;
-    u32x4 kf[2][KS];
-    auto load_k = [&](int t, u32x4 (&dst)[KS]) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const u32x4*)(kbase + t * 32 * RP + ks * 32);
-    };
-    load_k(0, kf[0]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t + 1 < NT) load_k(t + 1, kf[(t + 1) & 1]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) st[t] = mfma32<DT>(kf[t & 1][ks], qf[ks], st[t]);
-    }
-  };
-  auto softmax = [&](int kb) __attribute__((always_inline)) {
-    const int kleft = a.L - kb * KB;
-    if (kleft < KB) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi >= kleft) st[t][r] = NEG_BIG;
-    }
-    float mx = NEG_BIG;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-    mx = half_swap_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // first block: exp2(-huge) = 0 on o = l = 0
-    const float nm = -m_new * c;
-    // the sum is ONE chain of compiler-generated adds: two chains would be paired into v_pk_add_f32, and an inline-assembly add on the
-    // result of v_exp_f32 is outside the compiler's trans-use hazard handling (it read stale lanes on the GPU)
-    float ls = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fma1(st[t][r], c, nm));
-        const float p1 = __builtin_amdgcn_exp2f(fma1(st[t][r + 1], c, nm));
-        pk[t][r >> 1] = pack2<DT>(p0, p1);
-        ls += p0;
-        ls += p1;
-      }
-    l_run = l_run * alpha + ls;
-    const bool raised = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;   // nobody raised: alpha is exactly 1 in every lane
-    m_run = m_new;
-    if (raised) {
-#pragma unroll
-      for (int d = 0; d < DTL; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-  };
-  // O^T += V^T P^T: per k-step (tile t = step / 2, s = step % 2) two transpose reads per d tile (keys 16 s + 4 hi + 0..3 and + 8), one
-  // step ahead; the reads are inline assembly (in front of the builtin hipcc drains the LDS DMA in flight), their completion is counted here
-  auto weighted_sum = [&](int kb) __attribute__((always_inline)) {
-    const char* vbase = smem_attn + (kb % 3) * BLK + IMG + vread;
-    u32x2 vlo[2][DTL], vhi[2][DTL];
-    auto load_v = [&](int step, u32x2 (&lo)[DTL], u32x2 (&hi2)[DTL]) {
-      const char* pv = vbase + 16 * step * RP;
-      lo[0] = lds_tr16_asm<0>(pv); hi2[0] = lds_tr16_asm<2 * RP>(pv);
-      if constexpr (DTL > 1) { lo[1] = lds_tr16_asm<64>(pv); hi2[1] = lds_tr16_asm<2 * RP + 64>(pv); }
-      if constexpr (DTL > 2) { lo[2] = lds_tr16_asm<128>(pv); hi2[2] = lds_tr16_asm<2 * RP + 128>(pv); }
-    };
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    load_v(0, vlo[0], vhi[0]);
-#pragma unroll
-    for (int step = 0; step < 2 * NT; ++step) {
-      if (step + 1 < 2 * NT) {
-        load_v(step + 1, vlo[(step + 1) & 1], vhi[(step + 1) & 1]);
-        if constexpr (DTL == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const int t = step >> 1, s2 = step & 1;
-      const u32x4 pb = {pk[t][4 * s2], pk[t][4 * s2 + 1], pk[t][4 * s2 + 2], pk[t][4 * s2 + 3]};
-#pragma unroll
-      for (int d = 0; d < DTL; ++d) {
-        const u32x4 vfrag = {vlo[step & 1][d][0], vlo[step & 1][d][1], vhi[step & 1][d][0], vhi[step & 1][d][1]};
-        o[d] = mfma32<DT>(vfrag, pb, o[d]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (kb + 1 < nkb) {
-      if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
-    if (wave_active) {
-      scores(kb);
-      if constexpr (ABL != 8) softmax(kb);
-      weighted_sum(kb);
-    }
-  }
-  if (!wave_active) return;
-  const int q_idx = q0 + ql;
-  const float inv = 1.0f / half_swap_sum(l_run);
-  if (q_idx < a.L) {
-    half_t* orow = a.out + (size_t)(base + (int64_t)q_idx * a.row_stride) * a.D + head * HD;
-#pragma unroll
-    for (int d = 0; d < DTL; ++d)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int dd = 32 * d + 8 * r4 + 4 * hi;
-        if (dd < HD)
-          store_out4<DT, LO8>(a, orow + dd, o[d][4 * r4] * inv, o[d][4 * r4 + 1] * inv, o[d][4 * r4 + 2] * inv, o[d][4 * r4 + 3] * inv);
-      }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // attn_stream64 (round 6c): L > 256, head dim 72, on ONE wave per SIMD.  A workgroup is 4 waves = 256 queries of a (sequence, head);
 // a wave owns 64 queries (two 32-query column groups) and the whole 512-register file, so every K fragment and every V^T fragment
-// read from LDS feeds TWO MFMAs (the 8-wave kernels above read one fragment per MFMA-pair of half the size: their LDS pipe is as
-// busy as their matrix pipe), and the softmax is software-pipelined against the matrix work inside the wave:
+// read from LDS feeds TWO MFMAs, and the softmax is software-pipelined against the matrix work inside the wave:
 //   iteration i:  phase 1   S(i+1) = K(i+1) Q^T, both groups            (40 MFMAs, 20 ds_read_b128)
 //                 phase 2   O += V(i)^T P(i)^T, both groups             (48 MFMAs, 48 transpose reads)
 //                           with the softmax of block i+1 -- S(i+1) -> P(i+1) -- in the same instruction stream: the exponentials of
 //                           key tile t are written over P(i)'s tile t after the MFMAs that read it have been issued.
-// K and V have their own rings of three blocks (K(i+1) and V(i) are read in the same iteration); one barrier per iteration.
-// Fragment shapes, the key order of P and the K image are attn_stream32's; the V image has a pitch of 160 bytes (the tenth chunk is
-// padding) with the keys of every 8-key group stored as key 8 b + 4 h + i -> row 8 b + 2 i + h.
+// 64-key blocks; K and V have their own rings of four (K(i+1) and V(i) are read in the same iteration); one barrier per iteration.
+// The V image has a pitch of 160 bytes (the tenth chunk is padding) with the keys of every 8-key group stored as key 8 b + 4 h + i -> row
+// 8 b + 2 i + h: the four key rows a 32-lane group of a transpose read touches are then 16 banks apart.
+// Measured (profiles/r6c_attn_stream32_stream64_probe.log): 278 us (NG = 2) / 248 us (NG = 1) against the 8-wave
+// 16 x 16 kernel's 243 - 251 us on the Latte-1 shape -- NOT the default; kept as the worked example of the shape and of what it costs.
 constexpr int S64_KP = 144, S64_VP = 160, S64_KB = 64, S64_NS = 4, S64_KIMG = S64_KB * S64_KP, S64_VIMG = S64_KB * S64_VP;
 constexpr int STREAM64_LDS = S64_NS * (S64_KIMG + S64_VIMG) + 256;
 
@@ -1721,10 +1495,6 @@ int launch_attention(const AttnArgs& a_in, int dtype, hipStream_t st) {
         static std::atomic<uint64_t> attr_done_s64{0};                                                        \
         if (int rc_ = ensure_dynamic_lds((const void*)attn_stream64_kernel<72, DT>, STREAM64_LDS, attr_done_s64)) return rc_; \
         hipLaunchKernelGGL((attn_stream64_kernel<72, DT>), grid, dim3(256), STREAM64_LDS, st, a);             \
-      } else if (HD == 72 && a.variant == 11) {                                                               \
-        static std::atomic<uint64_t> attr_done_s32{0};                                                        \
-        if (int rc_ = ensure_dynamic_lds((const void*)attn_stream32_kernel<72, DT>, STREAM32_LDS, attr_done_s32)) return rc_; \
-        hipLaunchKernelGGL((attn_stream32_kernel<72, DT>), grid, block, STREAM32_LDS, st, a);                 \
       } else                                                                                                  \
       hipLaunchKernelGGL((attn_stream_kernel<HD, DT>), grid, block, STREAM_LDS, st, a);                       \
     } else if (full) {                                                                                          \

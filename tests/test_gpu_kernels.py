@@ -176,11 +176,11 @@ def test_attention(lib, dev, dt, case, mode):
 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] > 128])
-@pytest.mark.parametrize("variant", [1, 5, 11, 12, 13])
+@pytest.mark.parametrize("variant", [1, 5, 12, 13])
 def test_attention_long_sequence_kernels_forced(lib, dev, dt, case, variant, kernel_choice):
     """The spatial cases with more than 128 tokens through the kernels the default choice does not take for them: 1 = the generic
-    flash kernel, 5 = the streaming kernel (also for 128 < L <= 256, where the single-block kernel is the default), 11 / 12 = the
-    round-6c forms of the streaming kernel on the 32 x 32 x 16 MFMA shape for head dim 72 and L > 256 (8 waves x 32 queries; 4 waves x
+    flash kernel, 5 = the streaming kernel (also for 128 < L <= 256, where the single-block kernel is the default), 12 / 13 = the
+    round-6c forms of the streaming kernel on the 32 x 32 x 16 MFMA shape for head dim 72 and L > 256 (12: 4 waves x
     64 queries, one wave per SIMD, software-pipelined, lazy reference maximum; 13 = that pipeline on 8 waves x 32 queries) -- other shapes take
     the default kernel under them."""
     kernel_choice("attn_variant", variant)
@@ -235,17 +235,17 @@ def test_attention_forced_rescale(lib, dev):
 
 
 @pytest.mark.parametrize("hd,spike_key", [(72, 900), (64, 300), (72, 1023)])
-@pytest.mark.parametrize("kernel", ["stream", "flash", "stream32", "stream64", "stream64_8w"])
+@pytest.mark.parametrize("kernel", ["stream", "flash", "stream64", "stream64_8w"])
 def test_attention_blocks_forced_rescale(lib, dev, hd, spike_key, kernel, kernel_choice):
     """The online-softmax kernels for L > 256 (L = 1024: the streaming kernel with its ring of 128-key blocks, and the generic
     64-key-tile flash kernel it falls back to): a key in a LATE block dominates one query, so the running maximum jumps and
     the accumulated output / sum of the earlier blocks must be rescaled (guide section 5.4 rule 26); fp64 reference."""
     if kernel == "flash":
         kernel_choice("attn_variant", 1)
-    if kernel in ("stream32", "stream64", "stream64_8w"):   # (stream64 raises its reference maximum lazily: the spikes are what forces the raise)
+    if kernel in ("stream64", "stream64_8w"):   # (stream64 raises its reference maximum lazily: the spikes are what forces the raise)
         if hd != 72:
             pytest.skip("the 32 x 32 x 16 forms are instantiated for head dim 72")
-        kernel_choice("attn_variant", {"stream32": 11, "stream64": 12, "stream64_8w": 13}[kernel])
+        kernel_choice("attn_variant", {"stream64": 12, "stream64_8w": 13}[kernel])
     T, dt = 1024, 1
     g = torch.Generator("cpu").manual_seed(spike_key)
     qkv = torch.randn(T, 3 * hd, generator=g)
