@@ -909,24 +909,33 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
     poff[j] = piece_offset(j, 0);
     poff_l[j] = piece_offset(j, nkb - 1);
   }
-  auto stage_piece = [&](int kbk, int kbv, int j) __attribute__((always_inline)) {
+  // the wave-uniform part of an issue group's addresses, formed ONCE per group (as scalar arithmetic per piece it was ~65 SALU
+  // instructions per iteration and wave: 64-bit products of the block index)
+  struct Group { const char* gk; const char* gv; char* dk; char* dv; bool lk, lv; };
+  const char* const blk0 = (const char*)(qkv_h + (size_t)base * ld);
+  const int64_t blk_step = (int64_t)KB * a.row_stride * (int64_t)ld * 2;
+  auto make_group = [&](int kbk, int kbv) __attribute__((always_inline)) -> Group {
+    const int kk = min(kbk, nkb - 1), kv = min(kbv, nkb - 1);
+    return Group{blk0 + kk * blk_step, blk0 + kv * blk_step, kring + (kbk % NS) * KIMG, vring + (kbv % NS) * VIMG, kk == nkb - 1, kv == nkb - 1};
+  };
+  auto stage_piece = [&](const Group& gr, int j) __attribute__((always_inline)) {
     const int pc = min(wave + NWV * j, NPC - 1);
     const bool isv = pc >= 9;
-    const int kb = isv ? kbv : kbk, kb_ld = min(kb, nkb - 1);
-    char* dst = isv ? vring + (kb % NS) * VIMG + (pc - 9) * 1024 : kring + (kb % NS) * KIMG + pc * 1024;
-    const char* blk = (const char*)(qkv_h + (size_t)(base + (int64_t)kb_ld * KB * a.row_stride) * ld);
-    const unsigned off = kb_ld == nkb - 1 ? poff_l[j] : poff[j];
+    char* dst = isv ? gr.dv + (pc - 9) * 1024 : gr.dk + pc * 1024;
+    const char* blk = isv ? gr.gv : gr.gk;
+    const unsigned off = (isv ? gr.lv : gr.lk) ? poff_l[j] : poff[j];
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(blk + off),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   auto stage_group = [&](int kbk, int kbv) __attribute__((always_inline)) {
+    const Group gr = make_group(kbk, kbv);
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) stage_piece(kbk, kbv, j);
+    for (int j = 0; j < NPW; ++j) stage_piece(gr, j);
   };
   // [K(0)] (its pieces only), then G(0..2) here, G(i + 3) in iteration i
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
-    if (wave + NWV * j < 9) stage_piece(0, 0, j);
+    if (wave + NWV * j < 9) stage_piece(make_group(0, 0), j);
   stage_group(1, 0);
   stage_group(2, 1);
   stage_group(3, 2);
@@ -955,7 +964,7 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
   // and pass (128 per block, measured in the listing).  What the compiler does for its own MFMAs is done by hand here: the chain of a
   // (group, tile) accumulates in place (back-to-back srcC = vDst needs no wait state), and its last MFMA carries the 20 wait states
   // a VALU read of a 16-pass result needs -- hidden, the matrix pipe is busy for 32 cycles anyway.
-  auto scores = [&](int kb, int dma_kb) __attribute__((always_inline)) {
+  auto scores = [&](int kb, const Group* dma) __attribute__((always_inline)) {
     const char* kbase = kring + (kb % NS) * KIMG + kread;
     u32x4 kf[2][KS];
     auto load_k = [&](int t, u32x4 (&dst)[KS]) {
@@ -972,12 +981,12 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          if (ABL != 7 && dma_kb >= 0 && g == 0) {   // (the prologue call passes -1: compile-time after inlining)
+          if (ABL != 7 && dma != nullptr && g == 0) {   // (the prologue call passes nullptr: compile-time after inlining)
             if constexpr (NG == 2) {
-              if (ks == 1 && t == 0) stage_piece(dma_kb + 1, dma_kb, 0);   // pieces 0, 1 of G(dma_kb) behind 4 / 12 MFMAs of the phase
-              if (ks == 3 && t == 0) stage_piece(dma_kb + 1, dma_kb, 1);
+              if (ks == 1 && t == 0) stage_piece(*dma, 0);   // pieces 0, 1 of the group behind 4 / 12 MFMAs of the phase
+              if (ks == 3 && t == 0) stage_piece(*dma, 1);
             } else {
-              if (ks == 2 && t == 0) stage_piece(dma_kb + 1, dma_kb, 0);
+              if (ks == 2 && t == 0) stage_piece(*dma, 0);
             }
           }
           if constexpr (NG == 1) {
@@ -1068,7 +1077,7 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
   typedef std::integral_constant<bool, true> yes_t;
   typedef std::integral_constant<bool, false> no_t;
   if (wave_active) {
-    scores(0, -1);
+    scores(0, nullptr);
     softmax_max(0, yes_t{});
 #pragma unroll
     for (int t = 0; t < NT; ++t) softmax_exp(t);
@@ -1087,6 +1096,7 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
       if constexpr (ABL != 7) stage_group(i + 4, i + 3);
       return;
     }
+    const Group gr = make_group(i + 4, i + 3);
     // V^T fragments of P(i)'s first two k-steps are requested before anything else (V(i) has landed): three buffers, two steps ahead
     const char* vbase = vring + (i % NS) * VIMG + vread;
     u32x2 vlo[3][DTL], vhi[3][DTL];
@@ -1101,12 +1111,12 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
           for (int r = 0; r < 16; ++r) o[g][d][r] *= alpha[g];
     }
     if constexpr (MORE) {
-      scores(i + 1, i + 3);
+      scores(i + 1, &gr);
       if constexpr (ABL != 8) softmax_max(i + 1, masked);
     } else {
       if constexpr (ABL != 7) {
-        stage_piece(i + 4, i + 3, 0);
-        if constexpr (NG == 2) stage_piece(i + 4, i + 3, 1);
+        stage_piece(gr, 0);
+        if constexpr (NG == 2) stage_piece(gr, 1);
       }
     }
 #pragma unroll
@@ -1122,9 +1132,9 @@ __global__ void __launch_bounds__(512 / NG) attn_stream64_kernel(AttnArgs a) {
       }
       if constexpr (ABL != 7) {   // the group's remaining pieces between the k-steps
         if constexpr (NG == 2) {
-          if (step < 3) stage_piece(i + 4, i + 3, 2 + step);
+          if (step < 3) stage_piece(gr, 2 + step);
         } else {
-          if (step == 0 || step == 2) stage_piece(i + 4, i + 3, 1 + step / 2);
+          if (step == 0 || step == 2) stage_piece(gr, 1 + step / 2);
         }
       }
       const int t = step >> 1, s2 = step & 1;
