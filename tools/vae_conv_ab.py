@@ -9,7 +9,7 @@ import latte_amd
 from latte_amd import _lib
 from latte_amd.random_init import vae_decoder_state_dict
 lib = _lib.load_library()
-choices = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,5").split(",")]
+choices = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1,3").split(",")]
 dev = torch.device("cuda")
 vae = latte_amd.AutoencoderKL(latent_size=32, max_frames=16, compute_dtype="f16")
 vae.load_state_dict(vae_decoder_state_dict(0))
