@@ -26,13 +26,12 @@ static std::atomic<int> g_debug_choice[DBG_NUM_CHOICES];
 int debug_choice(DebugChoice c) { return g_debug_choice[c].load(std::memory_order_relaxed); }
 int set_debug_choice(const char* name, int value) {
   static const char* const names[DBG_NUM_CHOICES] = {"attn_variant", "xattn_flash", "tn_kernel", "tn_wn", "attn_bwd_tiles", "conv_kernel", "vae_split"};
-  static const int allowed[DBG_NUM_CHOICES][4] = {{1, 5, 12, 13}, {1, 0, 0, 0}, {4, 0, 0, 0}, {4, 0, 0, 0}, {1, 2, 0, 0}, {1, 2, 3, 4}, {0, 0, 0, 0}};   // (conv_kernel 5 / 6: below)
+  static const int allowed[DBG_NUM_CHOICES][4] = {{1, 5, 12, 13}, {1, 0, 0, 0}, {4, 0, 0, 0}, {4, 0, 0, 0}, {1, 2, 0, 0}, {1, 2, 3, 4}, {0, 0, 0, 0}};
   for (int i = 0; i < DBG_NUM_CHOICES; ++i) {
     if (name && std::string(name) == names[i]) {
       bool ok = value == 0;
       for (int k = 0; k < 4; ++k) ok = ok || (allowed[i][k] != 0 && value == allowed[i][k]);
-      ok = ok || (i == DBG_VAE_SPLIT && (value >> 24) == 1);
-      ok = ok || (i == DBG_CONV_KERNEL && (value == 5 || value == 6));   // the halo-staged convolution wherever it applies / nowhere   // (1 << 24) | pass mask (vae_engine.cpp: vae_split_mask)
+      ok = ok || (i == DBG_VAE_SPLIT && (value >> 24) == 1);   // (1 << 24) | pass mask (vae_engine.cpp: vae_split_mask)
 #ifdef LATTE_GEMM_ABLATE
       ok = ok || (i == DBG_ATTN_VARIANT && value >= 7 && value <= 19);   // measurement build: attn_stream ablations (results garbage)
 #endif

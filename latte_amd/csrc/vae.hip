@@ -583,157 +583,6 @@ __global__ void __launch_bounds__(512) conv3x3_pps_kernel(ConvArgs g) {
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 6c: the ping-pong convolution with a HALO-STAGED activation operand.  A workgroup owns a 16 x 16 pixel tile of one image (256
-// pixels x BN output channels, the same eight waves / wave tiles / epilogue as conv3x3_pp_kernel); per 64-channel chunk the 18 x 18
-// pixel patch around the tile is written to LDS ONCE (41 DMA instructions per workgroup, spread over the chunk before) and the nine
-// taps read their fragments out of it at shifted pixel rows -- conv3x3_pp_kernel gathers the 256 pixel rows again for every tap: 32
-// DMA instructions per K tile, four per wave, which at 128 output channels is as much wave-holding issue time as the K tile has MFMA
-// time (the six 128-channel convolutions of the SD-VAE decoder ran at 0.24 of the MFMA peak).  K order: chunk outermost, tap inside
-// (the other kernels run tap outermost: same products, another fp32 summation order -- not bit-identical to them).
-// Patch image: pixel row p = py * 18 + px at p * 128 bytes, its eight 16-byte chunks XOR-swizzled with (p >> 1) & 7 on the DMA's
-// source side.  No upsample, nine taps, H and W multiples of 16 (the launcher sends everything else to conv3x3_pp_kernel).
-template <int BN, int DT>
-__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs g) {
-  constexpr int PW = 18, NPIX = PW * PW, PINSTR = (NPIX * 8 + 63) / 64, PATCH = PINSTR * 1024;   // 324 rows, 41 instructions, 41 KB
-  constexpr int WTN = BN / 4, FN = WTN / 16;
-  constexpr int B_BYTES = BN * 128, OFF_B = 2 * PATCH;
-  constexpr int BG_INSTR = BN / 8 / 4;   // W rows per wave of group 0
-  constexpr int PJ = (PINSTR + 7) / 8;   // patch pieces per wave (6)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2, wn = wave & 3;
-  const int H = g.Hin, W = g.Win;
-  const int K = 9 * g.Cin;
-  const int tiles_x = W >> 4, tiles_img = (H >> 4) * tiles_x;
-  int tm, tn;
-  tile_coords(g.N * tiles_img, g.Cout / BN, tm, tn);
-  const int img = tm / tiles_img, trem = tm - img * tiles_img;
-  const int y0 = (trem / tiles_x) << 4, x0 = (trem % tiles_x) << 4;
-  const int n0 = tn * BN;
-
-  // patch DMA: instruction i = wave + 8 j writes LDS bytes [1024 i, 1024 i + 1024) of the patch buffer; lane l carries chunk slot
-  // (l & 7) of patch pixel p = 8 i + (l >> 3), i.e. the pixel's channel chunk (l & 7) ^ ((p >> 1) & 7); out-of-image pixels and the
-  // rows past the patch get an offset beyond the descriptor's range (zeros)
-  unsigned pvoff[PJ];
-#pragma unroll
-  for (int j = 0; j < PJ; ++j) {
-    const int p = (wave + 8 * j) * 8 + (lane >> 3);
-    const int py = p / PW, px = p - py * PW;
-    const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-    const bool ok = p < NPIX && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    const int schunk = (lane & 7) ^ ((p >> 1) & 7);
-    pvoff[j] = ok ? ((unsigned)((img * H + yy) * W + xx) * (unsigned)g.Cin + (unsigned)(schunk * 8)) * 2u : 0xFFFFFFF0u;
-  }
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.in, 0, (unsigned)((size_t)g.N * H * W * g.Cin * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, (unsigned)((size_t)g.Cout * K * 2), 0x00020000);
-  typedef __attribute__((address_space(3))) void lds_void_c;
-  auto dma_patch_piece = [&](int c, int j) {   // piece j of this wave for channel chunk c
-    if (wave + 8 * j < PINSTR)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_c*)(smem + (c & 1) * PATCH + (wave + 8 * j) * 1024), 16, pvoff[j], (unsigned)(c * 128), 0, 0);
-  };
-  const int lrow = lane >> 3, cpos = lane & 7;
-  const int srow = wn * 8 + lrow;
-  const int schunk_b = cpos ^ ((srow >> 1) & 7);
-  const unsigned voff_b = ((unsigned)srow * (unsigned)K + (unsigned)(schunk_b * 8)) * 2u;
-  const unsigned b_step = 32u * (unsigned)K * 2u;
-  const int cpt = g.Cin >> 6;            // channel chunks
-  const int nk = 9 * cpt;                // K tiles: kt = 9 c + tap
-  auto dma_b_all = [&](int kt) {
-    char* sB = smem + OFF_B + (kt & 1) * B_BYTES + wn * 1024;
-    const int c = kt / 9, tap = kt - 9 * c;
-    const unsigned so = ((unsigned)n0 * (unsigned)K + (unsigned)(tap * g.Cin + c * 64)) * 2u;
-#pragma unroll
-    for (int j = 0; j < BG_INSTR; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_c*)(sB + j * 4 * 1024), 16, voff_b, so + (unsigned)j * b_step, 0, 0);
-  };
-
-  const int frow = lane & 15;
-  const int b_off = (wn * WTN + frow) * 128 + ((lane >> 4) ^ ((lane >> 1) & 7)) * 16;
-  const int kq = lane >> 4;
-
-  f32x4 acc[8][FN];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int j = 0; j < PJ; ++j) dma_patch_piece(0, j);
-  if (grp == 0) dma_b_all(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (nk > 1 && grp == 0) dma_b_all(1);
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger the two groups by one segment
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int c = kt / 9, tap = kt - 9 * c;
-    const char* pbuf = smem + (c & 1) * PATCH;
-    const char* bbuf = smem + OFF_B + (kt & 1) * B_BYTES;
-    u32x4 bf[2][FN], af[2][8];
-    // ---- L(kt): the A fragments of tile row grp * 8 + i, shifted by the tap
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const int pp0 = (grp * 8 + 1 + dy) * PW + 1 + dx + frow;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[ks][j] = *(const u32x4*)(bbuf + ((b_off + j * 2048) ^ (ks << 6)));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int pp = pp0 + PW * i;
-      const int off = pp * 128 + ((kq ^ ((pp >> 1) & 7)) << 4);
-      af[0][i] = *(const u32x4*)(pbuf + off);
-      af[1][i] = *(const u32x4*)(pbuf + (off ^ 64));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- C(kt)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(bf[ks][j], af[ks][i], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own DMA issued one iteration ago (W tile kt + 1, a patch piece) landed
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk && grp == 0) dma_b_all(kt + 2);
-    if (tap >= 2 && tap < 2 + PJ && c + 1 < cpt) dma_patch_piece(c + 1, tap - 2);   // the next chunk's patch, one piece per tap
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance group 1's extra barrier
-
-  const int ncol = n0 + wn * WTN + (lane >> 4) * 4;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t m = (size_t)(img * H + y0 + grp * 8 + i) * W + x0 + frow;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = ncol + j * 16;
-      const float4 b4 = *(const float4*)(g.bias + n);
-      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-      const size_t o = m * g.Cout + n;
-      if (g.out32 != nullptr) {
-        if (g.res32 != nullptr) {
-          const float4 r4 = *(const float4*)(g.res32 + o);
-          v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
-        }
-        *(float4*)(g.out32 + o) = make_float4(v0, v1, v2, v3);
-        continue;
-      }
-      if (g.res != nullptr) {
-        const u32x2 r2 = *(const u32x2*)(g.res + o);
-        float r0, r1, r2f, r3;
-        unpack2<DT>(r2[0], r0, r1);
-        unpack2<DT>(r2[1], r2f, r3);
-        v0 += r0; v1 += r1; v2 += r2f; v3 += r3;
-      }
-      const u32x2 p = {pack2<DT>(v0, v1), pack2<DT>(v2, v3)};
-      *(u32x2*)(g.out + o) = p;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ GroupNorm
 // partial[n][slab][g] = (sum, sumsq) over the slab's pixels and the group's channels.  One thread owns 8 consecutive
 // channels of a pixel (16-byte loads); the per-thread sums are combined in a FIXED order (deterministic).
@@ -1239,7 +1088,6 @@ inline int grid_for(size_t n, int block) {
 
 }  // namespace
 
-constexpr bool HALO_DEFAULT = false;   // (flipped once the halo-staged kernel is measured faster inside the decoders)
 int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* out,
                    const half_t* zeros, int N, int Hin, int Win, int Cin, int Cout, int ups, int dtype, hipStream_t st,
                    const float* res32, float* out32, int taps3) {
@@ -1270,26 +1118,6 @@ int launch_conv3x3(const half_t* in, const half_t* w, const float* bias, const h
       static std::atomic<uint64_t> attr_b{0};
       if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_pps_kernel<128, LATTE_DTYPE_F16>, LDS_PP, attr_b)) return rc_;
       hipLaunchKernelGGL((conv3x3_pps_kernel<128, LATTE_DTYPE_F16>), dim3(nblk), dim3(512), LDS_PP, st, a);
-    }
-    kprof_mark(VC_CONV3, st);
-    LATTE_HIP(hipGetLastError());
-    return LATTE_OK;
-  }
-  // round 6c: the halo-staged form for the plain nine-tap convolutions on maps of whole 16 x 16 tiles (conv_kernel 5 asks for it;
-  // conv_kernel 6 keeps it away where it would be the default)
-  const bool halo_ok = pp_ok && !ups && !taps3 && Hin % 16 == 0 && Win % 16 == 0;
-  if (halo_ok && (debug_choice(DBG_CONV_KERNEL) == 5 || (debug_choice(DBG_CONV_KERNEL) == 0 && HALO_DEFAULT && pp_tiles >= 192))) {
-    constexpr int PATCH_B = 41 * 1024;
-    if (bn == 256) {
-      constexpr int LDS_H = 2 * PATCH_B + 2 * 256 * 128;
-      static std::atomic<uint64_t> attr_ha{0};
-      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_halo_kernel<256, LATTE_DTYPE_F16>, LDS_H, attr_ha)) return rc_;
-      hipLaunchKernelGGL((conv3x3_halo_kernel<256, LATTE_DTYPE_F16>), dim3(pp_tiles), dim3(512), LDS_H, st, a);
-    } else {
-      constexpr int LDS_H = 2 * PATCH_B + 2 * 128 * 128;
-      static std::atomic<uint64_t> attr_hb{0};
-      if (int rc_ = ensure_dynamic_lds((const void*)conv3x3_halo_kernel<128, LATTE_DTYPE_F16>, LDS_H, attr_hb)) return rc_;
-      hipLaunchKernelGGL((conv3x3_halo_kernel<128, LATTE_DTYPE_F16>), dim3(pp_tiles), dim3(512), LDS_H, st, a);
     }
     kprof_mark(VC_CONV3, st);
     LATTE_HIP(hipGetLastError());

@@ -78,10 +78,10 @@ def test_debug_choice_offers_only_implementations_of_the_same_function(lib):
     """Round-3 advisor finding: the launchers read LATTE_* environment variables per launch, among them ablation variants with
     garbage results.  The overrides are an explicit debug entry now (include/latte_amd_debug.h); the product library refuses the
     ablation values (attention variants 7-9, the removed block kernel's 4) and unknown names."""
-    for name, v in (("attn_variant", 4), ("attn_variant", 7), ("attn_variant", 9), ("no_such_choice", 1), ("tn_kernel", 3), ("conv_kernel", 7)):
+    for name, v in (("attn_variant", 4), ("attn_variant", 7), ("attn_variant", 9), ("no_such_choice", 1), ("tn_kernel", 3), ("conv_kernel", 5)):
         assert lib.latte_debug_set_choice(name.encode(), v) != 0, (name, v)
     for name, v in (("attn_variant", 1), ("attn_variant", 5), ("xattn_flash", 1), ("tn_kernel", 4), ("tn_wn", 4), ("attn_bwd_tiles", 1), ("attn_bwd_tiles", 2),
-                    ("conv_kernel", 1), ("conv_kernel", 2), ("conv_kernel", 3), ("conv_kernel", 4), ("conv_kernel", 5), ("conv_kernel", 6)):
+                    ("conv_kernel", 1), ("conv_kernel", 2), ("conv_kernel", 3), ("conv_kernel", 4)):
         assert lib.latte_debug_set_choice(name.encode(), v) == 0, (name, v)
         assert lib.latte_debug_set_choice(name.encode(), 0) == 0
 
