@@ -24,7 +24,11 @@ def main():
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="f16", choices=["f16"])
+    ap.add_argument("--attn-variant", type=int, default=0, help="latte_debug_set_choice(\"attn_variant\", v) for the whole run (12 / 13: the round-6c L > 256 kernels)")
     a = ap.parse_args()
+    if a.attn_variant:
+        from latte_amd import _lib
+        assert _lib.load_library().latte_debug_set_choice(b"attn_variant", a.attn_variant) == 0
     sd = t2v_state_dict(0, num_layers=a.layers)
     m = latte_amd.LatteT2V(num_layers=a.layers, compute_dtype=a.dtype, max_batch=a.batch).load_state_dict(sd).to("cuda")
     B = a.batch
